@@ -1,0 +1,22 @@
+// Shared helpers for the gfx950 kernels of libsis3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sis3d.h"
+
+#define SIS3D_WAVE 64
+
+void sis3d_record_hip_error(hipError_t e);
+
+static inline int sis3d_check_launch()
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        sis3d_record_hip_error(e);
+        return SIS3D_ELAUNCH;
+    }
+    return SIS3D_OK;
+}
+
+static inline hipStream_t as_stream(sis3d_stream_t s) { return (hipStream_t)s; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,355 @@
+// Dense 3D convolution for the 3D-SIS backbone / RPN / mask head on gfx950 (CDNA4).
+//
+// Replaces the cuDNN calls behind nn.Conv3d(k in {1, 2/s2, 3/p1}) + bias + ReLU + residual
+// add + sigmoid of lib/nets/backbones.py:17-40,171-287 and lib/nets/network.py:38-47,537-574.
+//
+// Formulation: implicit GEMM  D[voxel][cout] = sum_{tap,cin} A[voxel+tap][cin] * W[tap][cin][cout]
+// on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the fp32
+// roof of the chip, bitwise an fmaf chain -> well inside the 1e-4 logit tolerance).
+//
+//  * Activations are channels-last (x,y,z,c).  A workgroup owns a BX x BY x BZ brick of output
+//    voxels; the input halo brick for one CK-channel chunk is staged ONCE in LDS with fully
+//    coalesced 16 B loads and then serves all 27 (8, 1) taps: a tap is just a constant row offset
+//    into the LDS image, so there is no im2col buffer and no re-read of the input from L2.
+//  * A fragments: the MFMA wants A[i = lane&31][k = lane>>5]; the K order inside a group of 8
+//    channels is permuted so that lane l consumes channels 4*(l>>5)..+3 in four consecutive
+//    MFMAs -> one ds_read_b128 per four MFMAs.  LDS rows are padded to CK+4 floats: row stride
+//    = 9 (17) x 16 B, odd, so the 16-lane groups of ds_read_b128 spread over all 16 bank slots.
+//  * B fragments never touch LDS: weights are repacked once into "fragment order"
+//    [cout/32][tap][cin/8][lane][4], so each wave reads exactly the 1 KiB it needs per group of
+//    four MFMAs with one fully coalesced global_load_dwordx4 (L1/L2-resident: all waves of a
+//    workgroup with the same cout tile hit the same lines), prefetched one tap ahead in
+//    registers.  No barrier is needed per tap, only one pair per CK-channel chunk.
+//  * Epilogue fused: + bias, + residual, ReLU / sigmoid, channel-offset write (torch.cat of the
+//    colour and geometry branches), and the RPN head's permute/view into the
+//    (2,X,Y,Z,A) score and (X,Y,Z,6A) bbox layouts.
+//
+// This file may use FMA freely (fp32 tolerance 1e-4 applies, not bit-exactness).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvArgs {
+    const float *in;
+    int X, Y, Z;          // input grid
+    int cin, cin_stride;
+    const float *wp;      // packed weights
+    const float *bias;
+    int cout, ntiles;     // ntiles = ceil(cout/32)
+    int OX, OY, OZ;       // output grid
+    int flags;
+    const float *res;
+    int res_stride;
+    float *out;
+    int out_stride, out_coff;
+    float *out2;
+    int anchors;
+    int nbx, nby, nbz;    // bricks per axis
+    int ngroups;          // cout groups per brick
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// KS: kernel size (1,2,3); S: stride; brick BX*BY*BZ = 32*MW output voxels; NW waves along cout, each NTW
+// 32-wide cout tiles; CK channels per LDS chunk.
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int NTW, int CK>
+__global__ __launch_bounds__(64 * MW *NW) void conv3d_mfma_kernel(const ConvArgs a)
+{
+    static_assert(BX * BY * BZ == 32 * MW, "brick must hold 32*MW voxels");
+    constexpr int T = KS * KS * KS;
+    constexpr int PAD = (KS == 3) ? 1 : 0;
+    constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
+    constexpr int ROWS = IBX * IBY * IBZ;
+    constexpr int RS = CK + 4;                 // padded LDS row stride (floats)
+    constexpr int KGC = CK / 8;                // k-groups (8 channels) per chunk
+    constexpr int NTHREADS = 64 * MW * NW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [ROWS][RS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mw = wave % MW, nw = wave / MW;
+    const int li = lane & 31, kh = lane >> 5;
+
+    // block -> (brick, cout group); bricks vary fastest so neighbouring blocks share weight tiles in L2
+    int bid = blockIdx.x;
+    const int nbricks = a.nbx * a.nby * a.nbz;
+    const int group = bid / nbricks;
+    bid -= group * nbricks;
+    const int bz = bid % a.nbz, by = (bid / a.nbz) % a.nby, bx = bid / (a.nbz * a.nby);
+    const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;           // output brick origin
+    const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD, iz0 = oz0 * S - PAD;
+
+    // this lane's A row (output voxel m of the brick)
+    const int m = 32 * mw + li;
+    const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+    const int arow = ((S * lx) * IBY + S * ly) * IBZ + S * lz;
+    const float *aptr = lds + arow * RS + 4 * kh;
+
+    const int tile0 = (group * NW + nw) * NTW;                       // first 32-wide cout tile of this wave
+    const int kgtot = a.cin / 8;
+    const int nchunks = a.cin / CK;
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    float4 bcur[NTW][KGC], bnxt[NTW][KGC];
+    auto load_b = [&](float4(&dst)[NTW][KGC], int q, int tap) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int tile = min(tile0 + t, a.ntiles - 1);           // clamp: surplus tiles recompute the last one, never stored
+            const float4 *p = reinterpret_cast<const float4 *>(a.wp) + ((size_t)(tile * T + tap) * kgtot + q * KGC) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) dst[t][g] = p[g * 64];
+        }
+    };
+    load_b(bcur, 0, 0);
+
+    for (int q = 0; q < nchunks; ++q) {
+        if (q) __syncthreads();
+        // ---- stage the halo brick of chunk q: ROWS rows x CK floats, 16 B per thread, coalesced
+        for (int idx = tid; idx < ROWS * (CK / 4); idx += NTHREADS) {
+            const int row = idx / (CK / 4), c4 = idx % (CK / 4);
+            const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
+            const int gx = ix0 + hx, gy = iy0 + hy, gz = iz0 + hz;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z)
+                v = *reinterpret_cast<const float4 *>(a.in + ((size_t)(gx * a.Y + gy) * a.Z + gz) * a.cin_stride + q * CK + c4 * 4);
+            *reinterpret_cast<float4 *>(lds + row * RS + c4 * 4) = v;
+        }
+        __syncthreads();
+        // ---- 27 / 8 / 1 taps out of the same LDS image
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            // prefetch the next tap's (or next chunk's first) weight fragments
+            const bool last = (tap == T - 1);
+            if (!last) load_b(bnxt, q, tap + 1);
+            else if (q + 1 < nchunks) load_b(bnxt, q + 1, 0);
+            const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
+            const float *ap = aptr + ((dx * IBY + dy) * IBZ + dz) * RS;
+            float4 af[KGC];
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) af[g] = *reinterpret_cast<const float4 *>(ap + 8 * g);
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bcur[t][g].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bcur[t][g].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bcur[t][g].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bcur[t][g].w, acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) bcur[t][g] = bnxt[t][g];
+        }
+    }
+
+    // ---- epilogue.  D layout: column (cout) = lane&31, row (voxel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int64_t nvox_out = (int64_t)a.OX * a.OY * a.OZ;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tile = tile0 + t;
+        if (tile >= a.ntiles) continue;
+        const int co = tile * 32 + li;
+        if (co >= a.cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
+            if (ox >= a.OX || oy >= a.OY || oz >= a.OZ) continue;
+            const int64_t vox = ((int64_t)ox * a.OY + oy) * a.OZ + oz;
+            float v = acc[t][r] + bv;
+            if (a.flags & SIS3D_EPI_RESIDUAL) v += a.res[vox * a.res_stride + co];
+            if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
+            if (a.flags & SIS3D_EPI_SIGMOID) v = sigmoidf_(v);
+            if (a.flags & SIS3D_EPI_RPN_HEAD) {
+                const int A = a.anchors;
+                if (co < 2 * A) a.out[((int64_t)(co / A) * nvox_out + vox) * A + (co % A)] = v;
+                else a.out2[vox * (6 * A) + (co - 2 * A)] = v;
+            } else {
+                a.out[vox * a.out_stride + a.out_coff + co] = v;
+            }
+        }
+    }
+}
+
+// ---- weight repack: (Cout,Cin,k,k,k) -> [cout/32][tap][cin8/8][lane 64][4] -------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int cout, int cin, int T, int ntiles,
+                                                          int kgtot, float *__restrict__ packed)
+{
+    const int64_t total = (int64_t)ntiles * T * kgtot * 256;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        int64_t rest = idx >> 8;
+        const int kg = (int)(rest % kgtot);
+        rest /= kgtot;
+        const int tap = (int)(rest % T), tile = (int)(rest / T);
+        const int co = tile * 32 + (lane & 31);
+        const int ci = 8 * kg + 4 * (lane >> 5) + e;
+        float v = 0.0f;
+        if (co < cout && ci < cin) v = w[((int64_t)co * cin + ci) * T + tap];
+        packed[idx] = v;
+    }
+}
+
+// ---- first layers on the planar 2-channel grid (VALU: K = 16 / 54 is too thin for the matrix pipe) ------
+// thread = (output voxel, 4 consecutive couts); weights transposed into LDS as [ci*T+tap][cout]
+template <int KS, int S>
+__global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restrict__ in, int64_t is_c, int64_t is_x, int64_t is_y,
+                                                           int x0, int y0, int z0, int WX, int WY, int WZ, int OX, int OY, int OZ,
+                                                           const float *__restrict__ w, int cout, int flags,
+                                                           float *__restrict__ out, int out_stride)
+{
+    constexpr int T = KS * KS * KS, PAD = (KS == 3) ? 1 : 0, K = 2 * T;
+    extern __shared__ __attribute__((aligned(16))) float wl[];     // [K][cout]
+    for (int i = threadIdx.x; i < K * cout; i += blockDim.x) {
+        const int co = i % cout, k = i / cout;                     // k = ci*T + tap
+        wl[i] = w[(int64_t)co * K + k];
+    }
+    __syncthreads();
+    const int cq = cout / 4;
+    const int64_t total = (int64_t)OX * OY * OZ * cq;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % cq) * 4;
+        const int64_t v = t / cq;
+        const int oz = (int)(v % OZ), oy = (int)((v / OZ) % OY), ox = (int)(v / ((int64_t)OZ * OY));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+                    for (int dz = 0; dz < KS; ++dz) {
+                        const int wx = ox * S + dx - PAD, wy = oy * S + dy - PAD, wz = oz * S + dz - PAD;   // window coords
+                        float xv = 0.0f;
+                        if (wx >= 0 && wx < WX && wy >= 0 && wy < WY && wz >= 0 && wz < WZ)
+                            xv = in[ci * is_c + (int64_t)(x0 + wx) * is_x + (int64_t)(y0 + wy) * is_y + (z0 + wz)];
+                        const float4 wv = *reinterpret_cast<const float4 *>(wl + (ci * T + (dx * KS + dy) * KS + dz) * cout + c4);
+                        acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+                        acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+                    }
+        if (flags & SIS3D_EPI_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4 *>(out + v * out_stride + c4) = acc;
+    }
+}
+
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int NTW, int CK>
+int launch_cfg(ConvArgs &a, hipStream_t st)
+{
+    constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
+    constexpr size_t lds = (size_t)IBX * IBY * IBZ * (CK + 4) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS brick too large");
+    a.nbx = cdiv(a.OX, BX); a.nby = cdiv(a.OY, BY); a.nbz = cdiv(a.OZ, BZ);
+    a.ngroups = cdiv(a.ntiles, NW * NTW);
+    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, NTW, CK>;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    }
+    const int64_t blocks = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * MW * NW), lds, st, a);
+    return sis3d_check_launch();
+}
+
+// pick the tiling so that a launch has >= ~1k waves where the layer allows it (256 CUs x 4 SIMDs)
+template <int KS, int S>
+int dispatch(ConvArgs &a, hipStream_t st)
+{
+    const int64_t nvox = (int64_t)a.OX * a.OY * a.OZ;
+    const int ck = (a.cin % 32 == 0) ? 32 : 8;
+    if (a.cin % 8) return SIS3D_EUNSUPPORTED;
+    const bool big = nvox >= 32768;            // 48x24x48-class layers
+    if constexpr (S == 2) {
+        // k2 s2: input brick is 2x the output brick per axis; keep it small
+        if (ck == 32) {
+            if (a.ntiles >= 4) return launch_cfg<KS, S, 2, 4, 4, 1, 4, 1, 32>(a, st);
+            if (a.ntiles >= 2) return launch_cfg<KS, S, 2, 4, 4, 1, 2, 1, 32>(a, st);
+            return launch_cfg<KS, S, 4, 4, 4, 2, 1, 1, 32>(a, st);
+        }
+        return launch_cfg<KS, S, 2, 4, 4, 1, 2, 1, 8>(a, st);
+    } else {
+    if (ck == 8) {
+        if (a.ntiles >= 2) return launch_cfg<KS, S, 4, 4, 4, 2, 2, 1, 8>(a, st);
+        return launch_cfg<KS, S, 4, 4, 8, 4, 1, 1, 8>(a, st);
+    }
+    if (big) {
+        if (a.ntiles >= 2) return launch_cfg<KS, S, 4, 4, 8, 4, 1, 2, 32>(a, st);
+        return launch_cfg<KS, S, 4, 4, 8, 4, 1, 1, 32>(a, st);
+    }
+    // small volumes (24x12x24, mask crops): 64-voxel bricks, 32x32 per wave for occupancy
+    if (a.ntiles >= 2) return launch_cfg<KS, S, 4, 4, 4, 2, 2, 1, 32>(a, st);
+    return launch_cfg<KS, S, 4, 4, 4, 2, 1, 1, 32>(a, st);
+    }
+}
+
+} // namespace
+
+extern "C" size_t sis3d_conv_packed_floats(int cout, int cin, int ksize)
+{
+    const size_t ntiles = (cout + 31) / 32, kg = (cin + 7) / 8, T = (size_t)ksize * ksize * ksize;
+    return ntiles * T * kg * 256;
+}
+
+extern "C" int sis3d_conv_pack_weight(const float *w, int cout, int cin, int ksize, float *packed, sis3d_stream_t stream)
+{
+    if (!w || !packed || cout <= 0 || cin <= 0 || ksize < 1 || ksize > 3) return SIS3D_EINVAL;
+    const int T = ksize * ksize * ksize, ntiles = (cout + 31) / 32, kgtot = (cin + 7) / 8;
+    const int64_t total = (int64_t)ntiles * T * kgtot * 256;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0,
+                       as_stream(stream), w, cout, cin, T, ntiles, kgtot, packed);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                            int cout, int ksize, int stride, int flags, const float *residual, int res_stride, float *out,
+                            int out_stride, int out_coff, float *out2, int anchors, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
+    if ((cin % 8) || (cin_stride % 4) || cin_stride < cin) return SIS3D_EINVAL;
+    if ((flags & SIS3D_EPI_RESIDUAL) && !residual) return SIS3D_EINVAL;
+    if ((flags & SIS3D_EPI_RPN_HEAD) && (!out2 || anchors <= 0 || cout != 8 * anchors)) return SIS3D_EINVAL;
+    ConvArgs a;
+    a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
+    a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = (cout + 31) / 32;
+    a.flags = flags; a.res = residual; a.res_stride = res_stride;
+    a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = out2; a.anchors = anchors;
+    hipStream_t st = as_stream(stream);
+    if (ksize == 1 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<1, 1>(a, st); }
+    if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
+    if (ksize == 2 && stride == 2) { a.OX = X / 2; a.OY = Y / 2; a.OZ = Z / 2; if (!a.OX || !a.OY || !a.OZ) return SIS3D_EINVAL; return dispatch<2, 2>(a, st); }
+    return SIS3D_EUNSUPPORTED;
+}
+
+extern "C" int sis3d_conv3d_planar2(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, int X, int Y, int Z, int x0, int y0,
+                                    int z0, int OX, int OY, int OZ, const float *w, int cout, int ksize, int flags, float *out,
+                                    int out_stride, sis3d_stream_t stream)
+{
+    if (!in || !w || !out || OX <= 0 || OY <= 0 || OZ <= 0 || cout <= 0 || (cout % 4) || out_stride < cout || (out_stride % 4))
+        return SIS3D_EINVAL;
+    const int S = ksize == 2 ? 2 : 1;
+    const int WX = OX * S, WY = OY * S, WZ = OZ * S;                 // window of the grid this call reads
+    if (x0 < 0 || y0 < 0 || z0 < 0 || x0 + WX > X || y0 + WY > Y || z0 + WZ > Z) return SIS3D_EINVAL;
+    const int64_t total = (int64_t)OX * OY * OZ * (cout / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t st = as_stream(stream);
+    if (ksize == 2) {
+        hipLaunchKernelGGL((conv_planar2_kernel<2, 2>), dim3(blocks), dim3(256), sizeof(float) * 16 * cout, st, in, is_c, is_x, is_y,
+                           x0, y0, z0, WX, WY, WZ, OX, OY, OZ, w, cout, flags, out, out_stride);
+    } else if (ksize == 3) {
+        hipLaunchKernelGGL((conv_planar2_kernel<3, 1>), dim3(blocks), dim3(256), sizeof(float) * 54 * cout, st, in, is_c, is_x, is_y,
+                           x0, y0, z0, WX, WY, WZ, OX, OY, OZ, w, cout, flags, out, out_stride);
+    } else {
+        return SIS3D_EUNSUPPORTED;
+    }
+    return sis3d_check_launch();
+}

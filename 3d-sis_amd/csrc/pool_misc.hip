@@ -1,0 +1,87 @@
+// MaxPool3d(3,1,1) and layout helpers, channels-last, gfx950.
+//
+// Replaces nn.MaxPool3d(3,1,1) (lib/nets/backbones.py:206,210,220).  With channels-last
+// activations a voxel is one contiguous C-float row, so each of the 27 taps is a fully
+// coalesced 16 B/lane read served by L1/L2 (the maps are <= 3.5 MB); out-of-range taps are
+// skipped, which is the -inf padding of the reference.
+#include "common.h"
+#include <float.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool3_kernel(const float4 *__restrict__ in, int X, int Y, int Z, int C4,
+                                                       float4 *__restrict__ out)
+{
+    const int64_t total = (int64_t)X * Y * Z * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4);
+        const int64_t v = t / C4;
+        const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((int64_t)Z * Y));
+        float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+        m.x = m.y = m.z = m.w = -__builtin_huge_valf();
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= X) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= Y) continue;
+                for (int dz = -1; dz <= 1; ++dz) {
+                    const int zz = z + dz;
+                    if (zz < 0 || zz >= Z) continue;
+                    const float4 f = in[(((int64_t)xx * Y + yy) * Z + zz) * C4 + c];
+                    m.x = fmaxf(m.x, f.x); m.y = fmaxf(m.y, f.y); m.z = fmaxf(m.z, f.z); m.w = fmaxf(m.w, f.w);
+                }
+            }
+        }
+        out[t] = m;
+    }
+}
+
+// [rows][cols] -> [cols][rows] tiled transpose; the large dimension is mapped to gridDim.x
+template <bool ROWS_ON_X>
+__global__ void transpose_kernel(const float *__restrict__ src, int64_t rows, int64_t cols, float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const int64_t r0 = (int64_t)(ROWS_ON_X ? blockIdx.x : blockIdx.y) * 32;
+    const int64_t c0 = (int64_t)(ROWS_ON_X ? blockIdx.y : blockIdx.x) * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t r = r0 + j;
+        const int64_t c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? src[r * cols + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t c = c0 + j;
+        const int64_t r = r0 + threadIdx.x;
+        if (r < rows && c < cols) dst[c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+} // namespace
+
+extern "C" int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream)
+{
+    if (!in || !out || X <= 0 || Y <= 0 || Z <= 0 || C <= 0 || (C % 4)) return SIS3D_EINVAL;
+    const int64_t total = (int64_t)X * Y * Z * (C / 4);
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    hipLaunchKernelGGL(maxpool3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4 *)in, X, Y, Z, C / 4,
+                       (float4 *)out);
+    return sis3d_check_launch();
+}
+
+// planar (C, nvox) -> channels-last (nvox, C): a transpose of a [C][nvox] matrix
+extern "C" int sis3d_planar_to_cl(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream)
+{
+    if (!in || !out || C <= 0 || nvox <= 0) return SIS3D_EINVAL;
+    hipLaunchKernelGGL((transpose_kernel<false>), dim3(cdiv(nvox, 32), cdiv(C, 32)), dim3(32, 8), 0, as_stream(stream), in,
+                       (int64_t)C, nvox, out);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_cl_to_planar(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream)
+{
+    if (!in || !out || C <= 0 || nvox <= 0) return SIS3D_EINVAL;
+    hipLaunchKernelGGL((transpose_kernel<true>), dim3(cdiv(nvox, 32), cdiv(C, 32)), dim3(32, 8), 0, as_stream(stream), in, nvox,
+                       (int64_t)C, out);
+    return sis3d_check_launch();
+}

@@ -1,0 +1,70 @@
+"""ctypes binding of libsis3d_hip.so (the C-ABI drop-in boundary, include/sis3d.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsis3d_hip.so")
+
+c_int, c_i64, c_f32, c_sz, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes): exactly the declarations of include/sis3d.h
+SIGNATURES = {
+    "sis3d_abi_version": (c_int, []),
+    "sis3d_strerror": (ctypes.c_char_p, [c_int]),
+    "sis3d_last_hip_error": (ctypes.c_char_p, []),
+    "sis3d_nms_workspace_bytes": (c_sz, [c_int]),
+    "sis3d_nms": (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sis3d_nms_mask": (c_int, [c_vp, c_int, c_f32, c_vp, c_vp]),
+    "sis3d_nms_select": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sis3d_roi_pool_forward": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int,
+                                       c_int, c_f32, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "sis3d_roi_pool_levels": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_int,
+                                      c_int, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "sis3d_projection_forward": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "sis3d_project_views_workspace_bytes": (c_sz, [c_int, c_int, c_i64, c_i64]),
+    "sis3d_project_views_max": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64,
+                                        c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "sis3d_proposal_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "sis3d_softmax2": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "sis3d_conv_packed_floats": (c_sz, [c_int, c_int, c_int]),
+    "sis3d_conv_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "sis3d_conv3d": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
+                             c_int, c_int, c_vp, c_int, c_vp]),
+    "sis3d_conv3d_planar2": (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "sis3d_maxpool3d_3x3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "sis3d_planar_to_cl": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
+    "sis3d_cl_to_planar": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class Sis3dError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library or fail loudly -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Sis3dError("libsis3d_hip.so is not built (%s). Run `python 3d-sis_amd/build.py` "
+                             "or __graft_entry__.build(); sis3d has no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        l = lib()
+        raise Sis3dError("%s failed: %s (%d) hip: %s" % (what, l.sis3d_strerror(rc).decode(), rc,
+                                                         l.sis3d_last_hip_error().decode()))

@@ -1,0 +1,198 @@
+"""Mirror of lib/nets/backbones.py: same class names, module tree and parameter names / shapes
+(the checkpoint contract), forward on the HIP kernels.
+
+Modules are ordinary nn.Module parameter holders (so load_state_dict / state_dict work as in the
+reference) whose forward enqueues hand-written gfx950 kernels on channels-last activations; ReLU,
+bias, residual add and the colour/geometry concat are fused into the producing conv's epilogue.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import cfg as _default_cfg
+from .network import Network
+
+
+class _Packed(object):
+    """lazy repack cache, refreshed when the parameter is modified or replaced"""
+
+    def __init__(self):
+        self.pc = None
+
+    def get(self, conv, cin_pad=None):
+        w, b = conv.weight, conv.bias
+        ver = (w._version, None if b is None else b._version, w.data_ptr())
+        if self.pc is None or self.pc.version != ver:
+            self.pc = ops.PackedConv(w, b, cin_pad)
+        return self.pc
+
+
+class HipConv3d(nn.Conv3d):
+    """nn.Conv3d parameters, HIP forward.  k in {1, 3 (pad 1), 2 (stride 2)}; fuse_relu folds the
+    following nn.ReLU into the epilogue."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=True, fuse_relu=False, fuse_sigmoid=False):
+        super().__init__(cin, cout, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.fuse_relu, self.fuse_sigmoid = fuse_relu, fuse_sigmoid
+        self._packed = _Packed()
+
+    def forward(self, x, residual=None, out=None, out_coff=0):
+        k, s = self.kernel_size[0], self.stride[0]
+        if self.in_channels == 2 and x.shape[1] == 2 and not ops.is_cl(x):
+            y = ops.conv3d_planar2(x, self.weight, k, relu=self.fuse_relu)
+            if self.bias is not None:
+                raise ops._lib.Sis3dError("planar first-layer conv has no bias in the reference")
+            return y
+        x = ops.to_cl(x)
+        return ops.conv3d(x, self._packed.get(self), stride=s, relu=self.fuse_relu, residual=residual,
+                          sigmoid=self.fuse_sigmoid, out=out, out_coff=out_coff)
+
+
+class FusedReLU(nn.Module):
+    """Placeholder that keeps the nn.Sequential indices of the reference (geometry1.1, .5, ...);
+    the ReLU itself runs in the producing conv's epilogue."""
+
+    def forward(self, x):
+        return x
+
+
+class HipMaxPool3d(nn.Module):
+    """nn.MaxPool3d(3,1,1)"""
+
+    def forward(self, x):
+        return ops.maxpool3(ops.to_cl(x))
+
+
+class Bottleneck(nn.Module):
+    """backbones.py:17-40: relu(conv3(relu(conv2(relu(conv1(x))))) + x)"""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = HipConv3d(inplanes, planes, 1, stride=stride, fuse_relu=True)
+        self.conv2 = HipConv3d(planes, planes, 3, stride=1, padding=1, fuse_relu=True)
+        self.conv3 = HipConv3d(planes, inplanes, 1, fuse_relu=True)   # ReLU after the residual add
+        self.relu = FusedReLU()
+        self.stride = stride
+
+    def forward(self, x, out=None, out_coff=0):
+        x = ops.to_cl(x)
+        y = self.conv1(x)
+        y = self.conv2(y)
+        return self.conv3(y, residual=x, out=out, out_coff=out_coff)
+
+
+def _conv_relu(cin, cout, k, stride=1, padding=0):
+    return [HipConv3d(cin, cout, k, stride=stride, padding=padding, bias=False, fuse_relu=True), FusedReLU()]
+
+
+class Base_Backbone(Network):
+    def __init__(self, obbox=True, cfg=None):
+        super().__init__(cfg)
+        self._feat_stride = [4, 4, 4]
+        self._fc7_channels = 128
+        self._net_conv_level1_channels = 128
+        self._net_conv_level2_channels = 128
+        self._net_conv_level3_channels = 128
+
+    def _make_classifier(self):
+        ps = self.cfg.CLASS_POOLING_SIZE
+        return nn.Sequential(nn.Linear(self._net_conv_level1_channels * ps * ps * ps, 256), nn.ReLU(True),
+                             nn.Linear(256, 256), nn.ReLU(True), nn.Linear(256, 128), nn.ReLU(True))
+
+    # backbones.py:98-113
+    def _backbone(self):
+        cfg = self.cfg
+        if cfg.USE_IMAGES and cfg.ONLY_IMAGES:
+            l1 = self.color(self._imageft)
+        elif cfg.USE_IMAGES:
+            # torch.cat([color, geometry], 1) (backbones.py:109): the last geometry Bottleneck writes its
+            # channel range of the concatenated tensor directly (conv epilogue channel offset)
+            col = self.color(self._imageft)
+            mods = list(self.geometry1)
+            g = self._scene
+            for m in mods[:-1]:
+                g = m(g)
+            cc, gc = col.shape[1], mods[-1].conv3.out_channels
+            l1 = ops.new_act(cc + gc, col.shape[2:], col.device)
+            l1[:, :cc] = col
+            mods[-1](g, out=l1, out_coff=cc)
+        else:
+            l1 = self.geometry1(self._scene)
+        l2 = self.geometry2(l1)
+        return l1, l2, None
+
+
+class SUNCG_Backbone(Base_Backbone):
+    """backbones.py:118-169"""
+
+    def _init_backbone_classifier(self):
+        cfg = self.cfg
+        if not cfg.ONLY_IMAGES or not cfg.USE_IMAGES:
+            self.geometry1 = nn.Sequential(*_conv_relu(2, 64, 2, 2), Bottleneck(64, 32), *_conv_relu(64, 64, 2, 2), Bottleneck(64, 32))
+        if cfg.USE_IMAGES:
+            self.color = nn.Sequential(*_conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 2, 2), Bottleneck(64, 32),
+                                       *_conv_relu(64, 64, 2, 2), Bottleneck(64, 32))
+        if cfg.USE_IMAGES and cfg.ONLY_IMAGES:
+            cin = 64
+        elif cfg.USE_IMAGES:
+            cin = 128
+        else:
+            cin = 64
+        self.geometry2 = nn.Sequential(*_conv_relu(cin, 128, 3, 1, 1), Bottleneck(128, 64))
+        self.classifier = self._make_classifier()
+
+
+class ScanNet_Backbone(Base_Backbone):
+    """backbones.py:171-231"""
+
+    def _init_backbone_classifier(self):
+        cfg = self.cfg
+        if cfg.ONLY_IMAGES:
+            gc, cc = 0, 128
+        elif cfg.USE_IMAGES:
+            gc, cc = 64, 64
+        else:
+            gc, cc = 128, 0
+        if not cfg.ONLY_IMAGES or not cfg.USE_IMAGES:
+            self.geometry1 = nn.Sequential(*_conv_relu(2, 32, 2, 2), Bottleneck(32, 32), Bottleneck(32, 32),
+                                           *_conv_relu(32, gc, 2, 2), Bottleneck(gc, 32), Bottleneck(gc, 32))
+        if cfg.USE_IMAGES:
+            self.color = nn.Sequential(*_conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 2, 2), Bottleneck(64, 32), HipMaxPool3d(),
+                                       *_conv_relu(64, cc, 2, 2), Bottleneck(cc, 32), HipMaxPool3d())
+        self.geometry2 = nn.Sequential(*_conv_relu(gc + cc, 128, 3, 1, 1), Bottleneck(128, 64), Bottleneck(128, 64), HipMaxPool3d())
+        self.classifier = self._make_classifier()
+
+
+class MaskBackbone(nn.Module):
+    """backbones.py:236-287 (geometry-only mask head; MASK_USE_IMAGES variants are not on the benchmark path)."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg or _default_cfg
+        if cfg.MASK_USE_IMAGES or cfg.MASK_ONLY_IMAGES:
+            raise NotImplementedError("MASK_USE_IMAGES / MASK_ONLY_IMAGES are outside the ScanNet benchmark path")
+        mods = _conv_relu(2, 64, 3, 1, 1)
+        for _ in range(4):
+            mods += _conv_relu(64, 64, 3, 1, 1)
+        mods.append(HipConv3d(64, cfg.NUM_CLASSES, 1, bias=False))
+        self.geometry = nn.Sequential(*mods)
+
+    def forward(self, scene, imageft=None, window=None):
+        """scene: (1,2,dx,dy,dz) crop (any view of the planar grid with contiguous z), or the full grid +
+        window=(x0,y0,z0,x1,y1,z1).  Returns logical (1,NUM_CLASSES,dx,dy,dz); sigmoid in eval mode."""
+        g = self.geometry
+        x = ops.conv3d_planar2(scene, g[0].weight, 3, relu=True, window=window)
+        for i in (2, 4, 6, 8):
+            x = g[i](x)
+        last = g[10]
+        last.fuse_sigmoid = not self.training
+        return last(x)
+
+
+def state_dict_shapes(cfg=None):
+    """{name: shape} of the checkpoint for cfg (meta-device build: no allocation, no RNG use)."""
+    cfg = cfg or _default_cfg
+    with torch.device("meta"):
+        net = globals()[cfg.NET](cfg=cfg)
+        net.init_modules()
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}

@@ -1,0 +1,193 @@
+"""Mirror of lib/nets/network.py for the TEST branch (forward, lines 187-317).
+
+Same public surface as the reference's `Network`: `init_modules()`, `forward(blobs, mode,
+killing_inds)`, `_predictions{}`, `_scene_info`, `mask_backbone`, `delete_intermediate_states()`,
+and the same parameter tree.  Host code stays Python; every hot op is a HIP kernel launch on
+the current stream.  Between the H2D copy of the chunk and the single 4-byte read of the RoI
+count there is NO host synchronisation (the reference has three: NMS mask D2H, .nonzero() in
+_roi_pool_layer, .cpu().numpy() in the mask branch -- SURVEY.md 3.1).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..config import anchor_sizes, cfg as _default_cfg
+from ..layer_utils.generate_anchors import anchors_for_level
+from ..layer_utils.proposal_layer import ProposalEngine
+
+
+class Network(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.cfg = cfg or _default_cfg
+        self._predictions = {}
+        self._anchor_targets = {}
+        self._proposal_targets = {}
+        self._mask_targets = {}
+        self._losses = {}
+        self._proposals = ProposalEngine(self.cfg)
+        self._head_cache = {}
+
+    # network.py:35-64
+    def init_modules(self):
+        from . import backbones
+        cfg = self.cfg
+        self._init_backbone_classifier()
+        if cfg.USE_RPN:
+            for lv, ch in ((1, self._net_conv_level1_channels), (2, self._net_conv_level2_channels),
+                           (3, self._net_conv_level3_channels)):
+                A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
+                if A != 0:
+                    setattr(self, "rpn_net_level%d" % lv, backbones.HipConv3d(ch, cfg.RPN_CHANNELS, 3, padding=1, fuse_relu=True))
+                    setattr(self, "rpn_cls_score_net_level%d" % lv, nn.Sequential(nn.Conv3d(cfg.RPN_CHANNELS, A * 2, 1)))
+                    setattr(self, "rpn_bbox_pred_net_level%d" % lv, nn.Conv3d(cfg.RPN_CHANNELS, A * 6, 1))
+        if cfg.USE_CLASS:
+            self.classifier_cls_score_net = nn.Linear(self._fc7_channels, cfg.NUM_CLASSES)
+            self.classifier_bbox_pred_net = nn.Linear(self._fc7_channels, cfg.NUM_CLASSES * 6)
+        if cfg.USE_MASK:
+            self.mask_backbone = getattr(backbones, cfg.MASK_BACKBONE)(cfg=cfg)
+        if cfg.USE_IMAGES and not cfg.USE_IMAGES_GT:
+            raise NotImplementedError("ENet (lib/nets/enet.py) stays on PyTorch-ROCm/MIOpen and needs its checkpoint; "
+                                      "feed feature maps with USE_IMAGES_GT=True (SURVEY.md 8c)")
+
+    def delete_intermediate_states(self):
+        for d in (self._losses, self._predictions, self._anchor_targets, self._proposal_targets, self._mask_targets):
+            for k in list(d):
+                del d[k]
+
+    # ------------------------------------------------------------------ pieces --
+    def _rpn_head(self, lv):
+        """cls (2A) and bbox (6A) 1x1x1 convs packed as ONE 8A-channel GEMM (network.py:41-42,541-543)."""
+        cls = getattr(self, "rpn_cls_score_net_level%d" % lv)[0]
+        box = getattr(self, "rpn_bbox_pred_net_level%d" % lv)
+        ver = (cls.weight._version, cls.bias._version, box.weight._version, box.bias._version, cls.weight.data_ptr())
+        hit = self._head_cache.get(lv)
+        if hit is None or hit[0] != ver:
+            w = torch.cat([cls.weight.detach(), box.weight.detach()], 0)
+            b = torch.cat([cls.bias.detach(), box.bias.detach()], 0)
+            hit = (ver, ops.PackedConv(w, b))
+            self._head_cache[lv] = hit
+        return hit[1]
+
+    # network.py:537-574
+    def _region_proposal(self, net_conv_level1, net_conv_level2, net_conv_level3):
+        cfg = self.cfg
+        levels = []
+        for lv, feat in ((1, net_conv_level1), (2, net_conv_level2), (3, net_conv_level3)):
+            A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
+            if A == 0:
+                continue
+            rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
+            score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
+            prob = ops.softmax2(score)
+            self._predictions["rpn_cls_score_level%d" % lv] = score
+            self._predictions["rpn_cls_prob_level%d" % lv] = prob
+            self._predictions["rpn_bbox_pred_level%d" % lv] = bbox
+            anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
+            setattr(self, "_anchors_level%d" % lv, anchors)
+            levels.append((lv, prob, bbox, anchors))
+        self._prop = self._proposals.run(levels, self._scene_info[:3], "TEST")
+
+    # network.py:503-534 + backbones.py:92-96 + network.py:589-604, on the padded K rows
+    def _classify_rois(self, l1, l2):
+        cfg, p = self.cfg, self._prop
+        ps = cfg.CLASS_POOLING_SIZE
+        pool5 = ops.roi_pool_levels(l1, l2, p["rois"], p["levels"], ps, 1.0 / self._feat_stride[0], out_channels_last=True)
+        self._pool5 = pool5
+        x = pool5.permute(0, 2, 3, 4, 1).reshape(pool5.shape[0], -1)           # memory order (R, bins, C): a view
+        fc0 = self.classifier[0]
+        ver = (fc0.weight._version, fc0.weight.data_ptr())
+        hit = self._head_cache.get("fc0")
+        if hit is None or hit[0] != ver:
+            C, nb = pool5.shape[1], ps ** 3
+            wperm = fc0.weight.detach().view(-1, C, nb).permute(0, 2, 1).reshape(fc0.weight.shape[0], -1).contiguous()
+            hit = (ver, wperm)
+            self._head_cache["fc0"] = hit
+        x = F.relu(F.linear(x, hit[1], fc0.bias))
+        x = F.relu(self.classifier[2](x))
+        fc7 = F.relu(self.classifier[4](x))
+        cls_score = self.classifier_cls_score_net(fc7)
+        cls_pred = torch.max(cls_score, 1)[1]
+        cls_prob = F.softmax(cls_score, dim=1)
+        bbox_pred = self.classifier_bbox_pred_net(fc7)
+        return cls_score, cls_pred, cls_prob, bbox_pred
+
+    # network.py:283-317
+    def _mask_branch(self, n):
+        cfg = self.cfg
+        rois = self._predictions["rois"][0].cpu()
+        box_reg_pre = self._predictions["bbox_pred"].cpu().numpy()
+        pred_class = self._predictions["cls_pred"].cpu().numpy()
+        cls_prob = self._predictions["cls_prob"].cpu().numpy()
+        box_reg = np.zeros((box_reg_pre.shape[0], 6))
+        pred_conf = np.zeros((pred_class.shape[0]))
+        for i in range(pred_class.shape[0]):
+            box_reg[i, :] = box_reg_pre[i, pred_class[i] * 6:(pred_class[i] + 1) * 6]
+            pred_conf[i] = cls_prob[i, pred_class[i]]
+        from ..utils.bbox_transform import bbox_transform_inv, clip_boxes
+        pred_box = clip_boxes(bbox_transform_inv(rois, torch.from_numpy(box_reg).float()), self._scene_info[:3]).numpy()
+        sel = pred_conf > cfg.CLASS_THRESH
+        for idx, box in enumerate(pred_box):
+            if round(box[0]) >= round(box[3]) or round(box[1]) >= round(box[4]) or round(box[2]) >= round(box[5]):
+                sel[idx] = False
+        self.mask_backbone.eval()
+        masks = []
+        for ind, roi in enumerate(pred_box):
+            if sel[ind]:
+                b = [int(round(roi[k])) for k in range(6)]      # Python round: half-to-even, as the reference
+                masks.append(self.mask_backbone(self._scene, None, window=tuple(b)))
+        return [masks]
+
+    # ------------------------------------------------------------------ forward --
+    def forward(self, blobs, mode="TRAIN", killing_inds=None):
+        if mode != "TEST":
+            raise NotImplementedError("forward-only build: mode must be 'TEST' (training is out of scope, SURVEY.md 2)")
+        cfg = self.cfg
+        if blobs["data"].shape[0] != 1:
+            raise NotImplementedError("batch size 1 (as the reference's TEST path)")
+        self._scene_info = blobs["data"].shape[2:]
+        self._id = blobs["id"][0]
+        self.batch_size = 1
+        self._mode = "TEST"
+        dev = torch.device("cuda", torch.cuda.current_device())
+        with torch.no_grad():
+            self.eval()
+            self._scene = blobs["data"].to(dev, non_blocking=True).float()
+            self._gt_bbox = blobs.get("gt_box")
+            self._gt_mask = blobs.get("gt_mask") if cfg.USE_MASK else None
+            if cfg.USE_IMAGES:
+                if not cfg.USE_IMAGES_GT:
+                    raise NotImplementedError("ENet encoder not part of this build; pass feature maps (USE_IMAGES_GT)")
+                feats = blobs["nearest_images"]["images"][0].to(dev, non_blocking=True)
+                p3 = blobs["proj_ind_3d"][0].to(dev, non_blocking=True)
+                p2 = blobs["proj_ind_2d"][0].to(dev, non_blocking=True)
+                self._imageft = ops.project_views_max(feats, p3, p2, self._scene_info, killing_inds or (), channels_last=True)
+            if cfg.USE_BACKBONE:
+                l1, l2, l3 = self._backbone()
+                self._net_conv = (l1, l2)
+            if not cfg.USE_RPN:
+                raise NotImplementedError("USE_RPN=False (ground-truth boxes as RoIs) is a training/debug mode")
+            self._region_proposal(l1, l2, l3)
+            outs = None
+            if cfg.USE_CLASS:
+                outs = self._classify_rois(l1, l2)
+            # the only host sync of the detection path: number of surviving RoIs
+            n = int(self._prop["num"].item())
+            p = self._prop
+            self._predictions["rois"] = [p["rois"][:n]]
+            self._predictions["roi_scores"] = [p["scores"][:n].view(-1, 1)]
+            self._predictions["level_inds"] = [p["levels"][:n]]
+            if cfg.USE_CLASS:
+                for k, v in zip(("cls_score", "cls_pred", "cls_prob", "bbox_pred"), outs):
+                    self._predictions[k] = v[:n]
+                if cfg.USE_MASK:
+                    self._predictions["mask_pred"] = self._mask_branch(n)
+        return self._predictions
+
+    def _init_backbone_classifier(self):
+        raise NotImplementedError
+
+    def _backbone(self):
+        raise NotImplementedError

@@ -1,0 +1,328 @@
+"""torch-tensor front ends of the C ABI (include/sis3d.h).
+
+Every function enqueues on torch's CURRENT stream and never synchronises unless
+its return value has a data-dependent shape (documented per function).  Inputs
+must be CUDA (ROCm) tensors; CPU tensors raise -- there is no fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+CL3D = torch.channels_last_3d
+
+EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_RPN_HEAD = 1, 2, 4, 8
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.Sis3dError("%s must be a CUDA/ROCm tensor (sis3d has no CPU path)" % name)
+    if t.dtype != dtype:
+        raise _lib.Sis3dError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---------------------------------------------------------------------- NMS --
+def nms_raw(dets, thresh, max_keep=0):
+    """-> (keep int64 [n], num_keep int32 [1]) on the device; no host sync."""
+    dets = _dev(dets, "dets").contiguous()
+    if dets.dim() != 2 or dets.shape[1] != 6:
+        raise _lib.Sis3dError("dets must be (N,6)")
+    n = dets.shape[0]
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dets.device)
+    num = torch.zeros(1, dtype=torch.int32, device=dets.device)
+    wsb = lib().sis3d_nms_workspace_bytes(n)
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dets.device)
+    check(lib().sis3d_nms(_ptr(dets), n, float(thresh), int(max_keep), _ptr(keep), _ptr(num), _ptr(ws), wsb, _stream()), "sis3d_nms")
+    return keep, num
+
+
+def nms(dets, thresh, max_keep=0):
+    """lib/layer_utils/nms_wrapper.py:7-16 semantics: LongTensor (K,) of kept indices on dets' device.
+    The result length is data dependent -> one 4-byte D2H read (the reference copies the whole
+    bit matrix and sweeps on the host)."""
+    keep, num = nms_raw(dets, thresh, max_keep)
+    return keep[:int(num.item())].contiguous()
+
+
+def nms_mask(dets, thresh):
+    dets = _dev(dets, "dets").contiguous()
+    n = dets.shape[0]
+    mask = torch.zeros(n, (n + 63) // 64, dtype=torch.int64, device=dets.device)
+    check(lib().sis3d_nms_mask(_ptr(dets), n, float(thresh), _ptr(mask), _stream()), "sis3d_nms_mask")
+    return mask
+
+
+def nms_select(boxes_all, level_all, scores_sorted, order, n, thresh, max_keep):
+    """Fused top-n -> NMS -> first max_keep survivors (proposal_layer.py:181-197).  Fixed-size outputs
+    (rows >= num_keep are zero), no host sync."""
+    dev = boxes_all.device
+    rois = torch.empty(max_keep, 6, device=dev)
+    scores = torch.empty(max_keep, device=dev)
+    levels = torch.empty(max_keep, device=dev)
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib().sis3d_nms_workspace_bytes(n)
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    check(lib().sis3d_nms_select(_ptr(_dev(boxes_all, "boxes_all")), _ptr(_dev(level_all, "level_all")),
+                                 _ptr(_dev(scores_sorted, "scores_sorted")), _ptr(_dev(order, "order", torch.int64)), int(n),
+                                 float(thresh), int(max_keep), _ptr(rois), _ptr(scores), _ptr(levels), _ptr(keep), _ptr(num),
+                                 _ptr(ws), wsb, _stream()), "sis3d_nms_select")
+    return rois, scores, levels, keep, num
+
+
+# ------------------------------------------------------------------ RoI pool --
+def roi_pool(features, rois, pooled, scale, want_argmax=True, out_channels_last=False):
+    """features: logical (1,C,W,H,L), any strides (NCDHW or channels_last_3d).  -> out (R,C,pw,ph,pl)
+    [+ argmax int32].  out_channels_last: memory order (R, bins, C) behind the same logical shape."""
+    f = _dev(features, "features")
+    r = _dev(rois, "rois").contiguous()
+    if f.dim() != 5 or f.shape[0] != 1:
+        raise _lib.Sis3dError("features must be (1,C,W,H,L): batch size 1 only (roi_pooling_cuda.c:29-32)")
+    if r.dim() != 2 or r.shape[1] != 6:
+        raise _lib.Sis3dError("rois must be (R,6) (roi_pooling_cuda.c:20-23)")
+    _, C, W, H, L = f.shape
+    R = r.shape[0]
+    pw, ph, pl = pooled
+    nb = pw * ph * pl
+    if out_channels_last:
+        out = torch.empty(R, pw, ph, pl, C, device=f.device).permute(0, 4, 1, 2, 3)
+        os_n, os_c, os_b = nb * C, 1, C
+    else:
+        out = torch.empty(R, C, pw, ph, pl, device=f.device)
+        os_n, os_c, os_b = C * nb, nb, 1
+    arg = None
+    if want_argmax:
+        arg = torch.empty(out.shape, dtype=torch.int32, device=f.device) if not out_channels_last else \
+            torch.empty(R, pw, ph, pl, C, dtype=torch.int32, device=f.device).permute(0, 4, 1, 2, 3)
+    st = f.stride()
+    check(lib().sis3d_roi_pool_forward(_ptr(f), C, W, H, L, st[1], st[2], st[3], st[4], _ptr(r), R, pw, ph, pl, float(scale),
+                                       _ptr(out), _ptr(arg), os_n, os_c, os_b, _stream()), "sis3d_roi_pool_forward")
+    return (out, arg) if want_argmax else out
+
+
+def roi_pool_levels(f1, f2, rois, levels, pooled, scale, out_channels_last=True):
+    f1, f2 = _dev(f1, "features1"), _dev(f2, "features2")
+    if f1.shape != f2.shape or f1.stride() != f2.stride():
+        raise _lib.Sis3dError("both pyramid levels must share shape and strides")
+    r = _dev(rois, "rois").contiguous()
+    lv = _dev(levels, "levels").contiguous()
+    _, C, W, H, L = f1.shape
+    R = r.shape[0]
+    nb = pooled ** 3
+    if out_channels_last:
+        out = torch.empty(R, pooled, pooled, pooled, C, device=f1.device).permute(0, 4, 1, 2, 3)
+        os_n, os_c, os_b = nb * C, 1, C
+    else:
+        out = torch.empty(R, C, pooled, pooled, pooled, device=f1.device)
+        os_n, os_c, os_b = C * nb, nb, 1
+    st = f1.stride()
+    check(lib().sis3d_roi_pool_levels(_ptr(f1), _ptr(f2), C, W, H, L, st[1], st[2], st[3], st[4], _ptr(r), _ptr(lv), R, pooled,
+                                      float(scale), _ptr(out), os_n, os_c, os_b, _stream()), "sis3d_roi_pool_levels")
+    return out
+
+
+# ---------------------------------------------------------------- projection --
+def projection(label, lin3d, lin2d, volume_dims):
+    """Projection.forward (projection.py:124-136): -> (C,Z,Y,X)."""
+    label = _dev(label, "label")
+    C = 1 if label.dim() == 2 else label.shape[0]
+    feat = label.contiguous().view(C, -1)
+    a = _dev(lin3d, "lin_indices_3d", torch.int64).contiguous()
+    b = _dev(lin2d, "lin_indices_2d", torch.int64).contiguous()
+    X, Y, Z = (int(v) for v in volume_dims)
+    nvox = X * Y * Z
+    if a.numel() < nvox + 1 or b.numel() < nvox + 1:
+        raise _lib.Sis3dError("index lists must have volume+1 entries (slot 0 = count)")
+    out = torch.empty(C, Z, Y, X, device=label.device)
+    check(lib().sis3d_projection_forward(_ptr(feat), C, feat.shape[1], _ptr(a), _ptr(b), nvox, _ptr(out), _stream()),
+          "sis3d_projection_forward")
+    return out
+
+
+def project_views_max(feats, lin3d, lin2d, volume_dims, killing_inds=(), channels_last=True):
+    """Fused network.py:216-239.  -> logical (1,C,X,Y,Z); memory order channels-last (for our conv stack)
+    or the reference's (C,Z,Y,X) (permute(4,0,3,2,1) of a (C,Z,Y,X,1) tensor)."""
+    feats = _dev(feats, "feats").contiguous()
+    a = _dev(lin3d, "proj_ind_3d", torch.int64).contiguous()
+    b = _dev(lin2d, "proj_ind_2d", torch.int64).contiguous()
+    X, Y, Z = (int(v) for v in volume_dims)
+    nvox = X * Y * Z
+    V = min(feats.shape[0], a.shape[0], b.shape[0])      # zip() truncation of the reference loop
+    C = feats.shape[1]
+    npix = feats.shape[2] * feats.shape[3]
+    kill = (ctypes.c_uint8 * V)(*[1 if k in set(killing_inds or ()) else 0 for k in range(V)])
+    wsb = lib().sis3d_project_views_workspace_bytes(V, C, npix, nvox)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=feats.device)
+    if channels_last:
+        out = new_act(C, (X, Y, Z), feats.device)
+        os_c, os_x, os_y, os_z = 1, Y * Z * C, Z * C, C
+    else:
+        out = torch.empty(C, Z, Y, X, 1, device=feats.device).permute(4, 0, 3, 2, 1)
+        os_c, os_x, os_y, os_z = nvox, 1, X, X * Y
+    check(lib().sis3d_project_views_max(_ptr(feats), V, C, npix, _ptr(a), _ptr(b), kill, X, Y, Z, _ptr(out), os_c, os_x, os_y,
+                                        os_z, _ptr(ws), wsb, _stream()), "sis3d_project_views_max")
+    return out
+
+
+# ------------------------------------------------------------------ proposals --
+def proposal_decode(anchors, deltas, prob_fg, inside, dims, level_id, out_boxes, out_scores, out_levels):
+    n = int(inside.numel())
+    check(lib().sis3d_proposal_decode(_ptr(anchors), _ptr(deltas), _ptr(prob_fg), _ptr(inside), n, float(dims[0]), float(dims[1]),
+                                      float(dims[2]), float(level_id), _ptr(out_boxes), _ptr(out_scores), _ptr(out_levels),
+                                      _stream()), "sis3d_proposal_decode")
+
+
+def softmax2(score):
+    """F.softmax over dim 1 of a contiguous (1,2,...) tensor (network.py:546)."""
+    score = _dev(score, "score")
+    if not score.is_contiguous() or score.shape[0] != 1 or score.shape[1] != 2:
+        raise _lib.Sis3dError("softmax2 expects a contiguous (1,2,...) tensor")
+    prob = torch.empty_like(score)
+    check(lib().sis3d_softmax2(_ptr(score), _ptr(prob), score.numel() // 2, _stream()), "sis3d_softmax2")
+    return prob
+
+
+# ----------------------------------------------------------------------- conv --
+def new_act(C, dims, device):
+    """channels-last activation: logical (1,C,X,Y,Z), memory (X,Y,Z,C)."""
+    return torch.empty(tuple(dims) + (C,), device=device).permute(3, 0, 1, 2).unsqueeze(0)
+
+
+def is_cl(t):
+    """True if logical (1,C,X,Y,Z) tensor t is dense channels-last in memory."""
+    if t.dim() != 5 or t.shape[0] != 1:
+        return False
+    _, C, X, Y, Z = t.shape
+    return tuple(t.stride()[1:]) == (1, Y * Z * C, Z * C, C)
+
+
+def to_cl(t):
+    """any (1,C,X,Y,Z) float tensor -> channels-last memory (HIP transpose kernel when planar)."""
+    t = _dev(t, "activation")
+    if is_cl(t):
+        return t
+    _, C, X, Y, Z = t.shape
+    if t.is_contiguous():
+        out = new_act(C, (X, Y, Z), t.device)
+        check(lib().sis3d_planar_to_cl(_ptr(t), C, X * Y * Z, _ptr(out), _stream()), "sis3d_planar_to_cl")
+        return out
+    return to_cl(t.contiguous())
+
+
+def to_planar(t):
+    t = _dev(t, "activation")
+    if t.is_contiguous():
+        return t
+    if is_cl(t):
+        _, C, X, Y, Z = t.shape
+        out = torch.empty(t.shape, device=t.device)
+        check(lib().sis3d_cl_to_planar(_ptr(t), C, X * Y * Z, _ptr(out), _stream()), "sis3d_cl_to_planar")
+        return out
+    return t.contiguous()
+
+
+class PackedConv:
+    """Weights of one nn.Conv3d repacked into MFMA fragment order (sis3d_conv_pack_weight)."""
+
+    def __init__(self, weight, bias=None, cin_pad=None):
+        w = _dev(weight.detach(), "weight").contiguous()
+        self.cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+        if not (w.shape[2] == w.shape[3] == w.shape[4]):
+            raise _lib.Sis3dError("cubic kernels only")
+        self.k = k
+        self.cin = cin_pad or ((cin + 7) // 8) * 8           # kernel reads cin padded to a multiple of 8
+        if self.cin != cin:
+            wp = torch.zeros(self.cout, self.cin, k, k, k, device=w.device)
+            wp[:, :cin] = w
+            w = wp
+        n = lib().sis3d_conv_packed_floats(self.cout, self.cin, k)
+        self.packed = torch.empty(n, device=w.device)
+        check(lib().sis3d_conv_pack_weight(_ptr(w), self.cout, self.cin, k, _ptr(self.packed), _stream()), "sis3d_conv_pack_weight")
+        self.bias = _dev(bias.detach(), "bias").contiguous().clone() if bias is not None else None
+        self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+
+
+def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, out_coff=0, rpn_anchors=0):
+    """x: channels-last (1,Cin,X,Y,Z).  -> channels-last (1,Cout,OX,OY,OZ) (or writes `out` at channel
+    offset out_coff).  rpn_anchors=A: returns (score (1,2,X,Y,Z,A), bbox (1,X,Y,Z,6A)) contiguous."""
+    if not is_cl(x):
+        raise _lib.Sis3dError("conv3d expects a channels-last activation (use ops.to_cl)")
+    _, cin_t, X, Y, Z = x.shape
+    if cin_t != pc.cin:
+        raise _lib.Sis3dError("conv3d: activation has %d channels, packed weight expects %d" % (cin_t, pc.cin))
+    if pc.k == 2:
+        if stride != 2:
+            raise _lib.Sis3dError("k=2 convs are stride 2")
+        od = (X // 2, Y // 2, Z // 2)
+    else:
+        if stride != 1:
+            raise _lib.Sis3dError("k=1/3 convs are stride 1")
+        od = (X, Y, Z)
+    flags = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_SIGMOID if sigmoid else 0)
+    out2 = None
+    if rpn_anchors:
+        A = rpn_anchors
+        flags |= EPI_RPN_HEAD
+        score = torch.empty((1, 2) + od + (A,), device=x.device)
+        bbox = torch.empty((1,) + od + (6 * A,), device=x.device)
+        o_ptr, o2_ptr, ostride = _ptr(score), _ptr(bbox), 0
+        ret = (score, bbox)
+    else:
+        if out is None:
+            out = new_act(pc.cout, od, x.device)
+        elif not is_cl(out) or tuple(out.shape[2:]) != od:
+            raise _lib.Sis3dError("conv3d: bad `out`")
+        o_ptr, o2_ptr, ostride = _ptr(out), None, out.shape[1]
+        ret = out
+    res_stride = 0
+    if residual is not None:
+        if not is_cl(residual) or tuple(residual.shape[2:]) != od:
+            raise _lib.Sis3dError("conv3d: residual must be channels-last with the output's grid")
+        res_stride = residual.shape[1]
+    check(lib().sis3d_conv3d(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed), _ptr(pc.bias), pc.cout, pc.k, stride, flags,
+                             _ptr(residual), res_stride, o_ptr, ostride, out_coff, o2_ptr, rpn_anchors, _stream()), "sis3d_conv3d")
+    return ret
+
+
+def conv3d_planar2(x, weight, ksize, relu=True, window=None, cout_stride=None):
+    """First layers on the planar 2-channel grid (geometry1.0 k2s2; mask conv0 k3p1 on a crop window).
+    x: (1,2,X,Y,Z) with a contiguous z axis; weight: checkpoint layout (Cout,2,k,k,k)."""
+    x = _dev(x, "scene")
+    w = _dev(weight.detach(), "weight").contiguous()
+    if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != 2 or x.stride(4) != 1:
+        raise _lib.Sis3dError("planar2 conv expects (1,2,X,Y,Z) with contiguous z")
+    _, _, X, Y, Z = x.shape
+    S = 2 if ksize == 2 else 1
+    if window is None:
+        window = (0, 0, 0, X // S * S, Y // S * S, Z // S * S)
+    x0, y0, z0, x1, y1, z1 = window
+    od = ((x1 - x0) // S, (y1 - y0) // S, (z1 - z0) // S)
+    cout = w.shape[0]
+    cs = cout_stride or cout
+    out = new_act(cs, od, x.device)
+    if cs != cout:
+        out.zero_()
+    st = x.stride()
+    check(lib().sis3d_conv3d_planar2(_ptr(x), st[1], st[2], st[3], X, Y, Z, x0, y0, z0, od[0], od[1], od[2], _ptr(w), cout, ksize,
+                                     EPI_RELU if relu else 0, _ptr(out), cs, _stream()), "sis3d_conv3d_planar2")
+    return out
+
+
+def maxpool3(x):
+    if not is_cl(x):
+        raise _lib.Sis3dError("maxpool3 expects a channels-last activation")
+    _, C, X, Y, Z = x.shape
+    out = new_act(C, (X, Y, Z), x.device)
+    check(lib().sis3d_maxpool3d_3x3x3(_ptr(x), X, Y, Z, C, _ptr(out), _stream()), "sis3d_maxpool3d_3x3x3")
+    return out

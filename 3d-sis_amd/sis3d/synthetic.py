@@ -1,0 +1,77 @@
+"""Seeded synthetic inputs and weights (no datasets or checkpoints exist offline).
+
+Definitions follow SURVEY.md section 8(d):
+  * chunk: |truncated sdf| + known-mask, as lib/datasets/dataset.py:66-68 builds
+    ``blobs['data']`` (1,2,X,Y,Z) fp32;
+  * weights: every state_dict entry drawn U(-1/sqrt(fan_in), +1/sqrt(fan_in))
+    (the bound PyTorch's default Conv/Linear init uses) from a generator seeded
+    by the parameter NAME, so the reference net and ours get identical tensors
+    through ``load_state_dict`` regardless of module construction order;
+  * projection index lists: packed like ProjectionHelper.compute_projection
+    returns them (lib/layer_utils/projection.py:108-121): int64 (nvox+1,), slot 0
+    holds the count.
+Pure torch-CPU; used by tests, bench.py and oracle/make_golden.py.
+"""
+import zlib
+
+import torch
+
+CHUNK_DIMS = (96, 48, 96)
+
+
+def synth_chunk(chunk_id=0, dims=CHUNK_DIMS, truncated=3.0):
+    g = torch.Generator().manual_seed(1234 + int(chunk_id))
+    tsdf = 2.0 * torch.randn(*dims, generator=g)
+    data = torch.zeros(1, 2, *dims)
+    data[0, 0] = tsdf.clamp(-truncated, truncated).abs()
+    data[0, 1] = (tsdf > -1).float()
+    return data
+
+
+def synth_state_dict(shapes, seed=0, gains=None):
+    """shapes: {name: shape}; gains: {substring: factor} applied to matching names."""
+    out = {}
+    for name in shapes:
+        shape = tuple(shapes[name])
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * int(seed)) & 0x7FFFFFFF)
+        if name.endswith("weight") and len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+        elif name.endswith("bias"):
+            wname = name[:-4] + "weight"
+            fan_in = 1
+            for d in tuple(shapes[wname])[1:]:
+                fan_in *= d
+        else:
+            fan_in = 1
+        bound = 1.0 / (fan_in ** 0.5)
+        t = (torch.rand(*shape, generator=g) * 2.0 - 1.0) * bound
+        for key, f in (gains or {}).items():
+            if key in name:
+                t = t * f
+        out[name] = t
+    return out
+
+
+# spreads RPN scores away from 0.5 and lets a few class scores pass CLASS_THRESH
+DEFAULT_GAINS = {"rpn_cls_score_net": 8.0, "classifier_cls_score_net.weight": 150.0}
+
+
+def synth_views(chunk_id=0, n_views=5, n_per_view=3000, channels=128, image_hw=(32, 41), dims=CHUNK_DIMS):
+    """feature maps (V,C,h,w) + packed index lists (V,nvox+1) int64."""
+    g = torch.Generator().manual_seed(4321 + int(chunk_id))
+    nvox = dims[0] * dims[1] * dims[2]
+    npix = image_hw[0] * image_hw[1]
+    feats = torch.randn(n_views, channels, *image_hw, generator=g)
+    i3d = torch.zeros(n_views, nvox + 1, dtype=torch.int64)
+    i2d = torch.zeros(n_views, nvox + 1, dtype=torch.int64)
+    for v in range(n_views):
+        n = min(int(n_per_view), nvox)
+        vox = torch.randperm(nvox, generator=g)[:n].sort().values
+        pix = torch.randint(0, npix, (n,), generator=g)
+        i3d[v, 0] = n
+        i2d[v, 0] = n
+        i3d[v, 1:1 + n] = vox
+        i2d[v, 1:1 + n] = pix
+    return feats, i3d, i2d

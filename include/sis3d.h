@@ -1,0 +1,170 @@
+/* sis3d.h -- C ABI of libsis3d_hip.so: the MI355X (gfx950) forward path of 3D-SIS.
+ *
+ * Drop-in boundary.  Conventions, mirroring the
+ * reference's cffi layer ("caller allocates, int status") but with the status
+ * actually meaningful:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - nothing here allocates, frees or synchronises; all work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return value: SIS3D_OK (0) or a negative SIS3D_E* code; launch failures
+ *     are reported through the return value, never by exit() (the reference
+ *     calls exit(-1): roi_pooling_kernel.cu:127-132);
+ *   - tensors are fp32; index outputs are int32/int64 as stated;
+ *   - voxel grids use the reference's axis naming (X=W, Y=H, Z=L), Z fastest in
+ *     the reference's NCDHW tensors.  Entry points that take explicit element
+ *     strides work on either memory order (NCDHW or channels-last X,Y,Z,C).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the reference repo root).
+ */
+#ifndef SIS3D_H
+#define SIS3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIS3D_OK 0
+#define SIS3D_EINVAL (-1)   /* bad shape / argument (reference returned 0 and was ignored) */
+#define SIS3D_ELAUNCH (-2)  /* hipGetLastError() != success after a launch */
+#define SIS3D_EWORKSPACE (-3) /* workspace too small */
+#define SIS3D_EUNSUPPORTED (-4)
+
+typedef void *sis3d_stream_t; /* hipStream_t */
+
+int sis3d_abi_version(void);
+const char *sis3d_strerror(int code);
+/* last HIP error string recorded by a failing launch on this thread */
+const char *sis3d_last_hip_error(void);
+
+/* ---------------------------------------------------------------- 3D NMS --
+ * Replaces: int gpu_nms(THLongTensor* keep, THLongTensor* num_out, THCudaTensor* boxes,
+ *           float thresh)          lib/layer_utils/nms/src/nms_cuda.h, nms_cuda.c:10-67
+ *           + nms_kernel / _nms    lib/layer_utils/nms/src/cuda/nms_kernel.cu:34-94
+ * boxes [n][6] score-sorted (x1,y1,z1,x2,y2,z2), IoU with +1 extents, suppress
+ * iff !(iou <= thresh) (== cpu_nms, pth_nms.py:42).  keep [n] ascending kept
+ * indices (entries >= *num_keep untouched), num_keep[0] = count.  The greedy
+ * sweep runs ON THE DEVICE (the reference copies the mask to the host).
+ * max_keep > 0 stops after that many survivors (== keep[:max_keep]).
+ * workspace: sis3d_nms_workspace_bytes(n) bytes (bit matrix), any content. */
+size_t sis3d_nms_workspace_bytes(int n);
+int sis3d_nms(const float *boxes, int n, float thresh, int max_keep, int64_t *keep, int32_t *num_keep,
+              void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
+/* the IoU bit matrix alone: mask [n][ceil(n/64)] u64, bit j of word cb set iff
+ * box 64*cb+j (> i) is suppressed by box i (nms_kernel.cu:34-79). */
+int sis3d_nms_mask(const float *boxes, int n, float thresh, uint64_t *mask, sis3d_stream_t stream);
+
+/* Fused proposal selection (proposal_layer.py:181-197): boxes_all [m][6],
+ * scores_sorted [>=n] (descending), order [>=n] int64 indices into boxes_all,
+ * level_all [m] (1.0/2.0/..).  Takes the first n entries of `order`, runs NMS
+ * and writes the first min(count,max_keep) survivors to rois [max_keep][6],
+ * roi_scores [max_keep], roi_levels [max_keep] (float), keep [n] positions in the
+ * sorted list, num_keep[0].  Rows >= count are zero-filled (level 0). */
+int sis3d_nms_select(const float *boxes_all, const float *level_all, const float *scores_sorted, const int64_t *order,
+                     int n, float thresh, int max_keep, float *rois, float *roi_scores, float *roi_levels,
+                     int64_t *keep, int32_t *num_keep, void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
+
+/* --------------------------------------------------------- 3D RoI pooling --
+ * Replaces: int roi_pooling_forward_cuda(int pw,int ph,int pl,float scale, THCudaTensor* features,
+ *           THCudaTensor* rois, THCudaTensor* output, THCudaIntTensor* argmax)
+ *           lib/layer_utils/roi_pooling/src/roi_pooling_cuda.h, roi_pooling_cuda.c:7-52,
+ *           ROIPoolForward  lib/layer_utils/roi_pooling/src/cuda/roi_pooling_kernel.cu:15-134
+ * features: one scene, C channels on a W x H x L grid, element strides
+ * (fs_c, fs_w, fs_h, fs_l).  rois [R][6] scene coordinates.  out element
+ * (n,c,pw,ph,pl) is written at n*os_n + c*os_c + ((pw*PH+ph)*PL+pl)*os_bin.
+ * argmax (may be NULL) uses the same addressing and holds the NCDHW linear
+ * index (c*W+w)*H*L + h*L + l of the first strict maximum in w->h->l scan
+ * order, -1 for an empty bin (value 0) -- independent of the memory order. */
+int sis3d_roi_pool_forward(const float *features, int C, int W, int H, int L, int64_t fs_c, int64_t fs_w, int64_t fs_h,
+                           int64_t fs_l, const float *rois, int R, int pooled_w, int pooled_h, int pooled_l,
+                           float spatial_scale, float *out, int32_t *argmax, int64_t os_n, int64_t os_c, int64_t os_bin,
+                           sis3d_stream_t stream);
+/* Both pyramid levels + the row scatter of Network._roi_pool_layer
+ * (lib/nets/network.py:503-534) in one launch: roi n pools from features1 if
+ * levels[n]==1, features2 if ==2, otherwise its output rows are zero. */
+int sis3d_roi_pool_levels(const float *features1, const float *features2, int C, int W, int H, int L, int64_t fs_c,
+                          int64_t fs_w, int64_t fs_h, int64_t fs_l, const float *rois, const float *levels, int R,
+                          int pooled, float spatial_scale, float *out, int64_t os_n, int64_t os_c, int64_t os_bin,
+                          sis3d_stream_t stream);
+
+/* ------------------------------------------------- 2D -> 3D back-projection --
+ * Replaces: Projection.forward   lib/layer_utils/projection.py:124-136
+ * feat [C][npix]; lin3d/lin2d int64 [nvox+1], slot 0 = count n (read on the
+ * device).  out [C][nvox] = 0 except out[c][lin3d[1+k]] = feat[c][lin2d[1+k]]. */
+int sis3d_projection_forward(const float *feat, int C, int64_t npix, const int64_t *lin3d, const int64_t *lin2d,
+                             int64_t nvox, float *out, sis3d_stream_t stream);
+/* Replaces the per-view loop + pairwise MaxPool1d of lib/nets/network.py:216-239:
+ * feats [V][C][npix], lin3d/lin2d [V][nvox+1], kill_host [V] (1 = view skipped,
+ * may be NULL).  Per voxel and channel: max over the included views of
+ * (visible ? feature : 0); with one included view a plain copy.  Volume dims
+ * X,Y,Z (nvox = X*Y*Z, linear voxel index z*X*Y + y*X + x).  out element
+ * (c,x,y,z) at c*os_c + x*os_x + y*os_y + z*os_z: the reference's memory order
+ * is (os_c,os_x,os_y,os_z) = (nvox,1,X,X*Y); channels-last is (1,Y*Z*C,Z*C,C).
+ * workspace: sis3d_project_views_workspace_bytes(V,C,npix,nvox). */
+size_t sis3d_project_views_workspace_bytes(int V, int C, int64_t npix, int64_t nvox);
+int sis3d_project_views_max(const float *feats, int V, int C, int64_t npix, const int64_t *lin3d, const int64_t *lin2d,
+                            const uint8_t *kill_host, int X, int Y, int Z, float *out, int64_t os_c, int64_t os_x,
+                            int64_t os_y, int64_t os_z, void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
+
+/* ------------------------------------------------------- proposal decoding --
+ * Replaces proposal_layer.py:96-103 + bbox_transform_inv / clip_boxes
+ * (lib/utils/bbox_transform.py:59-99,4-21) for one level:
+ * for k < n_inside:  i = inside[k];  box = clip(decode(anchors[i], deltas[i]))
+ *   out_boxes[k] = box; out_scores[k] = prob_fg[i]; out_levels[k] = level_id.
+ * anchors [K*A][6], deltas = rpn_bbox_pred viewed (-1,6), prob_fg =
+ * rpn_cls_prob[0,1] viewed (-1). */
+int sis3d_proposal_decode(const float *anchors, const float *deltas, const float *prob_fg, const int32_t *inside,
+                          int n_inside, float dim_x, float dim_y, float dim_z, float level_id, float *out_boxes,
+                          float *out_scores, float *out_levels, sis3d_stream_t stream);
+/* softmax over dim 1 of (1,2,...) score maps (network.py:546): n = elements per class plane */
+int sis3d_softmax2(const float *score, float *prob, int64_t n, sis3d_stream_t stream);
+
+/* ------------------------------------------------------------ 3D convolution --
+ * Replaces the cuDNN calls behind nn.Conv3d / nn.MaxPool3d / nn.ReLU / residual
+ * add in lib/nets/backbones.py:17-40,171-287 and lib/nets/network.py:38-47.
+ * Activations are channels-last: element (x,y,z,c) at ((x*Y+y)*Z+z)*C + c
+ * (torch.channels_last_3d view of a logical (1,C,X,Y,Z) tensor).
+ *
+ * Weights are repacked once (sis3d_conv_pack_weight) from the checkpoint layout
+ * (Cout,Cin,kx,ky,kz) into MFMA fragment order; Cin is padded to a multiple of
+ * 8 and Cout to a multiple of 32 with zeros.  Returns floats needed by
+ * sis3d_conv_packed_floats. */
+size_t sis3d_conv_packed_floats(int cout, int cin, int ksize);
+int sis3d_conv_pack_weight(const float *w, int cout, int cin, int ksize, float *packed, sis3d_stream_t stream);
+
+#define SIS3D_EPI_RELU 1      /* max(v,0) last */
+#define SIS3D_EPI_RESIDUAL 2  /* v += residual[(vox)*res_stride + c] before ReLU */
+#define SIS3D_EPI_SIGMOID 4   /* 1/(1+exp(-v)) last (MaskBackbone eval, backbones.py:286) */
+#define SIS3D_EPI_RPN_HEAD 8  /* channels [0,2A) -> score (2,X,Y,Z,A); [2A,8A) -> bbox (X,Y,Z,6A) */
+
+/* out[(x,y,z)][co] = epi( sum_{tap,ci} in[(S*x+dx-P, ...)][ci] * w[co][ci][tap] + bias[co] )
+ * ksize/stride/pad in {(1,1,0),(3,1,1),(2,2,0)}.  in: (X,Y,Z,cin_stride>=cin) channels-last,
+ * reading channels [0,cin).  out: (OX,OY,OZ) voxels, row stride out_stride floats, channel offset
+ * out_coff (lets two convs write one concatenated tensor, backbones.py:109).
+ * bias may be NULL.  For SIS3D_EPI_RPN_HEAD: out = score base, out2 = bbox base, anchors = A. */
+int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                 int cout, int ksize, int stride, int flags, const float *residual, int res_stride, float *out,
+                 int out_stride, int out_coff, float *out2, int anchors, sis3d_stream_t stream);
+
+/* first layers: NCDHW (planar) 2-channel grid in, channels-last out
+ * (geometry1.0: Conv3d(2,32,k2,s2), backbones.py:188 ; mask head conv0: Conv3d(2,64,k3,p1), backbones.py:241).
+ * w in checkpoint layout (Cout,2,k,k,k).  in element (c,x,y,z) at c*is_c + x*is_x + y*is_y + z (z contiguous);
+ * the output covers the window [x0,x0+OX*stride) etc of the grid (crop for the mask head). */
+int sis3d_conv3d_planar2(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, int X, int Y, int Z, int x0, int y0,
+                         int z0, int OX, int OY, int OZ, const float *w, int cout, int ksize, int flags, float *out,
+                         int out_stride, sis3d_stream_t stream);
+
+/* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding */
+int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream);
+
+/* layout helpers: planar (C,X,Y,Z) <-> channels-last (X,Y,Z,C) */
+int sis3d_planar_to_cl(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
+int sis3d_cl_to_planar(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIS3D_H */

@@ -1,0 +1,165 @@
+"""Generate tests/golden/*.npz FROM THE REFERENCE ITSELF (run in the build
+container, where /root/reference exists):
+
+    python oracle/make_golden.py
+
+Test infrastructure.  Inputs come from the product's seeded synthetic helpers
+(`sis3d.synthetic`); outputs are whatever the reference's own code returns for
+them (imported in place by oracle/ref_harness.py, RoI pooling by the reference's
+roi_pooling.c built into oracle/_ref/).  The fixtures are what pins the oracle
+(tests/test_oracle_pinning.py) and, through it, the HIP path.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
+
+import ref_harness as rh                       # noqa: E402
+from sis3d import synthetic                    # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
+
+
+def nms_cases(ns):
+    g = torch.Generator().manual_seed(7)
+    cases = {}
+    for n in (1, 2, 63, 64, 65, 130, 400):
+        lo = torch.rand(n, 3, generator=g) * torch.tensor([90.0, 44.0, 90.0])
+        sz = torch.rand(n, 3, generator=g) * 30.0 + 1.0
+        boxes = torch.cat([lo, lo + sz], 1)
+        cases["rand%d" % n] = boxes
+    # adversarial: duplicates, nested, touching (+1 convention makes touching boxes overlap)
+    base = torch.tensor([[10.0, 10, 10, 20, 20, 20]])
+    adv = torch.cat([base, base, base + 0.5, torch.tensor([[20.0, 10, 10, 30, 20, 20]]),
+                     torch.tensor([[21.0, 10, 10, 31, 20, 20]]), torch.tensor([[12.0, 12, 12, 18, 18, 18]]),
+                     torch.tensor([[0.0, 0, 0, 96, 48, 96]]), torch.tensor([[5.0, 5, 5, 5, 5, 5]]),
+                     torch.tensor([[5.0, 5, 5, 5, 5, 5]])], 0)
+    cases["adversarial"] = adv
+    # integer-grid boxes produce exact IoU ties around simple fractions
+    gi = torch.randint(0, 12, (200, 3), generator=g).float() * 4
+    cases["grid200"] = torch.cat([gi, gi + torch.randint(1, 6, (200, 3), generator=g).float() * 4], 1)
+    out = {}
+    for name, b in cases.items():
+        for th in (0.1, 0.35, 0.5):
+            keep = ns.pth_nms.cpu_nms(b.numpy(), th)          # the reference's own numpy NMS
+            out["%s/boxes" % name] = b.numpy()
+            out["%s/keep_%g" % (name, th)] = np.asarray(keep, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "nms_cases.npz"), **out)
+    print("nms_cases", len(out))
+
+
+def roi_cases(ns):
+    g = torch.Generator().manual_seed(11)
+    feat = torch.randn(1, 8, 12, 6, 10, generator=g)
+    lo = torch.rand(24, 3, generator=g) * torch.tensor([44.0, 20.0, 36.0])
+    sz = torch.rand(24, 3, generator=g) * 24.0
+    rois = torch.cat([lo, lo + sz], 1)
+    rois[0] = torch.tensor([0.0, 0, 0, 48, 24, 40])          # whole map
+    rois[1] = torch.tensor([4.0, 4, 4, 4, 4, 4])             # degenerate -> forced 1x1x1
+    rois[2] = torch.tensor([40.0, 20, 36, 60, 30, 50])       # runs past the border
+    rois[3] = torch.tensor([60.0, 30, 50, 70, 40, 60])       # fully outside -> empty bins -> 0
+    rois[4] = torch.tensor([3.9999, 7.5, 0.25, 12.0001, 8.5, 39.75])
+    ref = rh.ref_roi_pool_c().forward(4, 4, 4, 0.25, feat, rois)       # reference roi_pooling.c
+    # reference pure-Python RoIPool (roi_pool.py:53-120) on a subset (slow) for argmax coordinates
+    rp = ns.roi_pool.RoIPool.__new__(ns.roi_pool.RoIPool)
+    rp.pooled_width = rp.pooled_height = rp.pooled_length = 2
+    rp.spatial_scale = 0.25
+    py = ns.roi_pool.RoIPool.forward(rp, feat, rois[:6])
+    np.savez_compressed(os.path.join(OUT, "roi_pool_cases.npz"), feat=feat.numpy(), rois=rois.numpy(),
+                        out_c_4=ref.numpy(), out_py_2=py.numpy(), argmax_whl_py_2=rp.remember_for_backward.numpy())
+    print("roi_pool_cases", ref.shape, py.shape)
+
+
+def projection_cases(ns):
+    dims = (12, 6, 10)
+    feats, i3d, i2d = synthetic.synth_views(3, n_views=3, n_per_view=150, channels=5, image_hw=(8, 9), dims=dims)
+    outs = [ns.projection.Projection.apply(f, a, b, dims).numpy() for f, a, b in zip(feats, i3d, i2d)]
+    lab2d = feats[0, 0]
+    out2d = ns.projection.Projection.apply(lab2d, i3d[0], i2d[0], dims).numpy()
+    np.savez_compressed(os.path.join(OUT, "projection_cases.npz"), feats=feats.numpy(), i3d=i3d.numpy(), i2d=i2d.numpy(),
+                        dims=np.array(dims), out=np.stack(outs), out2d=out2d)
+    print("projection_cases")
+
+
+def anchors_case(ns):
+    with rh.in_reference_dir():
+        a1, a2, _ = ns.generate_anchors.generate_anchors([3, 2, 4], [3, 2, 4], [], [4, 4, 4])
+        f1, f2, _ = ns.generate_anchors.generate_anchors([24, 12, 24], [24, 12, 24], [], [4, 4, 4])
+    np.savez_compressed(os.path.join(OUT, "anchors.npz"), small_l1=a1, small_l2=a2,
+                        full_l1_sha=np.array(sha(f1)), full_l2_sha=np.array(sha(f2)),
+                        full_l1_head=f1[:64], full_l2_tail=f2[-64:])
+    print("anchors", f1.shape, f2.shape)
+
+
+def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3):
+    net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=True)
+    shapes = {k: v.shape for k, v in net.state_dict().items()}
+    sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    data = synthetic.synth_chunk(chunk_id, dims)
+    feats = i3d = i2d = None
+    if use_images:
+        feats, i3d, i2d = synthetic.synth_views(chunk_id, n_views=n_views, n_per_view=n_per_view, dims=dims)
+    grabbed = {}
+    bb = net._backbone
+
+    def grab():
+        r = bb()
+        grabbed["l1"], grabbed["l2"] = r[0], r[1]
+        return r
+    net._backbone = grab
+    p = rh.forward(ns, net, rh.make_blobs(data, feats, i3d, i2d))
+    out = dict(dims=np.array(dims), chunk_id=np.array(chunk_id), n_views=np.array(n_views), n_per_view=np.array(n_per_view),
+               sub=np.array(sub), shapes_keys=np.array(sorted(shapes.keys())),
+               level1_sub=grabbed["l1"][0, :, ::sub, ::sub, ::sub].numpy(), level2_sub=grabbed["l2"][0, :, ::sub, ::sub, ::sub].numpy(),
+               level1_sha=np.array(sha(grabbed["l1"].numpy())), level2_sha=np.array(sha(grabbed["l2"].numpy())))
+    for lv in (1, 2):
+        out["rpn_cls_score_level%d_sub" % lv] = p["rpn_cls_score_level%d" % lv][0, :, ::sub, ::sub, ::sub].numpy()
+        out["rpn_cls_prob_level%d_sub" % lv] = p["rpn_cls_prob_level%d" % lv][0, :, ::sub, ::sub, ::sub].numpy()
+        out["rpn_bbox_pred_level%d_sub" % lv] = p["rpn_bbox_pred_level%d" % lv][0, ::sub, ::sub, ::sub].numpy()
+    out["rois"] = p["rois"][0].numpy()
+    out["roi_scores"] = p["roi_scores"][0].numpy()
+    out["level_inds"] = p["level_inds"][0].numpy()
+    for k in ("cls_score", "cls_pred", "cls_prob", "bbox_pred"):
+        out[k] = p[k].numpy()
+    masks = p["mask_pred"][0]
+    out["n_masks"] = np.array(len(masks))
+    for i, m in enumerate(masks[:4]):
+        out["mask_%d" % i] = m.numpy()
+    out["mask_shapes"] = np.array([list(m.shape[2:]) for m in masks]).reshape(-1, 3)
+    if use_images:
+        ift = net._imageft           # logical (1,C,X,Y,Z), memory (C,Z,Y,X)
+        nz = ift[0].abs().sum(0).nonzero()
+        out["imageft_nz_xyz"] = nz.numpy().astype(np.int32)
+        out["imageft_nz_val"] = ift[0][:, nz[:, 0], nz[:, 1], nz[:, 2]].numpy()
+        out["imageft_stride"] = np.array(ift.stride())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "R=%d" % out["rois"].shape[0], "masks=%d" % len(masks),
+          "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = rh.install()
+    nms_cases(ns)
+    roi_cases(ns)
+    projection_cases(ns)
+    anchors_case(ns)
+    e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)
+    e2e(ns, "e2e_geometry_small", False, (64, 32, 48), 1, sub=2)
+    e2e(ns, "e2e_images_small", True, (64, 32, 48), 2, n_views=3, n_per_view=400, sub=2)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+"""Run the REAL reference (Sekunde/3D-SIS, /root/reference) in place on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product (`3d-sis_amd/`) may import
+this file.  It exists to (a) pin `oracle/sis3d_oracle.py` (our CPU restatement)
+against the reference's own code and (b) generate the golden fixtures under
+`tests/golden/` (see `oracle/make_golden.py`).  `/root/reference` only exists in
+the build container; on the GPU box `available()` is False and every user of
+this module must skip.
+
+How the reference is made to run:
+  * `sys.path` gets `/root/reference` and the cwd is switched there while the
+    reference runs (anchor files are opened by relative path,
+    lib/layer_utils/generate_anchors.py:19).
+  * missing third-party modules are stubbed (easydict, ipdb, skimage, plyfile,
+    the two cffi `_ext` packages ...).
+  * `yaml.load` gets a SafeLoader (lib/utils/config.py:296 predates PyYAML 6).
+  * `.cuda()` is neutralised so `Network.forward` (lib/nets/network.py:75,191)
+    runs on CPU: this is the complete form of the README's "MAX_VOLUME=0 CPU
+    path".
+  * `RoIPoolFunction` (legacy instance-style autograd Function,
+    lib/layer_utils/roi_pooling/roi_pool.py:9-38) is replaced by a callable
+    that runs the reference's own `roi_pooling.c` compiled by
+    `oracle/Makefile` into `oracle/_ref/libref_roi_pooling.so`.
+No reference source is copied; it is imported / compiled where it lies.
+"""
+import contextlib
+import ctypes
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF_ROOT = os.environ.get("SIS3D_REFERENCE", "/root/reference")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REF_SO = os.path.join(_HERE, "_ref", "libref_roi_pooling.so")
+
+_installed = False
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_ROOT, "lib", "nets"))
+
+
+class _EasyDict(dict):
+    """20-line stand-in for `easydict.EasyDict` (attribute access + recursion)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {}, **kw)
+        for k, v in d.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, _EasyDict):
+            v = _EasyDict(v)
+        super().__setitem__(k, v)
+        super().__setattr__(k, v)
+
+    __setitem__ = __setattr__
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+@contextlib.contextmanager
+def in_reference_dir():
+    old = os.getcwd()
+    os.chdir(REF_ROOT)
+    try:
+        yield
+    finally:
+        os.chdir(old)
+
+
+class _RefRoiPoolC:
+    """ctypes view of the reference's own roi_pooling.c (built by oracle/Makefile)."""
+
+    class _THFloatTensor(ctypes.Structure):
+        _fields_ = [("data", ctypes.POINTER(ctypes.c_float)), ("size", ctypes.c_long * 8)]
+
+    def __init__(self):
+        self.lib = ctypes.CDLL(_REF_SO)
+        self.lib.roi_pooling_forward.restype = ctypes.c_int
+
+    def _wrap(self, t):
+        s = self._THFloatTensor()
+        s.data = ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
+        for i, d in enumerate(t.shape):
+            s.size[i] = d
+        return s
+
+    def forward(self, pw, ph, pl, scale, features, rois):
+        features = features.contiguous().float()
+        rois = rois.contiguous().float()
+        out = torch.zeros(rois.shape[0], features.shape[1], pw, ph, pl)
+        f, r, o = self._wrap(features), self._wrap(rois), self._wrap(out)
+        rc = self.lib.roi_pooling_forward(
+            ctypes.c_int(pw), ctypes.c_int(ph), ctypes.c_int(pl), ctypes.c_float(scale),
+            ctypes.byref(f), ctypes.byref(r), ctypes.byref(o))
+        assert rc == 1, "reference roi_pooling_forward returned %d" % rc
+        return out
+
+
+_ref_roi = None
+
+
+def ref_roi_pool_c():
+    global _ref_roi
+    if _ref_roi is None:
+        if not os.path.exists(_REF_SO):
+            raise RuntimeError("build oracle/_ref first: make -C oracle ref")
+        _ref_roi = _RefRoiPoolC()
+    return _ref_roi
+
+
+class RefRoIPoolCallable:
+    """Stands in for `RoIPoolFunction(pw,ph,pl,scale)(features, rois)`."""
+
+    def __init__(self, pw, ph, pl, scale):
+        self.a = (int(pw), int(ph), int(pl), float(scale))
+
+    def __call__(self, features, rois):
+        return ref_roi_pool_c().forward(*self.a, features, rois)
+
+
+def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=False):
+    """Import the reference with stubs; returns the module namespace we need."""
+    global _installed
+    if not available():
+        raise RuntimeError("reference not available at %s" % REF_ROOT)
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    if not _installed:
+        import yaml
+        _orig_load = yaml.load
+
+        def _load(stream, Loader=None, **kw):
+            return _orig_load(stream, Loader=Loader or yaml.SafeLoader, **kw)
+        yaml.load = _load
+
+        _stub("easydict", EasyDict=_EasyDict)
+        _stub("ipdb", set_trace=lambda *a, **k: None)
+        sk = _stub("skimage")
+        sk.transform = _stub("skimage.transform", resize=None)
+        _stub("plyfile", PlyData=None, PlyElement=None)
+        if "tools" not in sys.modules:
+            tools = _stub("tools")
+            tools.__path__ = []
+            tools.visualization = _stub("tools.visualization", write_bbox=None, write_mask=None)
+        # the two cffi extension packages (prebuilt cpython-36/sm_61 .so files are unusable)
+        _stub("lib.layer_utils.roi_pooling._ext", roi_pooling=None).__path__ = []
+        _stub("lib.layer_utils.nms._ext", nms=None).__path__ = []
+        if with_trainval:
+            _stub("h5py")
+            import scipy
+            scipy.misc = _stub("scipy.misc")
+            tv = _stub("torchvision")
+            tv.transforms = _stub("torchvision.transforms")
+            tn = _stub("torchnet")
+            tn.meter = _stub("torchnet.meter")
+            tn.meter.confusionmeter = _stub("torchnet.meter.confusionmeter", ConfusionMeter=None)
+            _stub("reprint", output=None)
+            _stub("tensorflow")
+        # neutralise .cuda(): the reference forward calls it unconditionally
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        torch.cuda.empty_cache = lambda: None
+        torch.cuda.synchronize = lambda *a, **k: None
+        _installed = True
+
+    with in_reference_dir():
+        from lib.utils.config import cfg, cfg_from_file
+        cfg_from_file(cfg_file)
+        # main.py:41-50 derives NUM_CLASSES from the label map (19 for ScanNet v2)
+        import csv
+        weights_pre = {}
+        with open(cfg.LABEL_MAP) as f:
+            for row in csv.DictReader(f):
+                weights_pre[int(row["mappedIdConsecutive"])] = float(row["weight"])
+        # lib/datasets/dataset.py:269-283 (load_mapping): background weight first
+        weights = [0.3280746813009404] + [weights_pre[k] for k in sorted(weights_pre)]
+        weights = [w for w in weights if w > 0]
+        cfg.NORMALIZE_WEIGHTS = weights
+        cfg.NUM_CLASSES = len(weights)
+        from lib.nets import backbones, network
+        from lib.layer_utils import proposal_layer as pl_mod
+        from lib.layer_utils import generate_anchors as ga_mod
+        from lib.layer_utils import projection as proj_mod
+        from lib.layer_utils.nms import pth_nms
+        from lib.layer_utils.roi_pooling import roi_pool
+        from lib.utils import bbox_transform
+        network.RoIPoolFunction = RefRoIPoolCallable
+    ns = types.SimpleNamespace(cfg=cfg, backbones=backbones, network=network, proposal_layer=pl_mod,
+                               generate_anchors=ga_mod, projection=proj_mod, pth_nms=pth_nms,
+                               roi_pool=roi_pool, bbox_transform=bbox_transform)
+    return ns
+
+
+def make_blobs(data, images=None, proj3d=None, proj2d=None, scene_id="syn0"):
+    blobs = {"data": data, "id": [scene_id], "gt_box": [torch.zeros(0, 7)], "gt_mask": [[]]}
+    if images is not None:
+        blobs["nearest_images"] = {"images": [images]}
+        blobs["proj_ind_3d"] = [proj3d]
+        blobs["proj_ind_2d"] = [proj2d]
+    return blobs
+
+
+def build_net(ns, seed=0, use_images=False, use_mask=True):
+    """`getattr(backbones, cfg.NET)(); init_modules()` as lib/model/trainval.py:68-70 does."""
+    cfg = ns.cfg
+    cfg.USE_IMAGES = bool(use_images)
+    cfg.USE_IMAGES_GT = bool(use_images)   # feature maps supplied directly (network.py:199-201)
+    cfg.USE_MASK = bool(use_mask)
+    torch.manual_seed(seed)
+    with in_reference_dir():
+        net = getattr(ns.backbones, cfg.NET)()
+        net.init_modules()
+    net.eval()
+    return net
+
+
+def forward(ns, net, blobs, killing_inds=()):
+    with in_reference_dir(), torch.no_grad():
+        net.forward(blobs, "TEST", list(killing_inds))
+    return net._predictions
