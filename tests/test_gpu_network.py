@@ -1,0 +1,130 @@
+"""End-to-end parity of the HIP forward (sis3d.nets mirror of lib/nets) against the oracle and the
+reference-generated golden fixtures, on the same seeded inputs and weights."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sis3d import config, synthetic  # noqa: E402
+
+TOL = 1e-4
+
+
+def build(cfg, seed=0):
+    from sis3d.nets import backbones
+    net = getattr(backbones, cfg.NET)(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synthetic.synth_state_dict(shapes, seed=seed, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    return net.cuda().eval(), sd
+
+
+def blobs_for(data, feats=None, i3d=None, i2d=None):
+    b = {"data": data, "id": ["syn0"], "gt_box": [torch.zeros(0, 7)], "gt_mask": [[]]}
+    if feats is not None:
+        b["nearest_images"] = {"images": [feats]}
+        b["proj_ind_3d"] = [i3d]
+        b["proj_ind_2d"] = [i2d]
+    return b
+
+
+def match_boxes(got, want, tol=1e-3):
+    """proposal SETS: every oracle box has a device box within tol (order may differ on near-ties)"""
+    if len(want) == 0:
+        return 1.0
+    d = (got[None, :, :] - want[:, None, :]).abs().amax(-1)
+    return float((d.min(1).values <= tol).float().mean())
+
+
+@pytest.mark.parametrize("name,use_images", [("e2e_geometry_small", False), ("e2e_images_small", True),
+                                             ("e2e_geometry_full", False)])
+def test_forward_vs_oracle_and_golden(oracle, golden, name, use_images):
+    g = golden(name)
+    dims = tuple(int(v) for v in g["dims"])
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES = use_images
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(int(g["chunk_id"]), dims)
+    feats = i3d = i2d = None
+    if use_images:
+        feats, i3d, i2d = synthetic.synth_views(int(g["chunk_id"]), n_views=int(g["n_views"]), n_per_view=int(g["n_per_view"]), dims=dims)
+    p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data, feats, i3d, i2d)
+    s = int(g["sub"])
+    # ---- stage outputs, fp32 tolerance
+    l1, l2 = net._net_conv
+    assert (l1.cpu() - o["level1"]).abs().max() <= TOL
+    assert (l2.cpu() - o["level2"]).abs().max() <= TOL
+    assert np.abs(l1.cpu()[0, :, ::s, ::s, ::s].numpy() - g["level1_sub"]).max() <= TOL      # vs the reference itself
+    for lv in (1, 2):
+        for k in ("rpn_cls_score_level%d", "rpn_cls_prob_level%d", "rpn_bbox_pred_level%d"):
+            assert p[k % lv].shape == o[k % lv].shape
+            assert (p[k % lv].cpu() - o[k % lv]).abs().max() <= TOL, k % lv
+    if use_images:
+        assert torch.equal(net._imageft.cpu(), o["imageft"])                                  # bit-exact gather
+    # ---- proposals: same set up to near-tie reordering
+    rois, want = p["rois"][0].cpu(), o["rois"][0]
+    frac = match_boxes(rois, want)
+    assert frac >= 0.9, frac
+    assert abs(rois.shape[0] - want.shape[0]) <= max(3, want.shape[0] // 10)
+    assert np.abs(np.sort(p["roi_scores"][0].cpu().numpy()[:, 0])[-20:] - np.sort(g["roi_scores"][:, 0])[-20:]).max() <= TOL
+
+
+def test_stage_isolated_heads_exact_inputs(oracle):
+    """feed ORACLE tensors into the device proposal / RoI / classifier stages: integer outputs bit-exact,
+    logits within 1e-4 (SURVEY.md 8c parity protocol (1)+(2))."""
+    from sis3d import ops
+    cfg = config.scannet_benchmark_cfg()
+    net, sd = build(cfg)
+    dims = synthetic.CHUNK_DIMS
+    data = synthetic.synth_chunk(0, dims)
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data)
+    net._scene_info = dims
+    levels = []
+    for lv in (1, 2):
+        anchors = oracle.generate_anchors((24, 12, 24), 4, config.anchor_sizes(cfg, lv))
+        levels.append((lv, o["rpn_cls_prob_level%d" % lv].cuda(), o["rpn_bbox_pred_level%d" % lv].cuda(), anchors))
+    r = net._proposals.run(levels, dims)
+    n = int(r["num"].item())
+    assert torch.equal(r["order"][:r["n_pre"]].cpu(), o["_order"])          # stable sort, same tie rule
+    assert torch.equal(r["keep"][:n].cpu(), o["_keep"])                     # NMS keep list bit-exact
+    assert (r["rois"][:n].cpu() - o["rois"][0]).abs().max() <= TOL
+    assert torch.equal(r["levels"][:n].cpu(), o["level_inds"][0])
+    # RoI pooling + classifier on the oracle's rois / features
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last_3d)
+    net._prop = dict(rois=o["rois"][0].cuda(), levels=o["level_inds"][0].cuda())
+    outs = net._classify_rois(cl(o["level1"]), cl(o["level2"]))
+    assert torch.equal(net._pool5.cpu(), o["pool5"])                        # pooled values bit-exact
+    assert (outs[0].cpu() - o["cls_score"]).abs().max() <= TOL
+    assert (outs[3].cpu() - o["bbox_pred"]).abs().max() <= TOL
+    assert torch.equal(outs[1].cpu(), o["cls_pred"])
+
+
+def test_mask_head_vs_oracle(oracle):
+    cfg = config.scannet_benchmark_cfg()
+    net, sd = build(cfg)
+    on = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
+    data = synthetic.synth_chunk(2)
+    for win in ((10, 5, 20, 22, 25, 33), (0, 0, 0, 8, 10, 9), (80, 30, 70, 96, 48, 96), (3, 3, 3, 4, 4, 4)):
+        x0, y0, z0, x1, y1, z1 = win
+        want = on.mask_backbone(data[:, :, x0:x1, y0:y1, z0:z1])
+        got = net.mask_backbone(data.cuda(), None, window=win)
+        assert got.shape == want.shape
+        assert (got.cpu() - want).abs().max() <= TOL
+        # the reference call form: a sliced view of the scene
+        got2 = net.mask_backbone(data.cuda()[:, :, x0:x1, y0:y1, z0:z1], None)
+        assert (got2.cpu() - want).abs().max() <= TOL
+
+
+def test_full_forward_masks(oracle, golden):
+    g = golden("e2e_geometry_full")
+    cfg = config.scannet_benchmark_cfg()
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(0)
+    p = net.forward(blobs_for(data), "TEST", [])
+    masks = p["mask_pred"][0]
+    assert abs(len(masks) - int(g["n_masks"])) <= 3
+    for m in masks:
+        assert m.shape[1] == cfg.NUM_CLASSES and float(m.min()) >= 0 and float(m.max()) <= 1

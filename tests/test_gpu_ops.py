@@ -1,0 +1,186 @@
+"""Parity of the HIP kernels (through the C ABI / sis3d.ops) against the CPU oracle and the
+reference-generated golden fixtures.  Bit-exact for NMS keep lists, RoI-pool values + argmax and
+projection scatters; fp32 tolerances stated per test for decode / conv."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sis3d import config, synthetic  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from sis3d import ops as o
+    o.lib()  # fails loudly if libsis3d_hip.so is missing
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------ NMS
+def test_nms_golden_bit_exact(ops, golden):
+    g = golden("nms_cases")
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        boxes = torch.from_numpy(g[name + "/boxes"])
+        for th in (0.1, 0.35, 0.5):
+            keep = ops.nms(dev(boxes), th).cpu().numpy()
+            assert np.array_equal(keep, g["%s/keep_%g" % (name, th)]), (name, th)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 400, 1024, 1025, 2500, 6400])
+def test_nms_random_vs_oracle(ops, oracle, n):
+    g = torch.Generator().manual_seed(n)
+    lo = torch.rand(n, 3, generator=g) * torch.tensor([380.0, 44.0, 760.0])
+    sz = torch.rand(n, 3, generator=g) * 40.0 + 1.0
+    boxes = torch.cat([lo, lo + sz], 1)
+    for th in (0.1, 0.5):
+        want = oracle.nms(boxes, th)
+        got = ops.nms(dev(boxes), th).cpu()
+        assert torch.equal(got, want), (n, th)
+        # max_keep == truncation of the full list
+        got_k = ops.nms(dev(boxes), th, max_keep=7).cpu()
+        assert torch.equal(got_k, want[:7])
+    if n >= 2:
+        m = ops.nms_mask(dev(boxes), 0.3).cpu()
+        want_m = oracle.nms_mask(boxes, 0.3)
+        cb = (n + 63) // 64
+        # only tiles on/above the diagonal are defined by the kernel contract
+        for i in range(0, n, max(1, n // 50)):
+            assert torch.equal(m[i, i // 64:], want_m[i, i // 64:]), i
+        assert m.shape == (n, cb)
+
+
+def test_nms_ties_and_nan(ops, oracle):
+    b = torch.tensor([[0.0, 0, 0, 10, 10, 10]] * 5 + [[float("nan"), 0, 0, 10, 10, 10]] + [[50.0, 20, 50, 60, 30, 60]])
+    for th in (0.0, 0.1, 0.999, 1.0):
+        assert torch.equal(ops.nms(dev(b), th).cpu(), oracle.nms(b, th)), th
+    e = torch.zeros(0, 6)
+    assert ops.nms(dev(e), 0.1).numel() == 0
+
+
+def test_nms_select_matches_proposal_layer_tail(ops, oracle):
+    g = torch.Generator().manual_seed(5)
+    m = 3000
+    lo = torch.rand(m, 3, generator=g) * torch.tensor([80.0, 40.0, 80.0])
+    boxes = torch.cat([lo, lo + torch.rand(m, 3, generator=g) * 20 + 1], 1)
+    scores = torch.rand(m, generator=g)
+    scores[100:110] = scores[100]                      # ties
+    lv = (torch.rand(m, generator=g) > 0.5).float() + 1
+    s_sorted, order = scores.sort(descending=True, stable=True)
+    n_pre, k_out = 400, 200
+    keep = oracle.nms(boxes[order[:n_pre]], 0.1)[:k_out]
+    rois, rs, rl, kp, num = ops.nms_select(dev(boxes), dev(lv), dev(s_sorted), dev(order), n_pre, 0.1, k_out)
+    n = int(num.item())
+    assert n == keep.numel()
+    assert torch.equal(kp[:n].cpu(), keep)
+    assert torch.equal(rois[:n].cpu(), boxes[order[:n_pre]][keep])
+    assert torch.equal(rs[:n].cpu(), s_sorted[:n_pre][keep])
+    assert torch.equal(rl[:n].cpu(), lv[order[:n_pre]][keep])
+    assert (rois[n:] == 0).all() and (rl[n:] == 0).all()
+
+
+# ------------------------------------------------------------------------------- RoI pool
+def test_roi_pool_golden_bit_exact(ops, golden):
+    g = golden("roi_pool_cases")
+    feat, rois = torch.from_numpy(g["feat"]), torch.from_numpy(g["rois"])
+    out, arg = ops.roi_pool(dev(feat), dev(rois), (4, 4, 4), 0.25)
+    assert np.array_equal(out.cpu().numpy(), g["out_c_4"])
+    out2, arg2 = ops.roi_pool(dev(feat), dev(rois[:6]), (2, 2, 2), 0.25)
+    assert np.array_equal(out2.cpu().numpy(), g["out_py_2"])
+
+
+@pytest.mark.parametrize("layout", ["ncdhw", "channels_last"])
+def test_roi_pool_vs_oracle_full_size(ops, oracle, layout):
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(1, 128, 24, 12, 24, generator=g)
+    feat[0, :, 5, 5, 5] = feat[0, :, 5, 5, 6]            # equal values inside a window: first max must win
+    R = 200
+    lo = torch.rand(R, 3, generator=g) * torch.tensor([90.0, 44.0, 90.0])
+    rois = torch.cat([lo, (lo + torch.rand(R, 3, generator=g) * 50).clamp(max=96)], 1)
+    rois[0] = torch.tensor([0.0, 0, 0, 96, 48, 96])
+    want, want_arg = oracle.roi_pool(feat, rois, (4, 4, 4), 0.25)
+    f = dev(feat)
+    if layout == "channels_last":
+        f = f.contiguous(memory_format=torch.channels_last_3d)
+    out, arg = ops.roi_pool(f, dev(rois), (4, 4, 4), 0.25, out_channels_last=(layout == "channels_last"))
+    assert torch.equal(out.cpu(), want)
+    assert torch.equal(arg.cpu(), want_arg)
+
+
+def test_roi_pool_levels_matches_python_scatter(ops, oracle):
+    g = torch.Generator().manual_seed(4)
+    f1 = torch.randn(1, 128, 24, 12, 24, generator=g)
+    f2 = torch.randn(1, 128, 24, 12, 24, generator=g)
+    R = 64
+    lo = torch.rand(R, 3, generator=g) * torch.tensor([80.0, 40.0, 80.0])
+    rois = torch.cat([lo, lo + torch.rand(R, 3, generator=g) * 30], 1)
+    lv = (torch.rand(R, generator=g) > 0.4).float() + 1
+    lv[-3:] = 0                                           # padded rows
+    want = torch.zeros(R, 128, 4, 4, 4)
+    for lid, f in ((1, f1), (2, f2)):
+        idx = (lv == lid).nonzero()[:, 0]
+        want[idx] = oracle.roi_pool(f, rois[idx], (4, 4, 4), 0.25, want_argmax=False)
+    cl = lambda t: dev(t).contiguous(memory_format=torch.channels_last_3d)
+    out = ops.roi_pool_levels(cl(f1), cl(f2), dev(rois), dev(lv), 4, 0.25, out_channels_last=True)
+    assert torch.equal(out.cpu(), want)
+
+
+# ----------------------------------------------------------------------------- projection
+def test_projection_golden_bit_exact(ops, golden):
+    g = golden("projection_cases")
+    dims = tuple(int(v) for v in g["dims"])
+    feats, i3d, i2d = (torch.from_numpy(g[k]) for k in ("feats", "i3d", "i2d"))
+    for v in range(feats.shape[0]):
+        out = ops.projection(dev(feats[v]), dev(i3d[v]), dev(i2d[v]), dims)
+        assert np.array_equal(out.cpu().numpy(), g["out"][v])
+    out2 = ops.projection(dev(feats[0, 0]), dev(i3d[0]), dev(i2d[0]), dims)
+    assert np.array_equal(out2.cpu().numpy(), g["out2d"])
+
+
+@pytest.mark.parametrize("n_per_view,kill", [(3000, ()), (60000, ()), (3000, (1, 3)), (0, ())])
+def test_project_views_max_full_size(ops, oracle, n_per_view, kill):
+    dims = synthetic.CHUNK_DIMS
+    feats, i3d, i2d = synthetic.synth_views(0, n_views=5, n_per_view=n_per_view)
+    want = oracle.project_views_max(feats, i3d, i2d, dims, kill)          # logical (1,C,X,Y,Z)
+    for cl in (True, False):
+        got = ops.project_views_max(dev(feats), dev(i3d), dev(i2d), dims, kill, channels_last=cl)
+        assert got.shape == want.shape
+        if not cl:
+            assert got.stride() == want.stride()                          # the reference's (C,Z,Y,X) memory order
+        assert torch.equal(got.cpu(), want), (cl, n_per_view, kill)
+
+
+def test_project_views_single_view_is_plain_copy(ops, oracle):
+    dims = (16, 8, 12)
+    feats, i3d, i2d = synthetic.synth_views(1, n_views=1, n_per_view=100, channels=8, image_hw=(4, 5), dims=dims)
+    want = oracle.project_views_max(feats, i3d, i2d, dims)
+    got = ops.project_views_max(dev(feats), dev(i3d), dev(i2d), dims, channels_last=True)
+    assert torch.equal(got.cpu(), want)
+    assert (want < 0).any()                                               # negatives survive: no zero clamp with one view
+
+
+# --------------------------------------------------------------------------------- decode
+def test_proposal_decode_and_softmax(ops, oracle):
+    c = config.scannet_benchmark_cfg()
+    dims = (96, 48, 96)
+    g = torch.Generator().manual_seed(8)
+    for lv, A in ((1, 3), (2, 11)):
+        anchors = torch.from_numpy(oracle.generate_anchors((24, 12, 24), 4, config.anchor_sizes(c, lv)))
+        score = torch.randn(1, 2, 24, 12, 24, A, generator=g) * 3
+        bbox = torch.randn(1, 24, 12, 24, 6 * A, generator=g) * 0.5
+        prob_want = torch.softmax(score, 1)
+        prob = ops.softmax2(dev(score))
+        assert (prob.cpu() - prob_want).abs().max() <= 1e-6
+        inds = oracle.inside_anchor_inds(anchors, dims)
+        want_b, want_s = oracle.decode_candidates(prob_want, bbox, anchors, inds, dims)
+        n = inds.numel()
+        ob, os_, ol = torch.empty(n, 6).cuda(), torch.empty(n).cuda(), torch.empty(n).cuda()
+        ops.proposal_decode(dev(anchors), dev(bbox), dev(prob_want)[0, 1], dev(inds.int()), dims, lv, ob, os_, ol)
+        assert (ob.cpu() - want_b).abs().max() <= 1e-4          # fp32 box tolerance (expf vs torch exp: <= 2 ulp)
+        assert torch.equal(os_.cpu(), want_s[:, 0])
+        assert (ol == lv).all()
