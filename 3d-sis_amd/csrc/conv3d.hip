@@ -26,6 +26,7 @@
 //
 // This file may use FMA freely (fp32 tolerance 1e-4 applies, not bit-exactness).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -53,23 +54,30 @@ struct ConvArgs {
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // KS: kernel size (1,2,3); S: stride; brick BX*BY*BZ = 32*MW output voxels; NW waves along cout, each NTW
-// 32-wide cout tiles; CK channels per LDS chunk.
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int NTW, int CK>
-__global__ __launch_bounds__(64 * MW *NW) void conv3d_mfma_kernel(const ConvArgs a)
+// 32-wide cout tiles; KW waves split the reduction (taps for k=2/3, channel groups for k=1) of the SAME
+// output tile and are summed through LDS at the end (intra-workgroup split-K: no atomics, deterministic);
+// CK channels per LDS chunk (k=1: CK == cin, a single chunk).
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK>
+__global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const ConvArgs a)
 {
     static_assert(BX * BY * BZ == 32 * MW, "brick must hold 32*MW voxels");
     constexpr int T = KS * KS * KS;
+    constexpr bool SPLIT_TAPS = (KS != 1);
+    static_assert(!SPLIT_TAPS || T % KW == 0, "taps must split evenly over the KW waves");
+    constexpr int TPW = SPLIT_TAPS ? T / KW : 1;           // taps per wave
     constexpr int PAD = (KS == 3) ? 1 : 0;
     constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
     constexpr int ROWS = IBX * IBY * IBZ;
-    constexpr int RS = CK + 4;                 // padded LDS row stride (floats)
-    constexpr int KGC = CK / 8;                // k-groups (8 channels) per chunk
-    constexpr int NTHREADS = 64 * MW * NW;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [ROWS][RS]
+    constexpr int RS = CK + 4;                             // padded LDS row stride (floats)
+    constexpr int KGC = CK / 8;                            // k-groups (8 channels) per chunk
+    static_assert(SPLIT_TAPS || KGC % KW == 0, "channel groups must split evenly over the KW waves");
+    constexpr int KGW = SPLIT_TAPS ? KGC : KGC / KW;       // k-groups this wave consumes per tap
+    constexpr int NTHREADS = 64 * MW * NW * KW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [ROWS][RS], later reused for the split-K reduction
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mw = wave % MW, nw = wave / MW;
+    const int mw = wave % MW, nw = (wave / MW) % NW, kw = wave / (MW * NW);
     const int li = lane & 31, kh = lane >> 5;
 
     // block -> (brick, cout group); bricks vary fastest so neighbouring blocks share weight tiles in L2
@@ -85,11 +93,11 @@ __global__ __launch_bounds__(64 * MW *NW) void conv3d_mfma_kernel(const ConvArgs
     const int m = 32 * mw + li;
     const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
     const int arow = ((S * lx) * IBY + S * ly) * IBZ + S * lz;
-    const float *aptr = lds + arow * RS + 4 * kh;
+    const float *aptr = lds + arow * RS + 4 * kh + (SPLIT_TAPS ? 0 : 8 * KGW * kw);
 
     const int tile0 = (group * NW + nw) * NTW;                       // first 32-wide cout tile of this wave
     const int kgtot = a.cin / 8;
-    const int nchunks = a.cin / CK;
+    const int nchunks = SPLIT_TAPS ? a.cin / CK : 1;
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -97,17 +105,36 @@ __global__ __launch_bounds__(64 * MW *NW) void conv3d_mfma_kernel(const ConvArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    float4 bcur[NTW][KGC], bnxt[NTW][KGC];
-    auto load_b = [&](float4(&dst)[NTW][KGC], int q, int tap) {
+    // ---- software pipeline at k-group granularity.  One step = one group of 8 input channels of one tap =
+    // one 16 B A fragment (LDS) + one 16 B B fragment per cout tile (global, fragment-order packed) + 4 MFMAs per
+    // tile.  B fragments are fetched DB-1 steps ahead (L2 latency), A fragments one step ahead (LDS latency);
+    // rings are indexed with compile-time constants (the step loop is fully unrolled) and the order is pinned
+    // with sched_barrier so hipcc cannot sink the loads next to their use.  Small rings keep the kernel at
+    // <= 64 VGPRs -> 8 waves/SIMD, which is what hides the per-chunk LDS refill of the other workgroups.
+    constexpr int NS = TPW * KGW;                          // steps per chunk for this wave
+    constexpr int DB = (NS % 4 == 0) ? 4 : (NS % 3 == 0) ? 3 : (NS % 2 == 0) ? 2 : 1;
+    constexpr int DA = 2;                                  // A ring restarts at slot 0 every chunk: no wrap constraint
+    float4 bq[DB][NTW];
+    float4 aq[DA];
+    auto load_b = [&](float4(&dst)[NTW], int q, int s) {
+        const int ti = s / KGW, g = s % KGW;
+        const int tap = SPLIT_TAPS ? kw + KW * ti : 0;
+        const int kg = SPLIT_TAPS ? q * KGC + g : KGW * kw + g;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int tile = min(tile0 + t, a.ntiles - 1);           // clamp: surplus tiles recompute the last one, never stored
-            const float4 *p = reinterpret_cast<const float4 *>(a.wp) + ((size_t)(tile * T + tap) * kgtot + q * KGC) * 64 + lane;
-#pragma unroll
-            for (int g = 0; g < KGC; ++g) dst[t][g] = p[g * 64];
+            dst[t] = reinterpret_cast<const float4 *>(a.wp)[((size_t)(tile * T + tap) * kgtot + kg) * 64 + lane];
         }
     };
-    load_b(bcur, 0, 0);
+    auto load_a = [&](float4 &dst, int s) {
+        const int ti = s / KGW, g = s % KGW;
+        const int tap = SPLIT_TAPS ? kw + KW * ti : 0;
+        const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
+        dst = *reinterpret_cast<const float4 *>(aptr + ((dx * IBY + dy) * IBZ + dz) * RS + 8 * g);
+    };
+#pragma unroll
+    for (int d = 0; d < (DB > 1 ? DB - 1 : 1); ++d)
+        if (d < NS) load_b(bq[d], 0, d);
 
     for (int q = 0; q < nchunks; ++q) {
         if (q) __syncthreads();
@@ -122,32 +149,48 @@ __global__ __launch_bounds__(64 * MW *NW) void conv3d_mfma_kernel(const ConvArgs
             *reinterpret_cast<float4 *>(lds + row * RS + c4 * 4) = v;
         }
         __syncthreads();
-        // ---- 27 / 8 / 1 taps out of the same LDS image
-#pragma unroll 1
-        for (int tap = 0; tap < T; ++tap) {
-            // prefetch the next tap's (or next chunk's first) weight fragments
-            const bool last = (tap == T - 1);
-            if (!last) load_b(bnxt, q, tap + 1);
-            else if (q + 1 < nchunks) load_b(bnxt, q + 1, 0);
-            const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
-            const float *ap = aptr + ((dx * IBY + dy) * IBZ + dz) * RS;
-            float4 af[KGC];
+        load_a(aq[0], 0);
 #pragma unroll
-            for (int g = 0; g < KGC; ++g) af[g] = *reinterpret_cast<const float4 *>(ap + 8 * g);
-#pragma unroll
-            for (int g = 0; g < KGC; ++g) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bcur[t][g].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bcur[t][g].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bcur[t][g].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bcur[t][g].w, acc[t], 0, 0, 0);
-                }
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (DB > 1) {
+                const int sn = s + DB - 1;                 // wraps into the next chunk's first steps
+                if (sn < NS) load_b(bq[sn % DB], q, sn);
+                else if (q + 1 < nchunks) load_b(bq[sn % DB], q + 1, sn - NS);
             }
+            if (s + 1 < NS) load_a(aq[(s + 1) % DA], s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 av = aq[s % DA];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const float4 bv = bq[s % DB][t];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- split-K reduction through LDS: waves kw>0 publish, waves kw==0 accumulate and run the epilogue
+    if constexpr (KW > 1) {
+        __syncthreads();                                   // everyone is done reading the A image
+        if (kw > 0) {
+            float *red = lds + ((size_t)((kw - 1) * (MW * NW) + nw * MW + mw) * NTW) * 1024;
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                for (int g = 0; g < KGC; ++g) bcur[t][g] = bnxt[t][g];
+                for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (kw > 0) return;
+#pragma unroll
+        for (int k = 1; k < KW; ++k) {
+            const float *red = lds + ((size_t)((k - 1) * (MW * NW) + nw * MW + mw) * NTW) * 1024;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) * 64 + lane];
         }
     }
 
@@ -243,52 +286,90 @@ __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restri
     }
 }
 
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int NTW, int CK>
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK>
 int launch_cfg(ConvArgs &a, hipStream_t st)
 {
     constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
-    constexpr size_t lds = (size_t)IBX * IBY * IBZ * (CK + 4) * sizeof(float);
+    constexpr size_t tile_b = (size_t)IBX * IBY * IBZ * (CK + 4) * sizeof(float);
+    constexpr size_t red_b = (size_t)(KW - 1) * MW * NW * NTW * 1024 * sizeof(float);
+    constexpr size_t lds = tile_b > red_b ? tile_b : red_b;
     static_assert(lds <= 160 * 1024, "LDS brick too large");
+    static_assert(64 * MW * NW * KW <= 1024, "workgroup too large");
     a.nbx = cdiv(a.OX, BX); a.nby = cdiv(a.OY, BY); a.nbz = cdiv(a.OZ, BZ);
     a.ngroups = cdiv(a.ntiles, NW * NTW);
-    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, NTW, CK>;
+    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK>;
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
     }
     const int64_t blocks = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * MW * NW), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * MW * NW * KW), lds, st, a);
     return sis3d_check_launch();
 }
 
-// pick the tiling so that a launch has >= ~1k waves where the layer allows it (256 CUs x 4 SIMDs)
+// ---- tiling choice.  The chip has 1024 SIMDs; a 32x32 output tile is the work quantum of one wave, and the
+// layers of this network have only 216..1728 such tiles, so the reduction is split over KW waves per tile
+// (taps for k=3/2, channel groups for k=1) to put >= ~2-5 waves on every SIMD.
 template <int KS, int S>
 int dispatch(ConvArgs &a, hipStream_t st)
 {
-    const int64_t nvox = (int64_t)a.OX * a.OY * a.OZ;
-    const int ck = (a.cin % 32 == 0) ? 32 : 8;
     if (a.cin % 8) return SIS3D_EUNSUPPORTED;
+    const int64_t nvox = (int64_t)a.OX * a.OY * a.OZ;
     const bool big = nvox >= 32768;            // 48x24x48-class layers
-    if constexpr (S == 2) {
-        // k2 s2: input brick is 2x the output brick per axis; keep it small
-        if (ck == 32) {
-            if (a.ntiles >= 4) return launch_cfg<KS, S, 2, 4, 4, 1, 4, 1, 32>(a, st);
-            if (a.ntiles >= 2) return launch_cfg<KS, S, 2, 4, 4, 1, 2, 1, 32>(a, st);
-            return launch_cfg<KS, S, 4, 4, 4, 2, 1, 1, 32>(a, st);
+    if constexpr (KS == 1) {
+        // k=1: one LDS chunk holds all input channels (CK == cin)
+        switch (a.cin) {
+        case 8:
+            return launch_cfg<1, 1, 4, 4, 4, 2, 1, 1, 1, 8>(a, st);
+        case 32:
+            if (a.ntiles >= 4) return launch_cfg<1, 1, 2, 4, 4, 1, 4, 2, 1, 32>(a, st);
+            if (big) return launch_cfg<1, 1, 4, 4, 4, 2, 1, 2, 1, 32>(a, st);
+            return launch_cfg<1, 1, 2, 4, 4, 1, 1, 4, 1, 32>(a, st);
+        case 64:
+            if (a.ntiles >= 4) return launch_cfg<1, 1, 2, 4, 4, 1, 4, 2, 1, 64>(a, st);
+            if (a.ntiles >= 2) return launch_cfg<1, 1, 2, 4, 4, 1, 2, 4, 1, 64>(a, st);
+            return launch_cfg<1, 1, 2, 4, 4, 1, 1, 4, 1, 64>(a, st);
+        case 128:
+            if (a.ntiles >= 2) return launch_cfg<1, 1, 2, 4, 4, 1, 2, 4, 1, 128>(a, st);
+            return launch_cfg<1, 1, 2, 4, 4, 1, 1, 8, 1, 128>(a, st);
+        case 256:
+            if (a.ntiles >= 2) return launch_cfg<1, 1, 2, 4, 4, 1, 2, 4, 1, 256>(a, st);
+            return launch_cfg<1, 1, 2, 4, 4, 1, 1, 8, 1, 256>(a, st);
+        default:
+            return SIS3D_EUNSUPPORTED;
         }
-        return launch_cfg<KS, S, 2, 4, 4, 1, 2, 1, 8>(a, st);
+    } else if constexpr (S == 2) {
+        // k2 s2: the input brick is 2x the output brick per axis -> small output bricks; 8 taps over KW=2/4 waves
+        if (a.cin % 32 == 0) {
+            if (a.ntiles >= 4) return launch_cfg<2, 2, 2, 4, 4, 1, 4, 2, 1, 32>(a, st);
+            if (a.ntiles >= 2) return launch_cfg<2, 2, 2, 4, 4, 1, 2, 4, 1, 32>(a, st);
+            return launch_cfg<2, 2, 2, 4, 4, 1, 1, 4, 1, 32>(a, st);
+        }
+        return launch_cfg<2, 2, 2, 4, 4, 1, 2, 2, 1, 8>(a, st);
     } else {
-    if (ck == 8) {
-        if (a.ntiles >= 2) return launch_cfg<KS, S, 4, 4, 4, 2, 2, 1, 8>(a, st);
-        return launch_cfg<KS, S, 4, 4, 8, 4, 1, 1, 8>(a, st);
-    }
-    if (big) {
-        if (a.ntiles >= 2) return launch_cfg<KS, S, 4, 4, 8, 4, 1, 2, 32>(a, st);
-        return launch_cfg<KS, S, 4, 4, 8, 4, 1, 1, 32>(a, st);
-    }
-    // small volumes (24x12x24, mask crops): 64-voxel bricks, 32x32 per wave for occupancy
-    if (a.ntiles >= 2) return launch_cfg<KS, S, 4, 4, 4, 2, 2, 1, 32>(a, st);
-    return launch_cfg<KS, S, 4, 4, 4, 2, 1, 1, 32>(a, st);
+        // k3 p1: 27 taps over KW=3 waves (9 each)
+        if (a.cin % 32) {
+            if (a.ntiles >= 2) return launch_cfg<3, 1, 4, 4, 4, 2, 2, 3, 1, 8>(a, st);
+            return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 1, 8>(a, st);
+        }
+        if (big) {
+            if (a.ntiles >= 2) return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 2, 32>(a, st);
+            return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 1, 32>(a, st);
+        }
+        // tuning hook (tools/conv_tune.py): SIS3D_K3_VARIANT selects an alternative tiling for the small-volume k3 layers
+        static const int variant = [] { const char *e = getenv("SIS3D_K3_VARIANT"); return e ? atoi(e) : 0; }();
+        if (a.ntiles >= 2) {
+            switch (variant) {
+            case 1: return launch_cfg<3, 1, 2, 4, 4, 1, 4, 3, 1, 32>(a, st);
+            case 2: return launch_cfg<3, 1, 4, 4, 4, 2, 2, 1, 1, 32>(a, st);
+            case 3: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 3, 1, 32>(a, st);
+            case 4: return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
+            case 5: return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 2, 32>(a, st);
+            case 6: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 1, 1, 32>(a, st);
+            default: return launch_cfg<3, 1, 4, 4, 4, 2, 2, 3, 1, 32>(a, st);
+            }
+        }
+        return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 1, 32>(a, st);
     }
 }
 

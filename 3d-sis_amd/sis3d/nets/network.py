@@ -71,25 +71,6 @@ class Network(nn.Module):
             self._head_cache[lv] = hit
         return hit[1]
 
-    # network.py:537-574
-    def _region_proposal(self, net_conv_level1, net_conv_level2, net_conv_level3):
-        cfg = self.cfg
-        levels = []
-        for lv, feat in ((1, net_conv_level1), (2, net_conv_level2), (3, net_conv_level3)):
-            A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
-            if A == 0:
-                continue
-            rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
-            score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
-            prob = ops.softmax2(score)
-            self._predictions["rpn_cls_score_level%d" % lv] = score
-            self._predictions["rpn_cls_prob_level%d" % lv] = prob
-            self._predictions["rpn_bbox_pred_level%d" % lv] = bbox
-            anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
-            setattr(self, "_anchors_level%d" % lv, anchors)
-            levels.append((lv, prob, bbox, anchors))
-        self._prop = self._proposals.run(levels, self._scene_info[:3], "TEST")
-
     # network.py:503-534 + backbones.py:92-96 + network.py:589-604, on the padded K rows
     def _classify_rois(self, l1, l2):
         cfg, p = self.cfg, self._prop
@@ -141,12 +122,50 @@ class Network(nn.Module):
         return [masks]
 
     # ------------------------------------------------------------------ forward --
+    def backbone_rpn(self, scene, imageft=None):
+        """Device-only: backbone + RPN convs/heads/softmax (BASELINE config 1).  Fills the rpn_* predictions."""
+        self._scene = scene
+        self._scene_info = scene.shape[2:]
+        if imageft is not None:
+            self._imageft = imageft
+        l1, l2, l3 = self._backbone()
+        self._net_conv = (l1, l2)
+        levels = []
+        cfg = self.cfg
+        for lv, feat in ((1, l1), (2, l2)):
+            A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
+            if A == 0:
+                continue
+            rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
+            score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
+            prob = ops.softmax2(score)
+            self._predictions["rpn_cls_score_level%d" % lv] = score
+            self._predictions["rpn_cls_prob_level%d" % lv] = prob
+            self._predictions["rpn_bbox_pred_level%d" % lv] = bbox
+            anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
+            setattr(self, "_anchors_level%d" % lv, anchors)
+            levels.append((lv, prob, bbox, anchors))
+        return l1, l2, levels
+
+    def detect(self, scene, imageft=None):
+        """Device-only, fixed-shape, sync-free detection pass (graph-capturable): backbone -> RPN ->
+        decode/sort/NMS -> two-level RoI pooling -> classifier, on K = RPN_POST_NMS_TOP_N padded rows.
+        Returns a dict of padded device tensors + `num` (int32 [1]) = number of valid rows."""
+        l1, l2, levels = self.backbone_rpn(scene, imageft)
+        self._prop = self._proposals.run(levels, self._scene_info[:3], "TEST")
+        out = dict(rois=self._prop["rois"], scores=self._prop["scores"], levels=self._prop["levels"], num=self._prop["num"])
+        if self.cfg.USE_CLASS:
+            out["cls_score"], out["cls_pred"], out["cls_prob"], out["bbox_pred"] = self._classify_rois(l1, l2)
+        return out
+
     def forward(self, blobs, mode="TRAIN", killing_inds=None):
         if mode != "TEST":
             raise NotImplementedError("forward-only build: mode must be 'TEST' (training is out of scope, SURVEY.md 2)")
         cfg = self.cfg
         if blobs["data"].shape[0] != 1:
             raise NotImplementedError("batch size 1 (as the reference's TEST path)")
+        if not (cfg.USE_BACKBONE and cfg.USE_RPN):
+            raise NotImplementedError("USE_BACKBONE/USE_RPN=False (ground-truth boxes as RoIs) are training/debug modes")
         self._scene_info = blobs["data"].shape[2:]
         self._id = blobs["id"][0]
         self.batch_size = 1
@@ -154,34 +173,26 @@ class Network(nn.Module):
         dev = torch.device("cuda", torch.cuda.current_device())
         with torch.no_grad():
             self.eval()
-            self._scene = blobs["data"].to(dev, non_blocking=True).float()
+            scene = blobs["data"].to(dev, non_blocking=True).float()
             self._gt_bbox = blobs.get("gt_box")
             self._gt_mask = blobs.get("gt_mask") if cfg.USE_MASK else None
+            imageft = None
             if cfg.USE_IMAGES:
                 if not cfg.USE_IMAGES_GT:
                     raise NotImplementedError("ENet encoder not part of this build; pass feature maps (USE_IMAGES_GT)")
                 feats = blobs["nearest_images"]["images"][0].to(dev, non_blocking=True)
                 p3 = blobs["proj_ind_3d"][0].to(dev, non_blocking=True)
                 p2 = blobs["proj_ind_2d"][0].to(dev, non_blocking=True)
-                self._imageft = ops.project_views_max(feats, p3, p2, self._scene_info, killing_inds or (), channels_last=True)
-            if cfg.USE_BACKBONE:
-                l1, l2, l3 = self._backbone()
-                self._net_conv = (l1, l2)
-            if not cfg.USE_RPN:
-                raise NotImplementedError("USE_RPN=False (ground-truth boxes as RoIs) is a training/debug mode")
-            self._region_proposal(l1, l2, l3)
-            outs = None
-            if cfg.USE_CLASS:
-                outs = self._classify_rois(l1, l2)
+                imageft = ops.project_views_max(feats, p3, p2, self._scene_info, killing_inds or (), channels_last=True)
+            d = self.detect(scene, imageft)
             # the only host sync of the detection path: number of surviving RoIs
-            n = int(self._prop["num"].item())
-            p = self._prop
-            self._predictions["rois"] = [p["rois"][:n]]
-            self._predictions["roi_scores"] = [p["scores"][:n].view(-1, 1)]
-            self._predictions["level_inds"] = [p["levels"][:n]]
+            n = int(d["num"].item())
+            self._predictions["rois"] = [d["rois"][:n]]
+            self._predictions["roi_scores"] = [d["scores"][:n].view(-1, 1)]
+            self._predictions["level_inds"] = [d["levels"][:n]]
             if cfg.USE_CLASS:
-                for k, v in zip(("cls_score", "cls_pred", "cls_prob", "bbox_pred"), outs):
-                    self._predictions[k] = v[:n]
+                for k in ("cls_score", "cls_pred", "cls_prob", "bbox_pred"):
+                    self._predictions[k] = d[k][:n]
                 if cfg.USE_MASK:
                     self._predictions["mask_pred"] = self._mask_branch(n)
         return self._predictions

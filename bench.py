@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- voxels/sec of the 3D-SIS forward hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload backbone_rpn|detect|images] [--no-graph]
+
+One process per GPU (for N>1 the driver launches this under torch.distributed.run; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the env).  A step = one pass of the hot path over one synthetic
+96x48x96 chunk per rank, inputs already resident in HBM (static buffers of the ChunkEngine); weights
+are seeded synthetic (no checkpoints exist offline).  Chunks are independent, so ranks share nothing
+on the data path (scaling: weak); the per-scene proposal all-gather is exercised by `--workload scene`.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     -- dominant kernel (the k3 128->256 RPN conv, 12.2 GFLOP/launch): achieved = algorithmic FLOPs /
+                  mean launch duration measured live with HIP events on the launch stream; peak = 157.3 TF
+                  (fp32 MFMA == fp32 vector peak of gfx950).  The HBM-roof fraction of the whole step is given
+                  beside it (the metric's "% HBM roofline"): algorithmic bytes per chunk / step time / 8 TB/s.
+  cpu_baseline -- the CPU oracle (torch-CPU operators = what the reference's MAX_VOLUME=0 path runs) timed on
+                  this box's host cores on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
+
+import torch  # noqa: E402
+
+VOXELS = 96 * 48 * 96
+# algorithmic work per chunk
+ALGO = {
+    "backbone_rpn": dict(bytes=261.4e6, flops=42.58e9),
+    "detect": dict(bytes=261.4e6 + 2 * 3.54e6 + 200 * 32768 + 8.4e6, flops=42.58e9 + 0.9e9),
+    "images": dict(bytes=517e6 + 28.3e6 + 59.8e6 + 226.5e6, flops=29.1e9 + 24.86e9),
+}
+DOMINANT_FLOPS = 2.0 * 6912 * 256 * 128 * 27        # rpn_net_level{1,2}: 12.23 GFLOP per launch
+FP32_PEAK_TF = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_net(workload):
+    from sis3d import config, synthetic
+    from sis3d.nets import backbones
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES = workload == "images"
+    cfg.USE_MASK = False
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    return net.cuda().eval(), cfg, sd
+
+
+def time_dominant_kernel(net, iters=50):
+    """mean duration of the rpn_net k3 128->256 conv launch, HIP events on the launch (current) stream"""
+    from sis3d import ops
+    l1 = net._net_conv[0]
+    conv = net.rpn_net_level1
+    for _ in range(5):
+        conv(l1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        conv(l1)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def cpu_baseline(workload, sd, cfg, seconds):
+    """the oracle's backbone+RPN (torch CPU operators, as the reference's CPU path) on the host cores"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sis3d_oracle as orc
+    from sis3d import config, synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = orc.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
+    data = synthetic.synth_chunk(0)
+    feats = i3d = i2d = None
+    if workload == "images":
+        feats, i3d, i2d = synthetic.synth_views(0)
+
+    def one():
+        with torch.no_grad():
+            if workload == "detect":
+                net.forward(data, feats, i3d, i2d)
+            else:
+                imageft = orc.project_views_max(feats, i3d, i2d, data.shape[2:]) if workload == "images" else None
+                l1, l2 = net.backbone(data, imageft)
+                net.rpn(l1, 1)
+                net.rpn(l2, 2)
+    one()
+    n, t0 = 0, time.time()
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 >= seconds or n >= 200:
+            break
+    dt = time.time() - t0
+    return dict(value=VOXELS * n / dt, unit="voxels/s", cores=cores, kind="port",
+                sample="%d forward passes (%s, oracle on torch-CPU ops, %d threads) in %.1f s" % (n, workload, cores, dt))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    from sis3d import synthetic, ops
+    from sis3d.engine import ChunkEngine
+    ops.lib()
+    net, cfg, sd = build_net(args.workload)
+    stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
+    eng = ChunkEngine(net, stage=stage, use_graph=not args.no_graph)
+    data = synthetic.synth_chunk(rank)
+    if args.workload == "images":
+        feats, i3d, i2d = synthetic.synth_views(rank)
+        eng.load(data.cuda(), feats.cuda(), i3d.cuda(), i2d.cuda())
+    else:
+        eng.load(data.cuda())
+    eng.prepare(warmup=2)
+    for _ in range(args.warmup):
+        eng.run()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = world * VOXELS * args.steps / dt
+
+    if rank == 0:
+        kt = time_dominant_kernel(net)
+        algo = ALGO[args.workload]
+        line = {
+            "metric": "voxels/sec forward on 96x48x96 chunks",
+            "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"backbone_rpn": "config[1]: one 96x48x96 chunk per GPU, geometry-only, HIP 3D-conv backbone + RPN "
+                                                    "(convs, heads, softmax), weights seeded synthetic",
+                                    "detect": "config[2] minus mask head: backbone + RPN + decode/sort/NMS + RoI pooling + classifier",
+                                    "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN"}[args.workload],
+                       "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,1,...> rpn_net 128->256 (fp32 v_mfma_f32_32x32x2_f32)",
+                         "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": DOMINANT_FLOPS / kt / 1e12 / FP32_PEAK_TF, "traffic": None,
+                         "launch_us": kt * 1e6},
+            "step_roofline": {"hbm_frac": algo["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "hbm_gbs_algorithmic": algo["bytes"] / (ms * 1e-3) / 1e9,
+                              "fp32_frac": algo["flops"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                              "binding": "fp32 FLOPs (AI 163 FLOP/B >> 20 FLOP/B machine balance)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, sd, cfg, args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

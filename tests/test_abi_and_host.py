@@ -1,0 +1,103 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sis3d.h declares (no compute
+without a GPU), the ctypes table matches the header, the product fails loudly instead of falling back,
+the product never touches oracle/, and the host-side mirror keeps the reference's contracts."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "3d-sis_amd")
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "sis3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sis3d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sis3d import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["python", os.path.join(PKG, "build.py")])
+    l = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(l, s), "libsis3d_hip.so does not export %s" % s
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+    assert l.sis3d_abi_version() == 1
+    assert l.sis3d_strerror(-1).decode().startswith("invalid")
+    # size helpers are host-only and safe without a GPU
+    assert l.sis3d_conv_packed_floats(256, 128, 3) == 8 * 27 * 16 * 256
+    assert l.sis3d_nms_workspace_bytes(400) == 0 and l.sis3d_nms_workspace_bytes(6400) == 6400 * 100 * 8
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from sis3d import ops, _lib
+    from sis3d.layer_utils.nms_wrapper import nms
+    from sis3d.layer_utils.roi_pooling.roi_pool import RoIPoolFunction
+    from sis3d.layer_utils.projection import Projection
+    with pytest.raises(_lib.Sis3dError):
+        nms(torch.zeros(4, 6), 0.1)
+    with pytest.raises(_lib.Sis3dError):
+        RoIPoolFunction(4, 4, 4, 0.25)(torch.zeros(1, 8, 4, 4, 4), torch.zeros(2, 6))
+    with pytest.raises(_lib.Sis3dError):
+        Projection.apply(torch.zeros(4, 3, 3), torch.zeros(9, dtype=torch.int64), torch.zeros(9, dtype=torch.int64), (2, 2, 2))
+    with pytest.raises(_lib.Sis3dError):
+        ops.maxpool3(torch.zeros(1, 4, 2, 2, 2))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for d, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(d, f)).read()
+                if re.search(r"^\s*(import|from)\s+(sis3d_oracle|ref_harness|oracle)\b", txt, re.M) or "libsis3d_oracle" in txt:
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_checkpoint_contract_matches_survey_appendix_a():
+    from sis3d import config
+    from sis3d.nets.backbones import state_dict_shapes
+    c = config.scannet_benchmark_cfg()
+    sh = state_dict_shapes(c)
+    assert sh["geometry1.0.weight"] == (32, 2, 2, 2, 2)
+    assert sh["geometry1.4.weight"] == (128, 32, 2, 2, 2)
+    assert sh["geometry1.6.conv1.weight"] == (32, 128, 1, 1, 1) and sh["geometry1.6.conv3.bias"] == (128,)
+    assert sh["geometry2.0.weight"] == (128, 128, 3, 3, 3) and "geometry2.0.bias" not in sh
+    assert sh["rpn_net_level2.weight"] == (256, 128, 3, 3, 3)
+    assert sh["rpn_cls_score_net_level2.0.weight"] == (22, 256, 1, 1, 1)
+    assert sh["rpn_bbox_pred_net_level1.weight"] == (18, 256, 1, 1, 1)
+    assert sh["classifier.0.weight"] == (256, 8192)
+    assert sh["classifier_bbox_pred_net.weight"] == (114, 128)
+    assert sh["mask_backbone.geometry.10.weight"] == (19, 64, 1, 1, 1)
+    n = sum(int(np.prod(s)) for s in sh.values())
+    assert n == 5320821                                              # SURVEY Appendix A total
+    c.USE_IMAGES = True
+    sh2 = state_dict_shapes(c)
+    assert sh2["color.0.weight"] == (64, 128, 2, 2, 2) and sh2["geometry1.4.weight"] == (64, 32, 2, 2, 2)
+    assert sum(int(np.prod(s)) for s in sh2.values()) == 5458165
+
+
+def test_anchor_mirror_matches_golden(golden):
+    from sis3d import config
+    from sis3d.layer_utils.generate_anchors import generate_anchors
+    g = golden("anchors")
+    a1, a2, a3 = generate_anchors([3, 2, 4], [3, 2, 4], [], [4, 4, 4], config.scannet_benchmark_cfg())
+    assert np.array_equal(a1, g["small_l1"]) and np.array_equal(a2, g["small_l2"]) and a3 is None
+
+
+def test_host_bbox_codec_matches_oracle(oracle):
+    from sis3d.utils.bbox_transform import bbox_transform_inv, clip_boxes
+    g = torch.Generator().manual_seed(0)
+    boxes = torch.rand(50, 6, generator=g) * 40
+    boxes[:, 3:] += boxes[:, :3]
+    deltas = torch.randn(50, 6, generator=g) * 0.3
+    assert torch.equal(clip_boxes(bbox_transform_inv(boxes, deltas), (96, 48, 96)),
+                       oracle.clip_boxes(oracle.bbox_transform_inv(boxes, deltas), (96, 48, 96)))

@@ -1,0 +1,86 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo processes run the chunk sharding / record all-gather /
+whole-scene NMS logic of sis3d.parallel with the CPU ORACLE injected as detector and NMS (test-only);
+the result must equal the single-process run and be identical on every rank."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_detect(payload):
+    """deterministic pseudo-detections per chunk (stands in for the per-chunk pipeline)"""
+    from sis3d.engine import RECORD_WIDTH
+    cid = payload
+    g = torch.Generator().manual_seed(100 + cid)
+    k = 12
+    n = 5 + cid % 7
+    lo = torch.rand(k, 3, generator=g) * torch.tensor([80.0, 40.0, 80.0])
+    rec = torch.zeros(k, RECORD_WIDTH)
+    rec[:, :3] = lo
+    rec[:, 3:6] = lo + torch.rand(k, 3, generator=g) * 30 + 1
+    rec[:, 6] = torch.rand(k, generator=g).round(decimals=1)     # coarse scores -> many ties across chunks
+    rec[:, 7] = 1 + (cid % 2)
+    return rec, n
+
+
+def _chunks(n):
+    return [(c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), c) for c in range(n)]
+
+
+def _worker(rank, world, port, n_chunks, out_dir):
+    for p in (os.path.join(ROOT, "3d-sis_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sis3d import parallel
+    import sis3d_oracle as orc
+    recs, keep = parallel.infer_scene(_chunks(n_chunks), _fake_detect, orc.nms, 12, 0.1)
+    torch.save((recs, keep), os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_chunks", [(2, 8), (2, 5), (3, 7)])
+def test_sharded_scene_equals_single_process(tmp_path, world, n_chunks, oracle):
+    from sis3d import parallel
+    want_recs, want_keep = parallel.infer_scene(_chunks(n_chunks), _fake_detect, oracle.nms, 12, 0.1)
+    assert want_recs.shape[0] == sum(5 + c % 7 for c in range(n_chunks))
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_chunks, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        recs, keep = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        assert torch.equal(recs, want_recs), r
+        assert torch.equal(keep, want_keep), r
+
+
+def test_pack_and_merge_rules(oracle):
+    from sis3d import parallel
+    from sis3d.engine import RECORD_WIDTH
+    assert parallel.shard_chunks(7, 1, 3) == [1, 4]
+    rec, n = _fake_detect(3)
+    blk = parallel.pack_block(rec, torch.tensor([n], dtype=torch.int32), (96.0, 0.0, 192.0))
+    assert blk.numel() == parallel.block_floats(12) and blk[0] == n
+    rows = blk[1:].view(12, RECORD_WIDTH)
+    assert torch.equal(rows[:n, 0], rec[:n, 0] + 96.0) and torch.equal(rows[:n, 5], rec[:n, 5] + 192.0)
+    assert (rows[n:] == 0).all()
+    # ties: stable order = (chunk,row)
+    blocks = torch.stack([parallel.pack_block(*_fake_detect(c), (0.0, 0.0, 0.0)) for c in range(3)])
+    recs, keep = parallel.merge_scene(blocks, 12, oracle.nms, 0.1)
+    s = recs[:, 6]
+    assert (s[:-1] >= s[1:]).all()
+    assert torch.equal(keep, oracle.nms(recs[:, :6].contiguous(), 0.1))

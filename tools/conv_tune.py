@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Micro-benchmark of sis3d.ops.conv3d on the network's layer shapes (HIP events on the launch stream).
+Usage (GPU box): python tools/conv_tune.py [layer ...]; env SIS3D_K3_VARIANT selects tiling variants."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
+from sis3d import ops  # noqa: E402
+
+LAYERS = {  # name: (cin, cout, k, dims)
+    "rpn": (128, 256, 3, (24, 12, 24)), "g2_0": (128, 128, 3, (24, 12, 24)), "g2_b": (64, 64, 3, (24, 12, 24)),
+    "g1_b1": (32, 32, 3, (48, 24, 48)), "g1_b2": (32, 32, 3, (24, 12, 24)),
+    "k1_32_32": (32, 32, 1, (48, 24, 48)), "k1_128_32": (128, 32, 1, (24, 12, 24)), "k1_32_128": (32, 128, 1, (24, 12, 24)),
+    "k1_128_64": (128, 64, 1, (24, 12, 24)), "k1_64_128": (64, 128, 1, (24, 12, 24)), "head_88": (256, 88, 1, (24, 12, 24)),
+    "k2_32_128": (32, 128, 2, (48, 24, 48)), "color0": (128, 64, 2, (96, 48, 96)),
+}
+
+
+def main():
+    names = sys.argv[1:] or list(LAYERS)
+    for n in names:
+        cin, cout, k, dims = LAYERS[n]
+        x = ops.new_act(cin, dims, torch.device("cuda"))
+        x.normal_()
+        w = torch.randn(cout, cin, k, k, k, device="cuda") * 0.05
+        pc = ops.PackedConv(w, torch.zeros(cout, device="cuda"))
+        st = 2 if k == 2 else 1
+        for _ in range(5):
+            ops.conv3d(x, pc, stride=st, relu=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        it = 50
+        e0.record()
+        for _ in range(it):
+            ops.conv3d(x, pc, stride=st, relu=True)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / it * 1e3
+        od = [d // st for d in dims]
+        fl = 2.0 * od[0] * od[1] * od[2] * cout * cin * k ** 3
+        by = 4.0 * (dims[0] * dims[1] * dims[2] * cin + od[0] * od[1] * od[2] * cout + cout * cin * k ** 3)
+        print("%-10s variant=%s  %8.1f us  %6.1f TF  %6.0f GB/s" % (n, os.environ.get("SIS3D_K3_VARIANT", "0"), us, fl / us / 1e6, by / us / 1e3))
+
+
+if __name__ == "__main__":
+    main()
