@@ -80,8 +80,15 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
     const int mw = wave % MW, nw = (wave / MW) % NW, kw = wave / (MW * NW);
     const int li = lane & 31, kh = lane >> 5;
 
-    // block -> (brick, cout group); bricks vary fastest so neighbouring blocks share weight tiles in L2
-    int bid = blockIdx.x;
+    // block -> (brick, cout group).  XCD-aware: the dispatcher places block b on XCD b % 8, each with a private
+    // 4 MiB L2; remap so every XCD owns one CONTIGUOUS range of the (group-major, brick-minor) work list, i.e.
+    // touches one or two cout groups -> its weight working set (<= 0.9 MB per group) stays L2-resident instead of
+    // all 8 L2s streaming the whole weight tensor.  Bijective for any grid size.  (+3 % on the k3 layers.)
+    int bid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
+        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
     const int nbricks = a.nbx * a.nby * a.nbz;
     const int group = bid / nbricks;
     bid -= group * nbricks;

@@ -99,12 +99,12 @@ class Base_Backbone(Network):
         return nn.Sequential(nn.Linear(self._net_conv_level1_channels * ps * ps * ps, 256), nn.ReLU(True),
                              nn.Linear(256, 256), nn.ReLU(True), nn.Linear(256, 128), nn.ReLU(True))
 
-    # backbones.py:98-113
-    def _backbone(self):
+    # backbones.py:98-113, split at level1 so the network can overlap the level-1 RPN branch with geometry2
+    def _backbone_level1(self):
         cfg = self.cfg
         if cfg.USE_IMAGES and cfg.ONLY_IMAGES:
-            l1 = self.color(self._imageft)
-        elif cfg.USE_IMAGES:
+            return self.color(self._imageft)
+        if cfg.USE_IMAGES:
             # torch.cat([color, geometry], 1) (backbones.py:109): the last geometry Bottleneck writes its
             # channel range of the concatenated tensor directly (conv epilogue channel offset)
             col = self.color(self._imageft)
@@ -116,10 +116,15 @@ class Base_Backbone(Network):
             l1 = ops.new_act(cc + gc, col.shape[2:], col.device)
             l1[:, :cc] = col
             mods[-1](g, out=l1, out_coff=cc)
-        else:
-            l1 = self.geometry1(self._scene)
-        l2 = self.geometry2(l1)
-        return l1, l2, None
+            return l1
+        return self.geometry1(self._scene)
+
+    def _backbone_level2(self, l1):
+        return self.geometry2(l1)
+
+    def _backbone(self):
+        l1 = self._backbone_level1()
+        return l1, self._backbone_level2(l1), None
 
 
 class SUNCG_Backbone(Base_Backbone):

@@ -29,6 +29,8 @@ class Network(nn.Module):
         self._losses = {}
         self._proposals = ProposalEngine(self.cfg)
         self._head_cache = {}
+        self._side = None
+        self.overlap_branches = True      # fork the level-1 RPN branch onto a second stream
 
     # network.py:35-64
     def init_modules(self):
@@ -122,30 +124,56 @@ class Network(nn.Module):
         return [masks]
 
     # ------------------------------------------------------------------ forward --
+    def _rpn_level(self, lv, feat):
+        """network.py:539-549 for one pyramid level: k3 conv + ReLU, fused cls/bbox 1x1x1 heads, 2-way softmax"""
+        cfg = self.cfg
+        A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
+        rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
+        score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
+        prob = ops.softmax2(score)
+        self._predictions["rpn_cls_score_level%d" % lv] = score
+        self._predictions["rpn_cls_prob_level%d" % lv] = prob
+        self._predictions["rpn_bbox_pred_level%d" % lv] = bbox
+        anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
+        setattr(self, "_anchors_level%d" % lv, anchors)
+        return (lv, prob, bbox, anchors)
+
     def backbone_rpn(self, scene, imageft=None):
-        """Device-only: backbone + RPN convs/heads/softmax (BASELINE config 1).  Fills the rpn_* predictions."""
+        """Device-only: backbone + RPN convs/heads/softmax (BASELINE config 1).  Fills the rpn_* predictions.
+        The level-1 RPN branch depends only on level1, so it runs on a forked stream CONCURRENTLY with
+        geometry2 + the level-2 branch (a fork/join in the captured HIP graph): the layers of this network have
+        only 216..1728 output tiles, so no single kernel fills 256 CUs evenly -- two independent kernels in flight
+        fill each other's idle CUs."""
         self._scene = scene
         self._scene_info = scene.shape[2:]
         if imageft is not None:
             self._imageft = imageft
-        l1, l2, l3 = self._backbone()
-        self._net_conv = (l1, l2)
-        levels = []
         cfg = self.cfg
-        for lv, feat in ((1, l1), (2, l2)):
-            A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
-            if A == 0:
-                continue
-            rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
-            score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
-            prob = ops.softmax2(score)
-            self._predictions["rpn_cls_score_level%d" % lv] = score
-            self._predictions["rpn_cls_prob_level%d" % lv] = prob
-            self._predictions["rpn_bbox_pred_level%d" % lv] = bbox
-            anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
-            setattr(self, "_anchors_level%d" % lv, anchors)
-            levels.append((lv, prob, bbox, anchors))
-        return l1, l2, levels
+        if cfg.NUM_ANCHORS_LEVEL3 != 0:
+            raise NotImplementedError("three pyramid levels are not used by any shipped config")
+        l1 = self._backbone_level1()
+        levels = {}
+        fork = cfg.NUM_ANCHORS_LEVEL1 != 0 and self.overlap_branches
+        main = torch.cuda.current_stream()
+        if fork:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                levels[1] = self._rpn_level(1, l1)
+                done = torch.cuda.Event()
+                done.record(self._side)
+        l2 = self._backbone_level2(l1)
+        if cfg.NUM_ANCHORS_LEVEL1 != 0 and not fork:
+            levels[1] = self._rpn_level(1, l1)
+        if cfg.NUM_ANCHORS_LEVEL2 != 0:
+            levels[2] = self._rpn_level(2, l2)
+        if fork:
+            main.wait_event(done)
+        self._net_conv = (l1, l2)
+        return l1, l2, [levels[k] for k in sorted(levels)]
 
     def detect(self, scene, imageft=None):
         """Device-only, fixed-shape, sync-free detection pass (graph-capturable): backbone -> RPN ->

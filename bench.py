@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
@@ -89,7 +89,6 @@ def cpu_baseline(workload, sd, cfg, seconds):
     import sis3d_oracle as orc
     from sis3d import config, synthetic
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     net = orc.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
     data = synthetic.synth_chunk(0)
     feats = i3d = i2d = None
@@ -105,16 +104,32 @@ def cpu_baseline(workload, sd, cfg, seconds):
                 l1, l2 = net.backbone(data, imageft)
                 net.rpn(l1, 1)
                 net.rpn(l2, 2)
-    one()
+
+    # oneDNN does not scale to hundreds of threads on a 0.02-GFLOP/voxel workload: pick the best of a short sweep
+    best_t, best = None, None
+    for t in [c for c in (16, 32, 64, 128) if c <= cores] or [cores]:
+        torch.set_num_threads(t)
+        one()
+        t0 = time.time()
+        one()
+        one()
+        d = (time.time() - t0) / 2
+        if best is None or d < best:
+            best_t, best = t, d
+        if d > 2.0 * best:
+            break
+    torch.set_num_threads(best_t)
     n, t0 = 0, time.time()
     while True:
         one()
         n += 1
-        if time.time() - t0 >= seconds or n >= 200:
+        if time.time() - t0 >= seconds or n >= 400:
             break
     dt = time.time() - t0
-    return dict(value=VOXELS * n / dt, unit="voxels/s", cores=cores, kind="port",
-                sample="%d forward passes (%s, oracle on torch-CPU ops, %d threads) in %.1f s" % (n, workload, cores, dt))
+    cores_used = best_t
+    return dict(value=VOXELS * n / dt, unit="voxels/s", cores=cores_used, kind="port", host_cores=cores,
+                sample="%d forward passes of one 96x48x96 chunk (%s; oracle = the reference's CPU operators via torch-CPU/oneDNN, "
+                       "%d threads, best of a 16/32/64/128 sweep) in %.1f s" % (n, workload, cores_used, dt))
 
 
 def main():

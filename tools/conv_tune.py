@@ -15,6 +15,8 @@ LAYERS = {  # name: (cin, cout, k, dims)
     "g1_b1": (32, 32, 3, (48, 24, 48)), "g1_b2": (32, 32, 3, (24, 12, 24)),
     "k1_32_32": (32, 32, 1, (48, 24, 48)), "k1_128_32": (128, 32, 1, (24, 12, 24)), "k1_32_128": (32, 128, 1, (24, 12, 24)),
     "k1_128_64": (128, 64, 1, (24, 12, 24)), "k1_64_128": (64, 128, 1, (24, 12, 24)), "head_88": (256, 88, 1, (24, 12, 24)),
+    "rpn_512wg": (128, 256, 3, (32, 16, 16)), "rpn_256wg": (128, 256, 3, (16, 16, 16)), "rpn_1024wg": (128, 256, 3, (32, 32, 16)),
+    "rpn_2048wg": (128, 256, 3, (32, 32, 32)), "rpn_768wg": (128, 256, 3, (32, 24, 16)),
     "k2_32_128": (32, 128, 2, (48, 24, 48)), "color0": (128, 64, 2, (96, 48, 96)),
 }
 
