@@ -32,6 +32,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+struct PwStage {
+    const float *wp, *bias, *res;
+    float *out;
+    int cout, res_stride, out_stride, flags;
+};
+
+constexpr int MAXP = 4;   // independent same-shape problems per launch (e.g. the two RPN levels)
+
 struct ConvArgs {
     const float *in;
     int X, Y, Z;          // input grid
@@ -49,6 +57,14 @@ struct ConvArgs {
     int anchors;
     int nbx, nby, nbz;    // bricks per axis
     int ngroups;          // cout groups per brick
+    // fused pointwise (1x1x1) stages applied to the output tile while it is still on chip (Bottleneck conv3 +
+    // residual + ReLU, and the NEXT block's conv1 + ReLU): see sis3d_conv3d_chain
+    int npw;
+    PwStage pw[2];
+    // batched launch: problems 1..nprob-1 share every shape field and differ only in these pointers
+    int nprob;
+    const float *b_in[MAXP], *b_wp[MAXP], *b_bias[MAXP], *b_res[MAXP];
+    float *b_out[MAXP], *b_out2[MAXP];
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -57,7 +73,8 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // 32-wide cout tiles; KW waves split the reduction (taps for k=2/3, channel groups for k=1) of the SAME
 // output tile and are summed through LDS at the end (intra-workgroup split-K: no atomics, deterministic);
 // CK channels per LDS chunk (k=1: CK == cin, a single chunk).
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK>
+// PW: compile the fused pointwise stages in (separate instantiation so the plain kernels keep their register budget)
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false>
 __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const ConvArgs a)
 {
     static_assert(BX * BY * BZ == 32 * MW, "brick must hold 32*MW voxels");
@@ -89,7 +106,18 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
         const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
         bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
     }
+    // batched launch: the work list is problem-major; pick this block's pointer set (uniform -> scalar loads;
+    // never copy the argument struct into a local, dynamic indexing would push it to scratch)
     const int nbricks = a.nbx * a.nby * a.nbz;
+    const float *p_in = a.in, *p_wp = a.wp, *p_bias = a.bias, *p_res = a.res;
+    float *p_out = a.out, *p_out2 = a.out2;
+    if (a.nprob > 1) {
+        const int per = nbricks * a.ngroups;
+        const int prob = bid / per;
+        bid -= prob * per;
+        p_in = a.b_in[prob]; p_wp = a.b_wp[prob]; p_bias = a.b_bias[prob]; p_res = a.b_res[prob];
+        p_out = a.b_out[prob]; p_out2 = a.b_out2[prob];
+    }
     const int group = bid / nbricks;
     bid -= group * nbricks;
     const int bz = bid % a.nbz, by = (bid / a.nbz) % a.nby, bx = bid / (a.nbz * a.nby);
@@ -130,7 +158,7 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int tile = min(tile0 + t, a.ntiles - 1);           // clamp: surplus tiles recompute the last one, never stored
-            dst[t] = reinterpret_cast<const float4 *>(a.wp)[((size_t)(tile * T + tap) * kgtot + kg) * 64 + lane];
+            dst[t] = reinterpret_cast<const float4 *>(p_wp)[((size_t)(tile * T + tap) * kgtot + kg) * 64 + lane];
         }
     };
     auto load_a = [&](float4 &dst, int s) {
@@ -152,7 +180,7 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             const int gx = ix0 + hx, gy = iy0 + hy, gz = iz0 + hz;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z)
-                v = *reinterpret_cast<const float4 *>(a.in + ((size_t)(gx * a.Y + gy) * a.Z + gz) * a.cin_stride + q * CK + c4 * 4);
+                v = *reinterpret_cast<const float4 *>(p_in + ((size_t)(gx * a.Y + gy) * a.Z + gz) * a.cin_stride + q * CK + c4 * 4);
             *reinterpret_cast<float4 *>(lds + row * RS + c4 * 4) = v;
         }
         __syncthreads();
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
                 for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
         }
         __syncthreads();
-        if (kw > 0) return;
+        if (kw == 0)
 #pragma unroll
         for (int k = 1; k < KW; ++k) {
             const float *red = lds + ((size_t)((k - 1) * (MW * NW) + nw * MW + mw) * NTW) * 1024;
@@ -203,31 +231,84 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
 
     // ---- epilogue.  D layout: column (cout) = lane&31, row (voxel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int64_t nvox_out = (int64_t)a.OX * a.OY * a.OZ;
+    constexpr int MROWS = 32 * MW;
+    const int npw = PW ? a.npw : 0;
+    const int c0s = a.cout + 4;                             // padded row stride of the on-chip output tile
+    if (PW && npw > 0) __syncthreads();                     // A image / reduction buffers are dead before the tile overwrites them
+    if (kw == 0) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const int tile = tile0 + t;
-        if (tile >= a.ntiles) continue;
-        const int co = tile * 32 + li;
-        if (co >= a.cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.0f;
+        for (int t = 0; t < NTW; ++t) {
+            const int tile = tile0 + t;
+            if (tile >= a.ntiles) continue;
+            const int co = tile * 32 + li;
+            if (co >= a.cout) continue;
+            const float bv = p_bias ? p_bias[co] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
-            if (ox >= a.OX || oy >= a.OY || oz >= a.OZ) continue;
-            const int64_t vox = ((int64_t)ox * a.OY + oy) * a.OZ + oz;
-            float v = acc[t][r] + bv;
-            if (a.flags & SIS3D_EPI_RESIDUAL) v += a.res[vox * a.res_stride + co];
-            if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
-            if (a.flags & SIS3D_EPI_SIGMOID) v = sigmoidf_(v);
-            if (a.flags & SIS3D_EPI_RPN_HEAD) {
-                const int A = a.anchors;
-                if (co < 2 * A) a.out[((int64_t)(co / A) * nvox_out + vox) * A + (co % A)] = v;
-                else a.out2[vox * (6 * A) + (co - 2 * A)] = v;
-            } else {
-                a.out[vox * a.out_stride + a.out_coff + co] = v;
+            for (int r = 0; r < 16; ++r) {
+                const int mm = 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
+                const bool inside = ox < a.OX && oy < a.OY && oz < a.OZ;
+                const int64_t vox = ((int64_t)ox * a.OY + oy) * a.OZ + oz;
+                float v = acc[t][r] + bv;
+                if ((a.flags & SIS3D_EPI_RESIDUAL) && inside) v += p_res[vox * a.res_stride + co];
+                if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
+                if (a.flags & SIS3D_EPI_SIGMOID) v = sigmoidf_(v);
+                if (PW && npw > 0) lds[mm * c0s + co] = v;        // keep the tile on chip for the fused 1x1x1 stages
+                if (!inside || !p_out) continue;
+                if (a.flags & SIS3D_EPI_RPN_HEAD) {
+                    const int A = a.anchors;
+                    if (co < 2 * A) p_out[((int64_t)(co / A) * nvox_out + vox) * A + (co % A)] = v;
+                    else p_out2[vox * (6 * A) + (co - 2 * A)] = v;
+                } else {
+                    p_out[vox * a.out_stride + a.out_coff + co] = v;
+                }
             }
         }
+    }
+    if constexpr (PW) {
+    if (npw == 0) return;
+    // ---- fused pointwise stages: out_s[M][Cs] = act(tile[M][Cprev] * W_s + b_s (+ residual)); every wave of the
+    // workgroup takes 32x32 tiles of the stage output.  A from the LDS tile, B from L2 (fragment-order pack).
+    constexpr int NWAVES = MW * NW * KW;
+    auto run_stage = [&](const PwStage &st, const float *tin, float *tout, int cprev, bool has_next) {
+        __syncthreads();
+        const int cs = st.cout, kgs = cprev / 8, ins = cprev + 4, outs = cs + 4;
+        const int ntl = MW * (cs / 32);
+        for (int tl = wave; tl < ntl; tl += NWAVES) {
+            const int mt = tl % MW, nt = tl / MW;
+            f32x16 c2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c2[r] = 0.0f;
+            const float *ap2 = tin + (32 * mt + li) * ins + 4 * kh;
+            const float4 *bp2 = reinterpret_cast<const float4 *>(st.wp) + (size_t)nt * kgs * 64 + lane;
+#pragma unroll 4
+            for (int g = 0; g < kgs; ++g) {
+                const float4 av = *reinterpret_cast<const float4 *>(ap2 + 8 * g);
+                const float4 bv = bp2[g * 64];
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c2, 0, 0, 0);
+            }
+            const int co = nt * 32 + li;
+            const float bb = st.bias ? st.bias[co] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
+                const bool inside = ox < a.OX && oy < a.OY && oz < a.OZ;
+                const int64_t vox = ((int64_t)ox * a.OY + oy) * a.OZ + oz;
+                float v = c2[r] + bb;
+                if ((st.flags & SIS3D_EPI_RESIDUAL) && inside) v += st.res[vox * st.res_stride + co];
+                if (st.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
+                if (has_next) tout[mm * outs + co] = v;
+                if (inside && st.out) st.out[vox * st.out_stride + co] = v;
+            }
+        }
+    };
+    float *t1 = lds + MROWS * c0s;
+    run_stage(a.pw[0], lds, t1, a.cout, npw > 1);
+    if (npw > 1) run_stage(a.pw[1], t1, lds, a.pw[0].cout, false);
     }
 }
 
@@ -293,25 +374,46 @@ __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restri
     }
 }
 
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK>
-int launch_cfg(ConvArgs &a, hipStream_t st)
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false>
+int launch_cfg_(ConvArgs &a, hipStream_t st)
 {
     constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
     constexpr size_t tile_b = (size_t)IBX * IBY * IBZ * (CK + 4) * sizeof(float);
     constexpr size_t red_b = (size_t)(KW - 1) * MW * NW * NTW * 1024 * sizeof(float);
-    constexpr size_t lds = tile_b > red_b ? tile_b : red_b;
-    static_assert(lds <= 160 * 1024, "LDS brick too large");
+    constexpr size_t lds0 = tile_b > red_b ? tile_b : red_b;
+    static_assert(lds0 <= 160 * 1024, "LDS brick too large");
+    size_t lds = lds0;
+    if (PW && a.npw > 0) {
+        // on-chip output tile (+ the first stage's output tile when a second stage follows), padded rows
+        if (cdiv(a.ntiles, NW * NTW) != 1) return SIS3D_EUNSUPPORTED;      // the workgroup must own every output channel
+        const size_t mrows = 32 * MW;
+        size_t need = mrows * (a.cout + 4) * sizeof(float);
+        if (a.npw > 1) need += mrows * (a.pw[0].cout + 4) * sizeof(float);
+        lds = need > lds ? need : lds;
+        if (lds > 160 * 1024) return SIS3D_EUNSUPPORTED;
+    }
     static_assert(64 * MW * NW * KW <= 1024, "workgroup too large");
     a.nbx = cdiv(a.OX, BX); a.nby = cdiv(a.OY, BY); a.nbz = cdiv(a.OZ, BZ);
     a.ngroups = cdiv(a.ntiles, NW * NTW);
-    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK>;
+    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, PW>;
     if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+        static size_t set_to = 0;
+        if (lds > set_to) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_to = lds; }
     }
-    const int64_t blocks = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups;
+    const int64_t blocks = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups * (a.nprob > 1 ? a.nprob : 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * MW * NW * KW), lds, st, a);
     return sis3d_check_launch();
+}
+
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK>
+int launch_cfg(ConvArgs &a, hipStream_t st)
+{
+    if constexpr (KS != 1 && CK == 32 && NW * NTW <= 4) {
+        if (a.npw > 0) return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true>(a, st);
+    } else {
+        if (a.npw > 0) return SIS3D_EUNSUPPORTED;
+    }
+    return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, false>(a, st);
 }
 
 // ---- tiling choice.  The chip has 1024 SIMDs; a 32x32 output tile is the work quantum of one wave, and the
@@ -330,7 +432,16 @@ int dispatch(ConvArgs &a, hipStream_t st)
             return launch_cfg<1, 1, 4, 4, 4, 2, 1, 1, 1, 8>(a, st);
         case 32:
             if (a.ntiles >= 4) return launch_cfg<1, 1, 2, 4, 4, 1, 4, 2, 1, 32>(a, st);
-            if (big) return launch_cfg<1, 1, 4, 4, 4, 2, 1, 2, 1, 32>(a, st);
+            if (big) {
+                static const int v1 = [] { const char *e = getenv("SIS3D_K1_VARIANT"); return e ? atoi(e) : 0; }();
+                switch (v1) {
+                case 1: return launch_cfg<1, 1, 4, 4, 4, 2, 1, 1, 1, 32>(a, st);
+                case 2: return launch_cfg<1, 1, 2, 4, 4, 1, 1, 1, 1, 32>(a, st);
+                case 3: return launch_cfg<1, 1, 4, 4, 8, 4, 1, 1, 1, 32>(a, st);
+                case 4: return launch_cfg<1, 1, 2, 4, 4, 1, 1, 2, 1, 32>(a, st);
+                default: return launch_cfg<1, 1, 4, 4, 4, 2, 1, 2, 1, 32>(a, st);
+                }
+            }
             return launch_cfg<1, 1, 2, 4, 4, 1, 1, 4, 1, 32>(a, st);
         case 64:
             if (a.ntiles >= 4) return launch_cfg<1, 1, 2, 4, 4, 1, 4, 2, 1, 64>(a, st);
@@ -365,18 +476,19 @@ int dispatch(ConvArgs &a, hipStream_t st)
         }
         // tuning hook (tools/conv_tune.py): SIS3D_K3_VARIANT selects an alternative tiling for the small-volume k3 layers
         static const int variant = [] { const char *e = getenv("SIS3D_K3_VARIANT"); return e ? atoi(e) : 0; }();
+        if (variant == 0 && a.ntiles >= 2 && a.ntiles <= 3 && a.npw == 0) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
+        if (variant == 0 && a.npw > 0 && a.ntiles == 2) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
         if (a.ntiles >= 2) {
             switch (variant) {
-            case 1: return launch_cfg<3, 1, 2, 4, 4, 1, 4, 3, 1, 32>(a, st);
-            case 2: return launch_cfg<3, 1, 4, 4, 4, 2, 2, 1, 1, 32>(a, st);
-            case 3: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 3, 1, 32>(a, st);
-            case 4: return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
-            case 5: return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 2, 32>(a, st);
-            case 6: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 1, 1, 32>(a, st);
+            case 1: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 9, 1, 32>(a, st);       // one tile per WG, taps over 9 waves
+            case 2: return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);       // 32 vox x 64 cout, 6 waves
+            case 3: return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 1, 32>(a, st);       // 128 vox x 32 cout, 12 waves (B shared 4x)
+            case 4: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 3, 1, 32>(a, st);       // one tile per WG, 3 waves
             default: return launch_cfg<3, 1, 4, 4, 4, 2, 2, 3, 1, 32>(a, st);
             }
         }
-        return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 1, 32>(a, st);
+        if (variant == 2) return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 1, 32>(a, st);
+        return launch_cfg<3, 1, 2, 4, 4, 1, 1, 9, 1, 32>(a, st);           // one tile per WG, 27 taps over 9 waves
     }
 }
 
@@ -407,10 +519,70 @@ extern "C" int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int c
     if ((flags & SIS3D_EPI_RESIDUAL) && !residual) return SIS3D_EINVAL;
     if ((flags & SIS3D_EPI_RPN_HEAD) && (!out2 || anchors <= 0 || cout != 8 * anchors)) return SIS3D_EINVAL;
     ConvArgs a;
+    a.nprob = 1;
+    a.npw = 0;
     a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = (cout + 31) / 32;
     a.flags = flags; a.res = residual; a.res_stride = res_stride;
     a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = out2; a.anchors = anchors;
+    hipStream_t st = as_stream(stream);
+    if (ksize == 1 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<1, 1>(a, st); }
+    if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
+    if (ksize == 2 && stride == 2) { a.OX = X / 2; a.OY = Y / 2; a.OZ = Z / 2; if (!a.OX || !a.OY || !a.OZ) return SIS3D_EINVAL; return dispatch<2, 2>(a, st); }
+    return SIS3D_EUNSUPPORTED;
+}
+
+extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                                  int cout, int ksize, int stride, int flags, float *out, int out_stride, int nstages,
+                                  const sis3d_pw_stage *stages, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nstages < 1 || nstages > 2 || !stages) return SIS3D_EINVAL;
+    if ((cin % 8) || (cin_stride % 4) || cin_stride < cin || (cout % 32) || cout > 128) return SIS3D_EINVAL;
+    if (flags & (SIS3D_EPI_RPN_HEAD | SIS3D_EPI_RESIDUAL)) return SIS3D_EUNSUPPORTED;
+    ConvArgs a;
+    a.nprob = 1;
+    a.npw = nstages;
+    int cprev = cout;
+    for (int i = 0; i < nstages; ++i) {
+        const sis3d_pw_stage &s = stages[i];
+        if (!s.packed_w || s.cout <= 0 || (s.cout % 32) || s.cout > 128 || s.cin != cprev) return SIS3D_EINVAL;
+        if ((s.flags & SIS3D_EPI_RESIDUAL) && !s.residual) return SIS3D_EINVAL;
+        if (!s.out && i + 1 == nstages) return SIS3D_EINVAL;
+        a.pw[i].wp = s.packed_w; a.pw[i].bias = s.bias; a.pw[i].res = s.residual; a.pw[i].out = s.out;
+        a.pw[i].cout = s.cout; a.pw[i].res_stride = s.res_stride; a.pw[i].out_stride = s.out_stride; a.pw[i].flags = s.flags;
+        cprev = s.cout;
+    }
+    a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
+    a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = cout / 32;
+    a.flags = flags; a.res = nullptr; a.res_stride = 0;
+    a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.anchors = 0;
+    hipStream_t st = as_stream(stream);
+    if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
+    if (ksize == 2 && stride == 2) { a.OX = X / 2; a.OY = Y / 2; a.OZ = Z / 2; if (!a.OX || !a.OY || !a.OZ) return SIS3D_EINVAL; return dispatch<2, 2>(a, st); }
+    return SIS3D_EUNSUPPORTED;
+}
+
+extern "C" int sis3d_conv3d_batched(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                    const float *const *packed_ws, const float *const *biases, int cout, int ksize, int stride,
+                                    int flags, const float *const *residuals, int res_stride, float *const *outs, int out_stride,
+                                    int out_coff, sis3d_stream_t stream)
+{
+    if (nprob < 1 || nprob > MAXP || !ins || !packed_ws || !outs) return SIS3D_EINVAL;
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || (cin % 8) || (cin_stride % 4) || cin_stride < cin) return SIS3D_EINVAL;
+    if (flags & SIS3D_EPI_RPN_HEAD) return SIS3D_EUNSUPPORTED;
+    ConvArgs a;
+    a.npw = 0;
+    a.nprob = nprob;
+    for (int p = 0; p < nprob; ++p) {
+        if (!ins[p] || !packed_ws[p] || !outs[p]) return SIS3D_EINVAL;
+        if ((flags & SIS3D_EPI_RESIDUAL) && (!residuals || !residuals[p])) return SIS3D_EINVAL;
+        a.b_in[p] = ins[p]; a.b_wp[p] = packed_ws[p]; a.b_bias[p] = biases ? biases[p] : nullptr;
+        a.b_res[p] = residuals ? residuals[p] : nullptr; a.b_out[p] = outs[p]; a.b_out2[p] = nullptr;
+    }
+    a.in = ins[0]; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
+    a.wp = packed_ws[0]; a.bias = a.b_bias[0]; a.cout = cout; a.ntiles = (cout + 31) / 32;
+    a.flags = flags; a.res = a.b_res[0]; a.res_stride = res_stride;
+    a.out = outs[0]; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = nullptr; a.anchors = 0;
     hipStream_t st = as_stream(stream);
     if (ksize == 1 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<1, 1>(a, st); }
     if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }

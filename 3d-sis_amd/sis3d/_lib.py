@@ -30,12 +30,22 @@ SIGNATURES = {
     "sis3d_conv_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
                              c_int, c_int, c_vp, c_int, c_vp]),
+    "sis3d_conv3d_chain": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int,
+                                   c_vp, c_vp]),
+    "sis3d_conv3d_batched": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int,
+                                     c_vp, c_int, c_int, c_vp]),
     "sis3d_conv3d_planar2": (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "sis3d_maxpool3d_3x3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "sis3d_planar_to_cl": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
     "sis3d_cl_to_planar": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
 }
+
+class PwStage(ctypes.Structure):
+    """struct sis3d_pw_stage (include/sis3d.h)"""
+    _fields_ = [("packed_w", c_vp), ("bias", c_vp), ("residual", c_vp), ("out", c_vp),
+                ("cin", c_int), ("cout", c_int), ("res_stride", c_int), ("out_stride", c_int), ("flags", c_int)]
+
 
 _lib = None
 

@@ -75,10 +75,63 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x, out=None, out_coff=0):
+        return self.forward_fused(x, None, None, out, out_coff)[0]
+
+    def forward_fused(self, x, y1=None, nxt=None, out=None, out_coff=0):
+        """ONE launch for conv2 + conv3 + residual + ReLU (+ the next block's conv1), the tile never leaves the CU
+        between them (sis3d_conv3d_chain).  y1: this block's conv1 output if a previous launch already produced it.
+        Returns (block output, next block's conv1 output or None)."""
         x = ops.to_cl(x)
-        y = self.conv1(x)
-        y = self.conv2(y)
-        return self.conv3(y, residual=x, out=out, out_coff=out_coff)
+        if y1 is None:
+            y1 = self.conv1(x)
+        if FUSE_BOTTLENECK:
+            stages = [dict(pc=self.conv3._packed.get(self.conv3), relu=True, residual=x, out=out, out_coff=out_coff)]
+            if nxt is not None:
+                stages.append(dict(pc=nxt.conv1._packed.get(nxt.conv1), relu=True))
+            try:
+                _, outs = ops.conv3d_chain(y1, self.conv2._packed.get(self.conv2), 1, stages)
+                return outs[0], (outs[1] if nxt is not None else None)
+            except ops.Sis3dUnsupported:
+                pass
+        y2 = self.conv2(y1)
+        return self.conv3(y2, residual=x, out=out, out_coff=out_coff), None
+
+
+FUSE_BOTTLENECK = True
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential whose forward fuses across module boundaries: a stem conv's launch also computes the
+    following Bottleneck's conv1, and every Bottleneck launch also computes the next Bottleneck's conv1."""
+
+    def forward(self, x, last_out=None, last_coff=0):
+        mods = list(self)
+
+        def consumer(i):                                   # the Bottleneck that directly consumes module i's output
+            j = i + 1
+            while j < len(mods) and isinstance(mods[j], FusedReLU):
+                j += 1
+            return mods[j] if j < len(mods) and isinstance(mods[j], Bottleneck) else None
+
+        y1 = None
+        for i, m in enumerate(mods):
+            last = i == len(mods) - 1
+            if isinstance(m, Bottleneck):
+                o, oc = (last_out, last_coff) if last else (None, 0)
+                x, y1 = m.forward_fused(x, y1, consumer(i), o, oc)
+            elif isinstance(m, FusedReLU):
+                continue
+            elif isinstance(m, HipConv3d) and FUSE_BOTTLENECK and consumer(i) is not None and not (m.in_channels == 2 and not ops.is_cl(x)):
+                nb = consumer(i)
+                try:
+                    x, outs = ops.conv3d_chain(ops.to_cl(x), m._packed.get(m), m.stride[0],
+                                               [dict(pc=nb.conv1._packed.get(nb.conv1), relu=True)], relu=m.fuse_relu, want_main=True)
+                    y1 = outs[0]
+                except ops.Sis3dUnsupported:
+                    x, y1 = m(x), None
+            else:
+                x, y1 = m(x), None
+        return x
 
 
 def _conv_relu(cin, cout, k, stride=1, padding=0):
@@ -108,14 +161,10 @@ class Base_Backbone(Network):
             # torch.cat([color, geometry], 1) (backbones.py:109): the last geometry Bottleneck writes its
             # channel range of the concatenated tensor directly (conv epilogue channel offset)
             col = self.color(self._imageft)
-            mods = list(self.geometry1)
-            g = self._scene
-            for m in mods[:-1]:
-                g = m(g)
-            cc, gc = col.shape[1], mods[-1].conv3.out_channels
+            cc, gc = col.shape[1], list(self.geometry1)[-1].conv3.out_channels
             l1 = ops.new_act(cc + gc, col.shape[2:], col.device)
             l1[:, :cc] = col
-            mods[-1](g, out=l1, out_coff=cc)
+            self.geometry1(self._scene, last_out=l1, last_coff=cc)
             return l1
         return self.geometry1(self._scene)
 
@@ -133,17 +182,17 @@ class SUNCG_Backbone(Base_Backbone):
     def _init_backbone_classifier(self):
         cfg = self.cfg
         if not cfg.ONLY_IMAGES or not cfg.USE_IMAGES:
-            self.geometry1 = nn.Sequential(*_conv_relu(2, 64, 2, 2), Bottleneck(64, 32), *_conv_relu(64, 64, 2, 2), Bottleneck(64, 32))
+            self.geometry1 = FusedSequential(*_conv_relu(2, 64, 2, 2), Bottleneck(64, 32), *_conv_relu(64, 64, 2, 2), Bottleneck(64, 32))
         if cfg.USE_IMAGES:
-            self.color = nn.Sequential(*_conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 2, 2), Bottleneck(64, 32),
-                                       *_conv_relu(64, 64, 2, 2), Bottleneck(64, 32))
+            self.color = FusedSequential(*_conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 2, 2), Bottleneck(64, 32),
+                                         *_conv_relu(64, 64, 2, 2), Bottleneck(64, 32))
         if cfg.USE_IMAGES and cfg.ONLY_IMAGES:
             cin = 64
         elif cfg.USE_IMAGES:
             cin = 128
         else:
             cin = 64
-        self.geometry2 = nn.Sequential(*_conv_relu(cin, 128, 3, 1, 1), Bottleneck(128, 64))
+        self.geometry2 = FusedSequential(*_conv_relu(cin, 128, 3, 1, 1), Bottleneck(128, 64))
         self.classifier = self._make_classifier()
 
 
@@ -159,12 +208,12 @@ class ScanNet_Backbone(Base_Backbone):
         else:
             gc, cc = 128, 0
         if not cfg.ONLY_IMAGES or not cfg.USE_IMAGES:
-            self.geometry1 = nn.Sequential(*_conv_relu(2, 32, 2, 2), Bottleneck(32, 32), Bottleneck(32, 32),
-                                           *_conv_relu(32, gc, 2, 2), Bottleneck(gc, 32), Bottleneck(gc, 32))
+            self.geometry1 = FusedSequential(*_conv_relu(2, 32, 2, 2), Bottleneck(32, 32), Bottleneck(32, 32),
+                                             *_conv_relu(32, gc, 2, 2), Bottleneck(gc, 32), Bottleneck(gc, 32))
         if cfg.USE_IMAGES:
-            self.color = nn.Sequential(*_conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 2, 2), Bottleneck(64, 32), HipMaxPool3d(),
-                                       *_conv_relu(64, cc, 2, 2), Bottleneck(cc, 32), HipMaxPool3d())
-        self.geometry2 = nn.Sequential(*_conv_relu(gc + cc, 128, 3, 1, 1), Bottleneck(128, 64), Bottleneck(128, 64), HipMaxPool3d())
+            self.color = FusedSequential(*_conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 2, 2), Bottleneck(64, 32), HipMaxPool3d(),
+                                         *_conv_relu(64, cc, 2, 2), Bottleneck(cc, 32), HipMaxPool3d())
+        self.geometry2 = FusedSequential(*_conv_relu(gc + cc, 128, 3, 1, 1), Bottleneck(128, 64), Bottleneck(128, 64), HipMaxPool3d())
         self.classifier = self._make_classifier()
 
 

@@ -29,8 +29,7 @@ class Network(nn.Module):
         self._losses = {}
         self._proposals = ProposalEngine(self.cfg)
         self._head_cache = {}
-        self._side = None
-        self.overlap_branches = True      # fork the level-1 RPN branch onto a second stream
+        self.batch_rpn = True             # both RPN k3 convs in one batched launch
 
     # network.py:35-64
     def init_modules(self):
@@ -124,11 +123,12 @@ class Network(nn.Module):
         return [masks]
 
     # ------------------------------------------------------------------ forward --
-    def _rpn_level(self, lv, feat):
+    def _rpn_level(self, lv, feat, rpn=None):
         """network.py:539-549 for one pyramid level: k3 conv + ReLU, fused cls/bbox 1x1x1 heads, 2-way softmax"""
         cfg = self.cfg
         A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
-        rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
+        if rpn is None:
+            rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
         score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
         prob = ops.softmax2(score)
         self._predictions["rpn_cls_score_level%d" % lv] = score
@@ -140,10 +140,9 @@ class Network(nn.Module):
 
     def backbone_rpn(self, scene, imageft=None):
         """Device-only: backbone + RPN convs/heads/softmax (BASELINE config 1).  Fills the rpn_* predictions.
-        The level-1 RPN branch depends only on level1, so it runs on a forked stream CONCURRENTLY with
-        geometry2 + the level-2 branch (a fork/join in the captured HIP graph): the layers of this network have
-        only 216..1728 output tiles, so no single kernel fills 256 CUs evenly -- two independent kernels in flight
-        fill each other's idle CUs."""
+        The two 128->256 k3 RPN convs (12.2 GFLOP each, the largest layers) are independent and of identical
+        shape: they go out as ONE batched launch (864 workgroups instead of 2 x 432, which evens out the
+        432-over-256-CUs quantisation that costs each of them ~17 %)."""
         self._scene = scene
         self._scene_info = scene.shape[2:]
         if imageft is not None:
@@ -152,28 +151,20 @@ class Network(nn.Module):
         if cfg.NUM_ANCHORS_LEVEL3 != 0:
             raise NotImplementedError("three pyramid levels are not used by any shipped config")
         l1 = self._backbone_level1()
-        levels = {}
-        fork = cfg.NUM_ANCHORS_LEVEL1 != 0 and self.overlap_branches
-        main = torch.cuda.current_stream()
-        if fork:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self._side.wait_event(ev)
-            with torch.cuda.stream(self._side):
-                levels[1] = self._rpn_level(1, l1)
-                done = torch.cuda.Event()
-                done.record(self._side)
         l2 = self._backbone_level2(l1)
-        if cfg.NUM_ANCHORS_LEVEL1 != 0 and not fork:
-            levels[1] = self._rpn_level(1, l1)
-        if cfg.NUM_ANCHORS_LEVEL2 != 0:
-            levels[2] = self._rpn_level(2, l2)
-        if fork:
-            main.wait_event(done)
         self._net_conv = (l1, l2)
-        return l1, l2, [levels[k] for k in sorted(levels)]
+        levels = []
+        if cfg.NUM_ANCHORS_LEVEL1 != 0 and cfg.NUM_ANCHORS_LEVEL2 != 0 and self.batch_rpn and l1.shape == l2.shape:
+            c1, c2 = self.rpn_net_level1, self.rpn_net_level2
+            r1, r2 = ops.conv3d_batched([l1, l2], [c1._packed.get(c1), c2._packed.get(c2)], relu=True)
+            levels.append(self._rpn_level(1, l1, r1))
+            levels.append(self._rpn_level(2, l2, r2))
+        else:
+            if cfg.NUM_ANCHORS_LEVEL1 != 0:
+                levels.append(self._rpn_level(1, l1))
+            if cfg.NUM_ANCHORS_LEVEL2 != 0:
+                levels.append(self._rpn_level(2, l2))
+        return l1, l2, levels
 
     def detect(self, scene, imageft=None):
         """Device-only, fixed-shape, sync-free detection pass (graph-capturable): backbone -> RPN ->

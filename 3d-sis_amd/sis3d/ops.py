@@ -295,6 +295,81 @@ def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, 
     return ret
 
 
+def conv3d_chain(x, pc, stride, stages, relu=True, want_main=False):
+    """Main conv (k3 / k2s2, + bias, ReLU) followed by fused 1x1x1 stages on the on-chip tile (sis3d_conv3d_chain).
+    stages: list of dicts(pc=PackedConv(k=1), relu=bool, residual=tensor|None, keep=bool).  Returns
+    (main_out | None, [stage outputs | None]).  Raises Sis3dUnsupported if no tiling can fuse this shape."""
+    if not is_cl(x):
+        raise _lib.Sis3dError("conv3d_chain expects a channels-last activation")
+    _, cin_t, X, Y, Z = x.shape
+    od = (X // 2, Y // 2, Z // 2) if pc.k == 2 else (X, Y, Z)
+    main = new_act(pc.cout, od, x.device) if want_main else None
+    arr = (_lib.PwStage * len(stages))()
+    outs = []
+    cprev = pc.cout
+    for i, st in enumerate(stages):
+        spc = st["pc"]
+        last = i + 1 == len(stages)
+        ostride, optr = spc.cout, None
+        if st.get("out") is not None:                     # write into a channel range of a wider tensor (torch.cat fusion)
+            o = st["out"]
+            if not is_cl(o) or tuple(o.shape[2:]) != od:
+                raise _lib.Sis3dError("conv3d_chain: bad stage `out`")
+            ostride, optr = o.shape[1], o.data_ptr() + 4 * int(st.get("out_coff", 0))
+        else:
+            o = new_act(spc.cout, od, x.device) if (st.get("keep", True) or last) else None
+            optr = o.data_ptr() if o is not None else None
+        outs.append(o)
+        res = st.get("residual")
+        if res is not None and (not is_cl(res) or tuple(res.shape[2:]) != od or res.shape[1] != spc.cout):
+            raise _lib.Sis3dError("conv3d_chain: residual shape mismatch")
+        arr[i].packed_w = spc.packed.data_ptr()
+        arr[i].bias = spc.bias.data_ptr() if spc.bias is not None else None
+        arr[i].residual = res.data_ptr() if res is not None else None
+        arr[i].out = optr
+        arr[i].cin, arr[i].cout = cprev, spc.cout
+        arr[i].res_stride = res.shape[1] if res is not None else 0
+        arr[i].out_stride = ostride
+        arr[i].flags = (EPI_RELU if st.get("relu", True) else 0) | (EPI_RESIDUAL if res is not None else 0)
+        if spc.cin != cprev or spc.k != 1:
+            raise _lib.Sis3dError("conv3d_chain: stage %d expects %d input channels, k=1" % (i, cprev))
+        cprev = spc.cout
+    rc = lib().sis3d_conv3d_chain(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed), _ptr(pc.bias), pc.cout, pc.k, stride,
+                                  EPI_RELU if relu else 0, _ptr(main), pc.cout, len(stages), arr, _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no fused tiling for this shape")
+    check(rc, "sis3d_conv3d_chain")
+    return main, outs
+
+
+class Sis3dUnsupported(_lib.Sis3dError):
+    pass
+
+
+def conv3d_batched(xs, pcs, stride=1, relu=False, residuals=None):
+    """Same-shape independent convolutions in one launch (sis3d_conv3d_batched).  xs: channels-last activations
+    of identical shape; pcs: PackedConv objects of identical geometry.  -> list of outputs."""
+    n = len(xs)
+    x0, p0 = xs[0], pcs[0]
+    for x, pc in zip(xs, pcs):
+        if not is_cl(x) or x.shape != x0.shape or (pc.cin, pc.cout, pc.k) != (p0.cin, p0.cout, p0.k) or (pc.bias is None) != (p0.bias is None):
+            raise _lib.Sis3dError("conv3d_batched: problems must share shape and geometry")
+    _, cin_t, X, Y, Z = x0.shape
+    od = (X // 2, Y // 2, Z // 2) if p0.k == 2 else (X, Y, Z)
+    outs = [new_act(p0.cout, od, x0.device) for _ in range(n)]
+    flags = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residuals is not None else 0)
+    arr = ctypes.c_void_p * n
+    ins = arr(*[x.data_ptr() for x in xs])
+    wps = arr(*[pc.packed.data_ptr() for pc in pcs])
+    bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
+    rs = arr(*[r.data_ptr() for r in residuals]) if residuals is not None else None
+    os_ = arr(*[o.data_ptr() for o in outs])
+    check(lib().sis3d_conv3d_batched(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, p0.k, stride, flags, rs,
+                                     residuals[0].shape[1] if residuals is not None else 0, os_, p0.cout, 0, _stream()),
+          "sis3d_conv3d_batched")
+    return outs
+
+
 def conv3d_planar2(x, weight, ksize, relu=True, window=None, cout_stride=None):
     """First layers on the planar 2-channel grid (geometry1.0 k2s2; mask conv0 k3p1 on a crop window).
     x: (1,2,X,Y,Z) with a contiguous z axis; weight: checkpoint layout (Cout,2,k,k,k)."""

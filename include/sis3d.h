@@ -149,6 +149,33 @@ int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int cin_stride, 
                  int cout, int ksize, int stride, int flags, const float *residual, int res_stride, float *out,
                  int out_stride, int out_coff, float *out2, int anchors, sis3d_stream_t stream);
 
+/* A k=3 (or k=2/s=2) convolution followed by up to two fused 1x1x1 convolutions applied to the output tile
+ * while it is still on chip: the Bottleneck of lib/nets/backbones.py:27-40 as ONE launch --
+ *     main  = relu(conv2(y1) + b2)                       (k3, `flags` = SIS3D_EPI_RELU; `out` may be NULL)
+ *     stage0= relu(conv3(main) + b3 + x)                 (1x1x1 + residual; Bottleneck output)
+ *     stage1= relu(conv1_next(stage0) + b1)              (optional: the NEXT block's conv1)
+ * or a stem conv (k2 s2 / k3) + the following block's conv1.  Each stage: cin = previous cout, cout in
+ * {32,64,96,128}; packed_w from sis3d_conv_pack_weight(ksize 1); out (may be NULL except for the last stage)
+ * is channels-last with row stride out_stride.  Returns SIS3D_EUNSUPPORTED if no tiling keeps all main-conv
+ * output channels in one workgroup (use separate launches then). */
+typedef struct sis3d_pw_stage {
+    const float *packed_w, *bias, *residual;
+    float *out;
+    int cin, cout, res_stride, out_stride, flags;
+} sis3d_pw_stage;
+int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                       int cout, int ksize, int stride, int flags, float *out, int out_stride, int nstages,
+                       const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
+
+/* nprob (<= 4) INDEPENDENT convolutions of identical shape in ONE launch (different input / weights / bias /
+ * residual / output pointers; host arrays of device pointers, read at call time).  Used for the two RPN levels
+ * (lib/nets/network.py:539,552): their 432 workgroups each leave 80 of the 256 CUs a workgroup short, a single
+ * 864-workgroup grid evens that out.  Same argument meaning as sis3d_conv3d. */
+int sis3d_conv3d_batched(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                         const float *const *packed_ws, const float *const *biases, int cout, int ksize, int stride, int flags,
+                         const float *const *residuals, int res_stride, float *const *outs, int out_stride, int out_coff,
+                         sis3d_stream_t stream);
+
 /* first layers: NCDHW (planar) 2-channel grid in, channels-last out
  * (geometry1.0: Conv3d(2,32,k2,s2), backbones.py:188 ; mask head conv0: Conv3d(2,64,k3,p1), backbones.py:241).
  * w in checkpoint layout (Cout,2,k,k,k).  in element (c,x,y,z) at c*is_c + x*is_x + y*is_y + z (z contiguous);

@@ -122,3 +122,57 @@ def test_layout_helpers(ops):
     assert ops.is_cl(c) and torch.equal(c.cpu(), x)
     p = ops.to_planar(c)
     assert p.is_contiguous() and torch.equal(p.cpu(), x)
+
+
+def test_batched_same_shape_convs(ops):
+    g = torch.Generator().manual_seed(9)
+    dims = (24, 12, 24)
+    xs = [torch.randn(1, 128, *dims, generator=g) for _ in range(2)]
+    ws = [_w(256, 128, 3, g) for _ in range(2)]
+    bs = [torch.randn(256, generator=g) * 0.1 for _ in range(2)]
+    pcs = [ops.PackedConv(w.cuda(), b.cuda()) for w, b in zip(ws, bs)]
+    outs = ops.conv3d_batched([cl(x) for x in xs], pcs, relu=True)
+    for x, w, b, o in zip(xs, ws, bs, outs):
+        want = F.relu(F.conv3d(x, w, b, padding=1))
+        assert (o.cpu() - want).abs().max() <= TOL
+        # identical to the single launch, bit for bit (same tiling, same summation order)
+        single = ops.conv3d(cl(x), ops.PackedConv(w.cuda(), b.cuda()), relu=True)
+        assert torch.equal(o, single)
+
+
+@pytest.mark.parametrize("planes,inplanes,nextp,dims,k", [(32, 32, 32, (48, 24, 48), 3), (32, 128, 32, (24, 12, 24), 3),
+                                                         (64, 128, 64, (24, 12, 24), 3), (64, 64, 0, (13, 9, 11), 3),
+                                                         (128, 0, 32, (48, 24, 48), 2), (64, 0, 32, (24, 12, 16), 2)])
+def test_fused_bottleneck_chain(ops, planes, inplanes, nextp, dims, k):
+    """one launch == conv2(k3)+ReLU -> conv3(1x1)+residual+ReLU -> next conv1(1x1)+ReLU  (backbones.py:27-40),
+    or a stem conv + the following block's conv1"""
+    g = torch.Generator().manual_seed(planes + inplanes + nextp)
+    if k == 3:
+        y1 = torch.randn(1, planes, *dims, generator=g)
+        x = torch.randn(1, inplanes, *dims, generator=g)
+        w2, b2 = _w(planes, planes, 3, g), torch.randn(planes, generator=g) * 0.1
+        w3, b3 = _w(inplanes, planes, 1, g), torch.randn(inplanes, generator=g) * 0.1
+        y2 = F.relu(F.conv3d(y1, w2, b2, padding=1))
+        want_x = F.relu(F.conv3d(y2, w3, b3) + x)
+        stages = [dict(pc=ops.PackedConv(w3.cuda(), b3.cuda()), relu=True, residual=cl(x), keep=True)]
+        want_n = None
+        if nextp:
+            w1, b1 = _w(nextp, inplanes, 1, g), torch.randn(nextp, generator=g) * 0.1
+            want_n = F.relu(F.conv3d(want_x, w1, b1))
+            stages.append(dict(pc=ops.PackedConv(w1.cuda(), b1.cuda()), relu=True))
+        main, outs = ops.conv3d_chain(cl(y1), ops.PackedConv(w2.cuda(), b2.cuda()), 1, stages)
+        assert main is None
+        assert (outs[0].cpu() - want_x).abs().max() <= TOL
+        if nextp:
+            assert (outs[1].cpu() - want_n).abs().max() <= TOL
+    else:
+        cin = 32
+        xin = torch.randn(1, cin, *dims, generator=g)
+        w0 = _w(planes, cin, 2, g)
+        w1, b1 = _w(nextp, planes, 1, g), torch.randn(nextp, generator=g) * 0.1
+        want0 = F.relu(F.conv3d(xin, w0, None, stride=2))
+        want1 = F.relu(F.conv3d(want0, w1, b1))
+        main, outs = ops.conv3d_chain(cl(xin), ops.PackedConv(w0.cuda(), None), 2,
+                                      [dict(pc=ops.PackedConv(w1.cuda(), b1.cuda()), relu=True)], want_main=True)
+        assert (main.cpu() - want0).abs().max() <= TOL
+        assert (outs[0].cpu() - want1).abs().max() <= TOL

@@ -1,0 +1,58 @@
+"""Whole-scene path on one GPU (world size 1): per-chunk captured graph -> record blocks -> whole-scene NMS,
+checked against the CPU oracle doing the same thing chunk by chunk."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sis3d import config, synthetic  # noqa: E402
+
+
+def test_scene_of_four_chunks_vs_oracle(oracle):
+    from sis3d import parallel
+    from sis3d.engine import RECORD_WIDTH
+    from sis3d.nets import backbones
+    from sis3d.scene import SceneRunner
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_MASK = False
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    dims = (64, 32, 48)
+    chunks = [(c, (float(dims[0] * (c % 2)), 0.0, float(dims[2] * (c // 2))), synthetic.synth_chunk(10 + c, dims)) for c in range(4)]
+    runner = SceneRunner(net, dims)
+    recs, keep = runner.infer(chunks)
+    assert recs.shape[1] == RECORD_WIDTH and recs.shape[0] > 0
+    s = recs[:, 6]
+    assert bool((s[:-1] >= s[1:]).all())
+    # the merge itself is exact: same records through the oracle NMS on the CPU give the same keep list
+    assert torch.equal(keep.cpu(), oracle.nms(recs[:, :6].cpu().contiguous(), cfg.TEST.RPN_NMS_THRESH))
+    # second run of the captured graph is bit-identical (static buffers, deterministic kernels)
+    recs2, keep2 = runner.infer(chunks)
+    assert torch.equal(recs, recs2) and torch.equal(keep, keep2)
+
+    # oracle: same per-chunk pipeline + same packing / merge rules
+    on = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
+
+    def odetect(data):
+        o = on.forward(data)
+        n = o["rois"][0].shape[0]
+        k = cfg.TEST.RPN_POST_NMS_TOP_N
+        rec = torch.zeros(k, RECORD_WIDTH)
+        rec[:n, :6] = o["rois"][0]
+        rec[:n, 6] = o["roi_scores"][0][:, 0]
+        rec[:n, 7] = o["level_inds"][0]
+        rec[:n, 8] = o["cls_pred"].float()
+        rec[:n, 9] = o["cls_prob"].gather(1, o["cls_pred"].view(-1, 1))[:, 0]
+        return rec, n
+    orecs, okeep = parallel.infer_scene(chunks, odetect, oracle.nms, cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH)
+    # proposal sets agree up to near-tie reordering (fp32 logits differ by ~1e-6 between oneDNN and the MFMA kernel)
+    assert abs(recs.shape[0] - orecs.shape[0]) <= max(3, orecs.shape[0] // 10)
+    got, want = recs[keep][:, :6].cpu(), orecs[okeep][:, :6]
+    d = (got[None] - want[:, None]).abs().amax(-1)
+    assert float((d.min(1).values <= 1e-3).float().mean()) >= 0.9
+    # boxes were shifted to scene coordinates
+    assert float(recs[:, 3].max()) > dims[0] and float(recs[:, 5].max()) > dims[2]

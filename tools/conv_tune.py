@@ -35,16 +35,28 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         it = 50
-        e0.record()
-        for _ in range(it):
+        # replay from a HIP graph so small kernels are not host-launch-bound
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
             ops.conv3d(x, pc, stride=st, relu=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(it):
+                ops.conv3d(x, pc, stride=st, relu=True)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / it * 1e3
         od = [d // st for d in dims]
         fl = 2.0 * od[0] * od[1] * od[2] * cout * cin * k ** 3
         by = 4.0 * (dims[0] * dims[1] * dims[2] * cin + od[0] * od[1] * od[2] * cout + cout * cin * k ** 3)
-        print("%-10s variant=%s  %8.1f us  %6.1f TF  %6.0f GB/s" % (n, os.environ.get("SIS3D_K3_VARIANT", "0"), us, fl / us / 1e6, by / us / 1e3))
+        print("%-10s variant=%s  %8.1f us  %6.1f TF  %6.0f GB/s" % (n, os.environ.get("SIS3D_K3_VARIANT", "0") + "/" + os.environ.get("SIS3D_K1_VARIANT", "0"), us, fl / us / 1e6, by / us / 1e3))
 
 
 if __name__ == "__main__":
