@@ -74,7 +74,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // output tile and are summed through LDS at the end (intra-workgroup split-K: no atomics, deterministic);
 // CK channels per LDS chunk (k=1: CK == cin, a single chunk).
 // PW: compile the fused pointwise stages in (separate instantiation so the plain kernels keep their register budget)
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false>
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4>
 __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const ConvArgs a)
 {
     static_assert(BX * BY * BZ == 32 * MW, "brick must hold 32*MW voxels");
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
     // with sched_barrier so hipcc cannot sink the loads next to their use.  Small rings keep the kernel at
     // <= 64 VGPRs -> 8 waves/SIMD, which is what hides the per-chunk LDS refill of the other workgroups.
     constexpr int NS = TPW * KGW;                          // steps per chunk for this wave
-    constexpr int DB = (NS % 4 == 0) ? 4 : (NS % 3 == 0) ? 3 : (NS % 2 == 0) ? 2 : 1;
+    // PF = requested ring depth: 4 when many waves share a SIMD, 12 for the small layers that run 1-2 waves per SIMD
+    constexpr int DB = (PF >= 12 && NS % 12 == 0) ? 12 : (PF >= 8 && NS % 8 == 0) ? 8 : (NS % 4 == 0) ? 4 : (NS % 3 == 0) ? 3 : (NS % 2 == 0) ? 2 : 1;
     constexpr int DA = 2;                                  // A ring restarts at slot 0 every chunk: no wrap constraint
     float4 bq[DB][NTW];
     float4 aq[DA];
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restri
     }
 }
 
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false>
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4>
 int launch_cfg_(ConvArgs &a, hipStream_t st)
 {
     constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
@@ -395,7 +396,7 @@ int launch_cfg_(ConvArgs &a, hipStream_t st)
     static_assert(64 * MW * NW * KW <= 1024, "workgroup too large");
     a.nbx = cdiv(a.OX, BX); a.nby = cdiv(a.OY, BY); a.nbz = cdiv(a.OZ, BZ);
     a.ngroups = cdiv(a.ntiles, NW * NTW);
-    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, PW>;
+    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, PW, PF>;
     if (lds > 64 * 1024) {
         static size_t set_to = 0;
         if (lds > set_to) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_to = lds; }
@@ -405,15 +406,22 @@ int launch_cfg_(ConvArgs &a, hipStream_t st)
     return sis3d_check_launch();
 }
 
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK>
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, int PF = 4>
 int launch_cfg(ConvArgs &a, hipStream_t st)
 {
+    static const int pf_override = [] { const char *e = getenv("SIS3D_PF"); return e ? atoi(e) : 0; }();
     if constexpr (KS != 1 && CK == 32 && NW * NTW <= 4) {
-        if (a.npw > 0) return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true>(a, st);
+        if (a.npw > 0) {
+            if (PF >= 12 && pf_override == 12) return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true, 12>(a, st);
+            return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true, 4>(a, st);
+        }
     } else {
         if (a.npw > 0) return SIS3D_EUNSUPPORTED;
     }
-    return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, false>(a, st);
+    if constexpr (PF >= 12) {
+        if (pf_override == 12) return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, false, 12>(a, st);
+    }
+    return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, false, 4>(a, st);
 }
 
 // ---- tiling choice.  The chip has 1024 SIMDs; a 32x32 output tile is the work quantum of one wave, and the
@@ -459,9 +467,9 @@ int dispatch(ConvArgs &a, hipStream_t st)
     } else if constexpr (S == 2) {
         // k2 s2: the input brick is 2x the output brick per axis -> small output bricks; 8 taps over KW=2/4 waves
         if (a.cin % 32 == 0) {
-            if (a.ntiles >= 4) return launch_cfg<2, 2, 2, 4, 4, 1, 4, 2, 1, 32>(a, st);
-            if (a.ntiles >= 2) return launch_cfg<2, 2, 2, 4, 4, 1, 2, 4, 1, 32>(a, st);
-            return launch_cfg<2, 2, 2, 4, 4, 1, 1, 4, 1, 32>(a, st);
+            if (a.ntiles >= 4) return launch_cfg<2, 2, 2, 4, 4, 1, 4, 2, 1, 32, 12>(a, st);
+            if (a.ntiles >= 2) return launch_cfg<2, 2, 2, 4, 4, 1, 2, 4, 1, 32, 12>(a, st);
+            return launch_cfg<2, 2, 2, 4, 4, 1, 1, 4, 1, 32, 12>(a, st);
         }
         return launch_cfg<2, 2, 2, 4, 4, 1, 2, 2, 1, 8>(a, st);
     } else {
@@ -472,12 +480,12 @@ int dispatch(ConvArgs &a, hipStream_t st)
         }
         if (big) {
             if (a.ntiles >= 2) return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 2, 32>(a, st);
-            return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 1, 32>(a, st);
+            return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 1, 32, 12>(a, st);
         }
         // tuning hook (tools/conv_tune.py): SIS3D_K3_VARIANT selects an alternative tiling for the small-volume k3 layers
         static const int variant = [] { const char *e = getenv("SIS3D_K3_VARIANT"); return e ? atoi(e) : 0; }();
-        if (variant == 0 && a.ntiles >= 2 && a.ntiles <= 3 && a.npw == 0) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
-        if (variant == 0 && a.npw > 0 && a.ntiles == 2) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
+        if (variant == 0 && a.ntiles >= 2 && a.ntiles <= 3 && a.npw == 0) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32, 12>(a, st);
+        if (variant == 0 && a.npw > 0 && a.ntiles == 2) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32, 12>(a, st);
         if (a.ntiles >= 2) {
             switch (variant) {
             case 1: return launch_cfg<3, 1, 2, 4, 4, 1, 1, 9, 1, 32>(a, st);       // one tile per WG, taps over 9 waves
@@ -488,7 +496,7 @@ int dispatch(ConvArgs &a, hipStream_t st)
             }
         }
         if (variant == 2) return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 1, 32>(a, st);
-        return launch_cfg<3, 1, 2, 4, 4, 1, 1, 9, 1, 32>(a, st);           // one tile per WG, 27 taps over 9 waves
+        return launch_cfg<3, 1, 2, 4, 4, 1, 1, 9, 1, 32, 12>(a, st);       // one tile per WG, 27 taps over 9 waves
     }
 }
 

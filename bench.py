@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--workload backbone_rpn|detect|images] [--no-graph]
 
 One process per GPU (for N>1 the driver launches this under torch.distributed.run; RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* come from the env).  A step = one pass of the hot path over one synthetic
-96x48x96 chunk per rank, inputs already resident in HBM (static buffers of the ChunkEngine); weights
+WORLD_SIZE / MASTER_* come from the env).  A step = one pass of the hot path over one batch of
+`--inflight` (default 2) independent synthetic 96x48x96 chunks per rank, each on its own HIP stream / captured
+graph, inputs already resident in HBM (static buffers of the ChunkEngine); weights
 are seeded synthetic (no checkpoints exist offline).  Chunks are independent, so ranks share nothing
 on the data path (scaling: weak); the per-scene proposal all-gather is exercised by `--workload scene`.
 
@@ -47,6 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="independent chunks in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -145,17 +147,19 @@ def main():
     else:
         torch.cuda.set_device(0)
     from sis3d import synthetic, ops
-    from sis3d.engine import ChunkEngine
+    from sis3d.engine import PipelinedEngines
     ops.lib()
     net, cfg, sd = build_net(args.workload)
     stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
-    eng = ChunkEngine(net, stage=stage, use_graph=not args.no_graph)
-    data = synthetic.synth_chunk(rank)
-    if args.workload == "images":
-        feats, i3d, i2d = synthetic.synth_views(rank)
-        eng.load(data.cuda(), feats.cuda(), i3d.cuda(), i2d.cuda())
-    else:
-        eng.load(data.cuda())
+    nfl = max(1, args.inflight)
+    eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph)
+    for i in range(nfl):
+        data = synthetic.synth_chunk(rank * nfl + i)
+        if args.workload == "images":
+            feats, i3d, i2d = synthetic.synth_views(rank * nfl + i)
+            eng.load(i, data, feats, i3d, i2d)
+        else:
+            eng.load(i, data)
     eng.prepare(warmup=2)
     for _ in range(args.warmup):
         eng.run()
@@ -177,11 +181,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
-    value = world * VOXELS * args.steps / dt
+    value = world * nfl * VOXELS * args.steps / dt
 
     if rank == 0:
         kt = time_dominant_kernel(net)
-        algo = ALGO[args.workload]
+        algo = {k: v * nfl for k, v in ALGO[args.workload].items()}
+        # latency of ONE chunk on an otherwise idle GPU (single stream), for reference
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            eng.run(0)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 50 * 1e3
         line = {
             "metric": "voxels/sec forward on 96x48x96 chunks",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,7 +202,8 @@ def main():
                                                     "(convs, heads, softmax), weights seeded synthetic",
                                     "detect": "config[2] minus mask head: backbone + RPN + decode/sort/NMS + RoI pooling + classifier",
                                     "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN"}[args.workload],
-                       "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world},
+                       "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world,
+                       "chunks_per_step_per_gpu": nfl, "streams_per_gpu": nfl, "single_chunk_latency_ms": single_ms},
             "roofline": {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,1,...> rpn_net 128->256 (fp32 v_mfma_f32_32x32x2_f32)",
                          "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": DOMINANT_FLOPS / kt / 1e12 / FP32_PEAK_TF, "traffic": None,

@@ -21,8 +21,33 @@ LAYERS = {  # name: (cin, cout, k, dims)
 }
 
 
+def bench_batched():
+    dims = (24, 12, 24)
+    xs = [ops.new_act(128, dims, torch.device("cuda")).normal_() for _ in range(2)]
+    pcs = [ops.PackedConv(torch.randn(256, 128, 3, 3, 3, device="cuda") * 0.05, torch.zeros(256, device="cuda")) for _ in range(2)]
+    for _ in range(3):
+        ops.conv3d_batched(xs, pcs, relu=True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            ops.conv3d_batched(xs, pcs, relu=True)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print("rpn_x2 batched  %8.1f us  %6.1f TF" % (us, 2 * 2.0 * 6912 * 256 * 128 * 27 / us / 1e6))
+
+
 def main():
     names = sys.argv[1:] or list(LAYERS)
+    if "rpn_x2" in names:
+        names.remove("rpn_x2")
+        bench_batched()
     for n in names:
         cin, cout, k, dims = LAYERS[n]
         x = ops.new_act(cin, dims, torch.device("cuda"))
