@@ -18,7 +18,7 @@
 
 namespace {
 
-struct Box { float x1, y1, z1, x2, y2, z2; };
+struct Box { float x1, y1, z1, x2, y2, z2, area, pad; };   // area = (x2-x1+1)*(y2-y1+1)*(z2-z1+1), computed once per box
 
 __device__ __forceinline__ float iou3d(const Box &a, const Box &b)
 {
@@ -28,9 +28,7 @@ __device__ __forceinline__ float iou3d(const Box &a, const Box &b)
     float h = fmaxf(bottom - top + 1.0f, 0.0f);
     float l = fmaxf(back - front + 1.0f, 0.0f);
     float inter = w * h * l;
-    float sa = (a.x2 - a.x1 + 1.0f) * (a.y2 - a.y1 + 1.0f) * (a.z2 - a.z1 + 1.0f);
-    float sb = (b.x2 - b.x1 + 1.0f) * (b.y2 - b.y1 + 1.0f) * (b.z2 - b.z1 + 1.0f);
-    return inter / (sa + sb - inter);
+    return inter / (a.area + b.area - inter);              // same binary32 values as recomputing the areas per pair
 }
 
 template <bool INDIRECT>
@@ -39,6 +37,8 @@ __device__ __forceinline__ Box load_box(const float *boxes, const int64_t *order
     const float *p = boxes + 6 * (INDIRECT ? order[i] : (int64_t)i);
     Box b;
     b.x1 = p[0]; b.y1 = p[1]; b.z1 = p[2]; b.x2 = p[3]; b.y2 = p[4]; b.z2 = p[5];
+    b.area = (b.x2 - b.x1 + 1.0f) * (b.y2 - b.y1 + 1.0f) * (b.z2 - b.z1 + 1.0f);
+    b.pad = 0.0f;
     return b;
 }
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
     if (ri < n) rows[lane] = load_box<INDIRECT>(boxes, order, ri);
     __syncthreads();
     const int ci = 64 * cb + lane;
-    Box col = {0, 0, 0, 0, 0, 0};
+    Box col = {0, 0, 0, 0, 0, 0, 1, 0};
     if (ci < n) col = load_box<INDIRECT>(boxes, order, ci);
     const uint64_t w = tile_word(rows, col, ci < n, rb, cb, n, thresh, lane);
     if (ri < n) mask[(size_t)ri * col_blocks + cb] = w;
@@ -163,10 +163,10 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restri
 }
 
 // ---------------------------------------------------------------- single-launch path (matrix in LDS)
-constexpr int SMALL_N = 1024;     // 1024 x 16 words x 8 B = 128 KiB of the 160 KiB LDS
+constexpr int SMALL_N = 960;      // 960 x 15 words x 8 B = 112 KiB matrix + 30 KiB boxes of the 160 KiB LDS
 
 template <bool INDIRECT, bool SELECT>
-__global__ __launch_bounds__(512) void nms_small_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order, int n,
+__global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order, int n,
                                                         float thresh, int max_keep, int64_t *__restrict__ keep,
                                                         int32_t *__restrict__ num_keep, const float *__restrict__ level_all,
                                                         const float *__restrict__ scores_sorted, float *__restrict__ rois,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void nms_small_kernel(const float *__restrict_
     __shared__ int s_nk;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
     for (int i = tid; i < npad; i += blockDim.x) {
-        Box b = {0, 0, 0, 0, 0, 0};
+        Box b = {0, 0, 0, 0, 0, 0, 1, 0};
         if (i < n) b = load_box<INDIRECT>(boxes, order, i);
         sbox[i] = b;
     }
@@ -285,7 +285,7 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, st, boxes, order, n, thresh, max_keep, keep, num_keep, level_all,
+        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, boxes, order, n, thresh, max_keep, keep, num_keep, level_all,
                            scores_sorted, rois, roi_scores, roi_levels);
         return sis3d_check_launch();
     }

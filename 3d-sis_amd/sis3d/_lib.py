@@ -25,7 +25,11 @@ SIGNATURES = {
     "sis3d_project_views_max": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64,
                                         c_i64, c_i64, c_vp, c_sz, c_vp]),
     "sis3d_proposal_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "sis3d_topk_desc": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "sis3d_softmax2": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "sis3d_classifier_workspace_floats": (c_sz, [c_int, c_int, c_int]),
+    "sis3d_classifier_forward": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp,
+                                         c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_conv_packed_floats": (c_sz, [c_int, c_int, c_int]),
     "sis3d_conv_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,

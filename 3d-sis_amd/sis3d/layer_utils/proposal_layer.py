@@ -52,8 +52,11 @@ class ProposalEngine:
             ops.proposal_decode(anc, bbox, prob_fg, inside, dims, lid, boxes[off:off + n], scores[off:off + n], lvl[off:off + n])
             off += n
         # stable descending sort: the tie rule pinned in the oracle (SURVEY.md 7 'Sort tie order')
-        s_sorted, order = torch.sort(scores, descending=True, stable=True)
         n_pre = min(pre_n, M) if pre_n > 0 else M
+        if 0 < n_pre <= 1024 and M <= 40960:
+            s_sorted, order = ops.topk_desc(scores, n_pre)     # one launch instead of a full 33k-element sort
+        else:
+            s_sorted, order = torch.sort(scores, descending=True, stable=True)
         k_out = post_n if post_n > 0 else n_pre
         rois, r_scores, r_levels, keep, num = ops.nms_select(boxes, lvl, s_sorted, order, n_pre, thr, k_out)
         return dict(rois=rois, scores=r_scores, levels=r_levels, num=num, order=order, keep=keep, n_pre=n_pre,

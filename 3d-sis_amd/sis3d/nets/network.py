@@ -79,22 +79,14 @@ class Network(nn.Module):
         pool5 = ops.roi_pool_levels(l1, l2, p["rois"], p["levels"], ps, 1.0 / self._feat_stride[0], out_channels_last=True)
         self._pool5 = pool5
         x = pool5.permute(0, 2, 3, 4, 1).reshape(pool5.shape[0], -1)           # memory order (R, bins, C): a view
-        fc0 = self.classifier[0]
-        ver = (fc0.weight._version, fc0.weight.data_ptr())
-        hit = self._head_cache.get("fc0")
-        if hit is None or hit[0] != ver:
-            C, nb = pool5.shape[1], ps ** 3
-            wperm = fc0.weight.detach().view(-1, C, nb).permute(0, 2, 1).reshape(fc0.weight.shape[0], -1).contiguous()
-            hit = (ver, wperm)
-            self._head_cache["fc0"] = hit
-        x = F.relu(F.linear(x, hit[1], fc0.bias))
-        x = F.relu(self.classifier[2](x))
-        fc7 = F.relu(self.classifier[4](x))
-        cls_score = self.classifier_cls_score_net(fc7)
-        cls_pred = torch.max(cls_score, 1)[1]
-        cls_prob = F.softmax(cls_score, dim=1)
-        bbox_pred = self.classifier_bbox_pred_net(fc7)
-        return cls_score, cls_pred, cls_prob, bbox_pred
+        fcs = [self.classifier[0], self.classifier[2], self.classifier[4]]
+        heads = [self.classifier_cls_score_net, self.classifier_bbox_pred_net]
+        ver = tuple(q._version for m in fcs + heads for q in (m.weight, m.bias)) + (fcs[0].weight.data_ptr(),)
+        hit = self._head_cache.get("mlp")
+        if hit is None or hit.version != ver:
+            hit = ops.PackedClassifier(fcs, heads[0], heads[1], pool5.shape[1], ps ** 3)
+            self._head_cache["mlp"] = hit
+        return ops.classifier_forward(x, hit)
 
     # network.py:283-317
     def _mask_branch(self, n):

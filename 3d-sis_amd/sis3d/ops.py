@@ -183,6 +183,17 @@ def proposal_decode(anchors, deltas, prob_fg, inside, dims, level_id, out_boxes,
                                       _stream()), "sis3d_proposal_decode")
 
 
+def topk_desc(scores, k):
+    """stable descending top-k of a 1-D score vector -> (scores_sorted (k,), order (k,) int64); k <= 1024"""
+    scores = _dev(scores, "scores").contiguous()
+    n = scores.numel()
+    k = min(int(k), n)
+    out_s = torch.empty(k, device=scores.device)
+    out_i = torch.empty(k, dtype=torch.int64, device=scores.device)
+    check(lib().sis3d_topk_desc(_ptr(scores), n, k, _ptr(out_s), _ptr(out_i), _stream()), "sis3d_topk_desc")
+    return out_s, out_i
+
+
 def softmax2(score):
     """F.softmax over dim 1 of a contiguous (1,2,...) tensor (network.py:546)."""
     score = _dev(score, "score")
@@ -392,6 +403,43 @@ def conv3d_planar2(x, weight, ksize, relu=True, window=None, cout_stride=None):
     check(lib().sis3d_conv3d_planar2(_ptr(x), st[1], st[2], st[3], X, Y, Z, x0, y0, z0, od[0], od[1], od[2], _ptr(w), cout, ksize,
                                      EPI_RELU if relu else 0, _ptr(out), cs, _stream()), "sis3d_conv3d_planar2")
     return out
+
+
+class PackedClassifier:
+    """classifier MLP + heads packed for sis3d_classifier_forward.  fc0's columns are permuted from the reference's
+    (C, bins) flatten order to the (bins, C) memory order of the channels-last pooled features."""
+
+    def __init__(self, fcs, cls_head, box_head, pool_c, pool_bins):
+        (w1, b1), (w2, b2), (w3, b3) = [(m.weight.detach(), m.bias.detach()) for m in fcs]
+        w1 = w1.view(w1.shape[0], pool_c, pool_bins).permute(0, 2, 1).reshape(w1.shape[0], -1).contiguous()
+        mk = lambda w, b: PackedConv(w.reshape(w.shape[0], w.shape[1], 1, 1, 1), b)
+        self.l1, self.l2, self.l3 = mk(w1, b1), mk(w2, b2), mk(w3, b3)
+        wh = torch.cat([cls_head.weight.detach(), box_head.weight.detach()], 0)
+        bh = torch.cat([cls_head.bias.detach(), box_head.bias.detach()], 0)
+        self.head = mk(wh, bh)
+        self.nc = cls_head.weight.shape[0]
+        self.version = tuple(p._version for m in list(fcs) + [cls_head, box_head] for p in (m.weight, m.bias)) + (fcs[0].weight.data_ptr(),)
+
+
+def classifier_forward(x, pk):
+    """x (R, K) fp32 rows on the GPU -> (cls_score (R,NC), cls_pred (R,) int64, cls_prob (R,NC), bbox_pred (R,6NC))"""
+    x = _dev(x, "pool5")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise _lib.Sis3dError("classifier_forward expects (R,K) rows")
+    R, K = x.shape
+    nc = pk.nc
+    dev = x.device
+    cls_score = torch.empty(R, nc, device=dev)
+    cls_prob = torch.empty(R, nc, device=dev)
+    cls_pred = torch.empty(R, dtype=torch.int64, device=dev)
+    bbox_pred = torch.empty(R, 6 * nc, device=dev)
+    nws = lib().sis3d_classifier_workspace_floats(R, K, pk.l1.cout)
+    ws = torch.empty(max(nws, 1), device=dev)
+    check(lib().sis3d_classifier_forward(_ptr(x), R, K, x.stride(0), _ptr(pk.l1.packed), _ptr(pk.l1.bias), pk.l1.cout,
+                                         _ptr(pk.l2.packed), _ptr(pk.l2.bias), pk.l2.cout, _ptr(pk.l3.packed), _ptr(pk.l3.bias),
+                                         pk.l3.cout, _ptr(pk.head.packed), _ptr(pk.head.bias), nc, _ptr(cls_score), _ptr(cls_prob),
+                                         _ptr(cls_pred), _ptr(bbox_pred), _ptr(ws), nws, _stream()), "sis3d_classifier_forward")
+    return cls_score, cls_pred, cls_prob, bbox_pred
 
 
 def maxpool3(x):

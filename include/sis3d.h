@@ -119,8 +119,28 @@ int sis3d_project_views_max(const float *feats, int V, int C, int64_t npix, cons
 int sis3d_proposal_decode(const float *anchors, const float *deltas, const float *prob_fg, const int32_t *inside,
                           int n_inside, float dim_x, float dim_y, float dim_z, float level_id, float *out_boxes,
                           float *out_scores, float *out_levels, sis3d_stream_t stream);
+/* Replaces `scores.sort(descending=True)` + `[:pre_nms_topN]` (proposal_layer.py:181-186): the k (<= 1024) largest
+ * of scores [n] in descending order, ties by ascending index (== torch.sort(stable=True, descending=True)[:k]).
+ * out_scores [k], out_idx [k] int64.  One launch (radix select + bitonic sort in LDS); k > n is clamped to n;
+ * n > 40960 returns SIS3D_EUNSUPPORTED (the score vector is held in registers). */
+int sis3d_topk_desc(const float *scores, int n, int k, float *out_scores, int64_t *out_idx, sis3d_stream_t stream);
 /* softmax over dim 1 of (1,2,...) score maps (network.py:546): n = elements per class plane */
 int sis3d_softmax2(const float *score, float *prob, int64_t n, sis3d_stream_t stream);
+
+/* ------------------------------------------------------------ RoI classifier --
+ * Replaces the five cuBLAS GEMMs + ReLU / softmax / max kernels of Base_Backbone._classifier and
+ * Network._region_classification (lib/nets/backbones.py:92-96,225-231, lib/nets/network.py:589-604):
+ *   fc7 = relu(L3(relu(L2(relu(L1(x))))));  cls_score = Lc(fc7);  bbox_pred = Lb(fc7);
+ *   cls_prob = softmax(cls_score, 1);  cls_pred = argmax(cls_score, 1) (first maximum).
+ * x [R][K] fp32 rows (row stride ldx); w?p = sis3d_conv_pack_weight(weight viewed (Cout,Cin,1,1,1), ksize 1);
+ * whp packs the two heads stacked: rows [0,NC) = classifier_cls_score_net, [NC,7NC) = classifier_bbox_pred_net,
+ * bh likewise.  K % 128 == 0, C1,C2,C3 % 32 == 0.  Two launches (split-K first layer, fused tail). */
+size_t sis3d_classifier_workspace_floats(int R, int K, int C1);
+int sis3d_classifier_forward(const float *x, int R, int K, int ldx, const float *w1p, const float *b1, int C1,
+                             const float *w2p, const float *b2, int C2, const float *w3p, const float *b3, int C3,
+                             const float *whp, const float *bh, int NC, float *cls_score, float *cls_prob,
+                             int64_t *cls_pred, float *bbox_pred, float *workspace, size_t workspace_floats,
+                             sis3d_stream_t stream);
 
 /* ------------------------------------------------------------ 3D convolution --
  * Replaces the cuDNN calls behind nn.Conv3d / nn.MaxPool3d / nn.ReLU / residual

@@ -184,3 +184,17 @@ def test_proposal_decode_and_softmax(ops, oracle):
         assert (ob.cpu() - want_b).abs().max() <= 1e-4          # fp32 box tolerance (expf vs torch exp: <= 2 ulp)
         assert torch.equal(os_.cpu(), want_s[:, 0])
         assert (ol == lv).all()
+
+
+@pytest.mark.parametrize("n,k", [(33394, 400), (5, 400), (400, 400), (1000, 1), (40960, 1024), (2048, 300)])
+def test_topk_desc_matches_stable_sort(ops, n, k):
+    g = torch.Generator().manual_seed(n + k)
+    s = torch.rand(n, generator=g)
+    if n > 100:
+        s[torch.randint(0, n, (n // 3,), generator=g)] = 0.5          # many exact ties, also AT the k-th value
+        s[7] = float("inf"); s[11] = -1.0; s[13] = -0.0; s[17] = 0.0
+    s = (s * 64).round() / 64 if n == 2048 else s                       # heavy tie case
+    ws, wo = torch.sort(s, descending=True, stable=True)
+    kk = min(k, n)
+    gs, go = ops.topk_desc(s.cuda(), k)
+    assert torch.equal(go.cpu(), wo[:kk]) and torch.equal(gs.cpu(), ws[:kk])
