@@ -111,7 +111,7 @@ __device__ __forceinline__ void dense32(const float *tin, int cin, const float *
         for (int r = 0; r < 16; ++r) c[r] = 0.0f;
         const float *ap = tin + li * ins + 4 * kh;
         const float4 *bp = reinterpret_cast<const float4 *>(wp) + (size_t)nt * kgs * 64 + lane;
-#pragma unroll 4
+#pragma unroll 16
         for (int g = 0; g < kgs; ++g) {
             const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * g);
             const float4 bv = bp[g * 64];
@@ -144,12 +144,21 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void mlp_tail_kernel(const TailArg
     const int wmax = max(max(a.C1, nh_pad), max(a.C2, a.C3));
     float *t0 = lds, *t1 = lds + 32 * (wmax + 4);
     // fc1: sum of the K-slices + bias + ReLU -> t0 [32][C1+4]
-    for (int idx = tid; idx < 32 * a.C1; idx += 64 * TAIL_WAVES) {
-        const int row = idx / a.C1, c = idx % a.C1;
-        float v = 0.0f;
-        for (int s = 0; s < a.S; ++s) v += a.part[((size_t)s * a.Rpad + m0 + row) * a.C1 + c];
-        v = fmaxf(v + a.b1[c], 0.0f);
-        t0[row * (a.C1 + 4) + c] = v;
+    const int c4n = a.C1 / 4;
+    for (int idx = tid; idx < 32 * c4n; idx += 64 * TAIL_WAVES) {
+        const int row = idx / c4n, c = (idx % c4n) * 4;
+        const float4 *src = reinterpret_cast<const float4 *>(a.part + ((size_t)m0 + row) * a.C1 + c);
+        const size_t sstride = (size_t)a.Rpad * a.C1 / 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int s = 0; s < a.S; ++s) {                   // fixed slice order: deterministic sum
+            const float4 p = src[s * sstride];
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const float4 bb = *reinterpret_cast<const float4 *>(a.b1 + c);
+        float *dst = t0 + row * (a.C1 + 4) + c;
+        dst[0] = fmaxf(v.x + bb.x, 0.0f); dst[1] = fmaxf(v.y + bb.y, 0.0f);
+        dst[2] = fmaxf(v.z + bb.z, 0.0f); dst[3] = fmaxf(v.w + bb.w, 0.0f);
     }
     __syncthreads();
     dense32(t0, a.C1, a.w2, a.b2, a.C2, a.C2, true, t1, wave, lane, nullptr, -1);

@@ -9,16 +9,25 @@
 // Design (MI355X): a 64x64 tile of the matrix is exactly one wavefront: lane =
 // column box, the 64 row boxes are walked with the row box broadcast from LDS,
 // and __ballot() of the 64 lanes IS the 64-bit mask word -- no per-thread bit
-// loop.  The sweep is a single workgroup: per 64-box block the in-block
-// decisions are resolved by one wave with v_readlane on the diagonal words (no
-// memory traffic), then all lanes OR the kept rows into the running remove
-// vector held in LDS.  For n <= SMALL_N the bit matrix never leaves LDS and the
-// whole NMS is ONE launch with no global scratch.
+// loop; one tile per workgroup so the matrix spreads over as many CUs as it has
+// tiles (a single workgroup doing all 28 tiles of n = 400 is VALU-bound: 28 us).
+// The sweep is a single workgroup: per 64-box block the in-block decisions are
+// resolved by one wave in SGPRs (s_ff1 over the not-yet-suppressed bits +
+// v_readlane on the diagonal words, no memory traffic), then the kept rows are
+// OR-folded into the later column blocks by the other waves with shuffles.  The
+// matrix is staged in LDS when it fits.  Measured n = 400: 57 us -> see profiles/.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 struct Box { float x1, y1, z1, x2, y2, z2, area, pad; };   // area = (x2-x1+1)*(y2-y1+1)*(z2-z1+1), computed once per box
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 
 __device__ __forceinline__ float iou3d(const Box &a, const Box &b)
 {
@@ -50,6 +59,7 @@ __device__ __forceinline__ uint64_t tile_word(const Box *rows, const Box &col, b
     uint64_t mine = 0;
     const int col_idx = 64 * cb + lane;
     const int nrows = min(64, n - 64 * rb);
+#pragma unroll 4
     for (int r = 0; r < nrows; ++r) {
         const Box a = rows[r];                       // LDS broadcast (same address in all lanes)
         const float v = iou3d(a, col);
@@ -82,55 +92,73 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
     if (ri < n) mask[(size_t)ri * col_blocks + cb] = w;
 }
 
-// Greedy sweep, one workgroup of 256 threads.  remv[] (one word per column block) lives in LDS.
+// Greedy sweep: ONE workgroup of 1024 threads over the bit matrix produced by nms_mask_kernel.
+//  * per 64-box block, wave 0 resolves the in-block decisions with the running remove word in SGPRs; it visits only
+//    the not-yet-suppressed boxes (s_ff1 on ~cur) and ORs in their diagonal words via v_readlane -- no memory traffic;
+//  * the kept rows are then folded into the remove words of the later column blocks by the other waves in parallel:
+//    wave w takes column block b+1+w, lane i contributes row i's word, 64-lane OR by shuffles;
+//  * the matrix is staged into LDS when it fits (n <= ~1400), else read from L2; the candidates' level / score are staged
+//    up front so the select variant never waits on a dependent global load inside the serial part.
+constexpr size_t SWEEP_LDS_MASK_MAX = 120 * 1024;
+
 template <bool SELECT>
-__global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restrict__ mask, int n, int max_keep,
-                                                        int64_t *__restrict__ keep, int32_t *__restrict__ num_keep,
-                                                        // SELECT outputs
-                                                        const float *__restrict__ boxes_all, const float *__restrict__ level_all,
-                                                        const float *__restrict__ scores_sorted, const int64_t *__restrict__ order,
-                                                        float *__restrict__ rois, float *__restrict__ roi_scores,
-                                                        float *__restrict__ roi_levels)
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, int n, int max_keep,
+                                                         int64_t *__restrict__ keep, int32_t *__restrict__ num_keep,
+                                                         const float *__restrict__ boxes_all, const float *__restrict__ level_all,
+                                                         const float *__restrict__ scores_sorted, const int64_t *__restrict__ order,
+                                                         float *__restrict__ rois, float *__restrict__ roi_scores,
+                                                         float *__restrict__ roi_levels, int stage_mask, int stage_meta)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *remv = (uint64_t *)smem;                 // [col_blocks]
+    const int col_blocks = (n + 63) / 64;
+    uint64_t *remv = (uint64_t *)smem;                                   // [col_blocks]
+    uint64_t *smask = remv + col_blocks;                                 // [n][col_blocks] if staged
+    float *slev = (float *)(smask + (stage_mask ? (size_t)n * col_blocks : 0));   // [n] if staged
+    float *sscr = slev + (stage_meta ? n : 0);
     __shared__ uint64_t s_kept;
     __shared__ int s_nk;
-    const int col_blocks = (n + 63) / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
     for (int c = tid; c < col_blocks; c += blockDim.x) remv[c] = 0;
+    if (stage_mask)
+        for (size_t i = tid; i < (size_t)n * col_blocks; i += blockDim.x) smask[i] = mask[i];
+    if (SELECT && stage_meta)
+        for (int i = tid; i < n; i += blockDim.x) { slev[i] = level_all[order[i]]; sscr[i] = scores_sorted[i]; }
     if (tid == 0) s_nk = 0;
     __syncthreads();
+    const uint64_t *M = stage_mask ? smask : mask;
     const int limit = max_keep > 0 ? max_keep : n;
     for (int b = 0; b < col_blocks; ++b) {
         if (wid == 0) {
             const int ri = 64 * b + lane;
-            const uint64_t diag = ri < n ? mask[(size_t)ri * col_blocks + b] : 0;
-            uint64_t cur = remv[b];
+            const uint64_t diag = ri < n ? M[(size_t)ri * col_blocks + b] : 0;
+            uint64_t cur = uniform64(remv[b]);
             const int nrows = min(64, n - 64 * b);
+            const uint64_t valid = nrows == 64 ? ~0ULL : ((1ULL << nrows) - 1ULL);
             const int nk0 = s_nk;
             int nk = nk0;
             uint64_t kept = 0;
-            for (int i = 0; i < nrows && nk < limit; ++i) {
-                if (!((cur >> i) & 1ULL)) {
-                    kept |= 1ULL << i;
-                    ++nk;
-                    // v_readlane: broadcast the diagonal word of row i
-                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)diag, i);
-                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(diag >> 32), i);
-                    cur |= ((uint64_t)hi << 32) | lo;
-                }
+            uint64_t avail = ~cur & valid;                               // candidates not suppressed so far
+            while (avail && nk < limit) {
+                const int i = __builtin_ctzll(avail);
+                kept |= 1ULL << i;
+                ++nk;
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)diag, i);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(diag >> 32), i);
+                cur |= ((uint64_t)hi << 32) | lo;
+                const uint64_t above = i == 63 ? 0ULL : (~0ULL << (i + 1));
+                avail = ~cur & valid & above;
             }
-            // survivors of this block: lane i writes its own slot (prefix popcount gives the rank)
             if ((kept >> lane) & 1ULL) {
                 const int rank = nk0 + __popcll(kept & ((1ULL << lane) - 1ULL));
                 const int i = 64 * b + lane;
                 keep[rank] = i;
                 if (SELECT) {
                     const int64_t src = order[i];
-                    for (int k = 0; k < 6; ++k) rois[6 * rank + k] = boxes_all[6 * src + k];
-                    roi_scores[rank] = scores_sorted[i];
-                    roi_levels[rank] = level_all[src];
+                    float *r = rois + 6 * rank;
+                    const float *p = boxes_all + 6 * src;
+                    r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3]; r[4] = p[4]; r[5] = p[5];
+                    roi_scores[rank] = stage_meta ? sscr[i] : scores_sorted[i];
+                    roi_levels[rank] = stage_meta ? slev[i] : level_all[src];
                 }
             }
             if (lane == 0) { s_kept = kept; s_nk = nk; }
@@ -138,15 +166,14 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restri
         __syncthreads();
         const uint64_t kept = s_kept;
         if (s_nk >= limit) break;
-        // fold the kept rows of block b into remv for the later column blocks
-        for (int c = b + 1 + tid; c < col_blocks; c += blockDim.x) {
-            uint64_t acc = remv[c], k = kept;
-            while (k) {
-                const int i = __builtin_ctzll(k);
-                k &= k - 1;
-                acc |= mask[(size_t)(64 * b + i) * col_blocks + c];
+        for (int c = b + 1 + wid; c < col_blocks; c += nw) {
+            const int ri = 64 * b + lane;
+            uint64_t v = (((kept >> lane) & 1ULL) && ri < n) ? M[(size_t)ri * col_blocks + c] : 0ULL;
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
+                v |= ((uint64_t)hi << 32) | lo;
             }
-            remv[c] = acc;
+            if (lane == 0) remv[c] |= v;
         }
         __syncthreads();
     }
@@ -162,108 +189,6 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t *__restri
     }
 }
 
-// ---------------------------------------------------------------- single-launch path (matrix in LDS)
-constexpr int SMALL_N = 960;      // 960 x 15 words x 8 B = 112 KiB matrix + 30 KiB boxes of the 160 KiB LDS
-
-template <bool INDIRECT, bool SELECT>
-__global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order, int n,
-                                                        float thresh, int max_keep, int64_t *__restrict__ keep,
-                                                        int32_t *__restrict__ num_keep, const float *__restrict__ level_all,
-                                                        const float *__restrict__ scores_sorted, float *__restrict__ rois,
-                                                        float *__restrict__ roi_scores, float *__restrict__ roi_levels)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int col_blocks = (n + 63) / 64;
-    const int npad = col_blocks * 64;
-    Box *sbox = (Box *)smem;                                        // [npad]
-    uint64_t *smask = (uint64_t *)(smem + (size_t)npad * sizeof(Box)); // [npad][col_blocks]
-    uint64_t *remv = smask + (size_t)npad * col_blocks;               // [col_blocks]
-    __shared__ uint64_t s_kept;
-    __shared__ int s_nk;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-    for (int i = tid; i < npad; i += blockDim.x) {
-        Box b = {0, 0, 0, 0, 0, 0, 1, 0};
-        if (i < n) b = load_box<INDIRECT>(boxes, order, i);
-        sbox[i] = b;
-    }
-    for (int c = tid; c < col_blocks; c += blockDim.x) remv[c] = 0;
-    if (tid == 0) s_nk = 0;
-    __syncthreads();
-    // upper-triangular tiles, one wave each
-    const int ntiles = col_blocks * (col_blocks + 1) / 2;
-    for (int t = wid; t < ntiles; t += nw) {
-        int rb = 0, rem = t;
-        while (rem >= col_blocks - rb) { rem -= col_blocks - rb; ++rb; }
-        const int cb = rb + rem;
-        const Box col = sbox[64 * cb + lane];
-        const uint64_t w = tile_word(sbox + 64 * rb, col, 64 * cb + lane < n, rb, cb, n, thresh, lane);
-        smask[(size_t)(64 * rb + lane) * col_blocks + cb] = w;
-    }
-    __syncthreads();
-    const int limit = max_keep > 0 ? max_keep : n;
-    for (int b = 0; b < col_blocks; ++b) {
-        if (wid == 0) {
-            const uint64_t diag = smask[(size_t)(64 * b + lane) * col_blocks + b];
-            uint64_t cur = remv[b];
-            const int nrows = min(64, n - 64 * b);
-            const int nk0 = s_nk;
-            int nk = nk0;
-            uint64_t kept = 0;
-            for (int i = 0; i < nrows && nk < limit; ++i) {
-                if (!((cur >> i) & 1ULL)) {
-                    kept |= 1ULL << i;
-                    ++nk;
-                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)diag, i);
-                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(diag >> 32), i);
-                    cur |= ((uint64_t)hi << 32) | lo;
-                }
-            }
-            if ((kept >> lane) & 1ULL) {
-                const int rank = nk0 + __popcll(kept & ((1ULL << lane) - 1ULL));
-                const int i = 64 * b + lane;
-                keep[rank] = i;
-                if (SELECT) {
-                    const Box bx = sbox[i];
-                    float *r = rois + 6 * rank;
-                    r[0] = bx.x1; r[1] = bx.y1; r[2] = bx.z1; r[3] = bx.x2; r[4] = bx.y2; r[5] = bx.z2;
-                    roi_scores[rank] = scores_sorted[i];
-                    roi_levels[rank] = level_all[order[i]];
-                }
-            }
-            if (lane == 0) { s_kept = kept; s_nk = nk; }
-        }
-        __syncthreads();
-        const uint64_t kept = s_kept;
-        if (s_nk >= limit) break;
-        for (int c = b + 1 + tid; c < col_blocks; c += blockDim.x) {
-            uint64_t acc = remv[c], k = kept;
-            while (k) {
-                const int i = __builtin_ctzll(k);
-                k &= k - 1;
-                acc |= smask[(size_t)(64 * b + i) * col_blocks + c];
-            }
-            remv[c] = acc;
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    const int nk = s_nk;
-    if (tid == 0) num_keep[0] = nk;
-    if (SELECT) {
-        for (int r = nk + tid; r < max_keep; r += blockDim.x) {
-            for (int k = 0; k < 6; ++k) rois[6 * r + k] = 0.0f;
-            roi_scores[r] = 0.0f;
-            roi_levels[r] = 0.0f;
-        }
-    }
-}
-
-size_t small_lds_bytes(int n)
-{
-    const size_t cb = (n + 63) / 64, npad = cb * 64;
-    return npad * sizeof(Box) + npad * cb * 8 + cb * 8;
-}
-
 template <bool INDIRECT, bool SELECT>
 int launch_nms(const float *boxes, const int64_t *order, const float *level_all, const float *scores_sorted, int n,
                float thresh, int max_keep, int64_t *keep, int32_t *num_keep, float *rois, float *roi_scores,
@@ -271,32 +196,27 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
 {
     if (n < 0 || !keep || !num_keep) return SIS3D_EINVAL;
     if (SELECT && max_keep <= 0) return SIS3D_EINVAL;
-    if (n == 0) {
-        // nothing to keep; still define the outputs
-        hipLaunchKernelGGL((nms_small_kernel<INDIRECT, SELECT>), dim3(1), dim3(64), 64, st, boxes, order, 0, thresh, max_keep,
-                           keep, num_keep, level_all, scores_sorted, rois, roi_scores, roi_levels);
-        return sis3d_check_launch();
-    }
-    if (n <= SMALL_N) {
-        const size_t lds = small_lds_bytes(n);
-        auto kern = nms_small_kernel<INDIRECT, SELECT>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, boxes, order, n, thresh, max_keep, keep, num_keep, level_all,
-                           scores_sorted, rois, roi_scores, roi_levels);
-        return sis3d_check_launch();
-    }
     const int cb = (n + 63) / 64;
-    if (ws_bytes < (size_t)n * cb * 8 || !ws) return SIS3D_EWORKSPACE;
+    const size_t mask_bytes = (size_t)n * cb * 8;
+    if (n > 0 && (ws_bytes < mask_bytes || !ws)) return SIS3D_EWORKSPACE;
     uint64_t *mask = (uint64_t *)ws;
-    hipLaunchKernelGGL((nms_mask_kernel<INDIRECT>), dim3(cb, cb), dim3(64), 0, st, boxes, order, n, thresh, mask);
-    int rc = sis3d_check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL((nms_sweep_kernel<SELECT>), dim3(1), dim3(256), (size_t)cb * 8, st, mask, n, max_keep, keep, num_keep,
-                       boxes, level_all, scores_sorted, order, rois, roi_scores, roi_levels);
+    if (n > 0) {
+        // the bit matrix on as many CUs as it has 64x64 tiles (a single workgroup is VALU-bound: 28 us for n = 400)
+        hipLaunchKernelGGL((nms_mask_kernel<INDIRECT>), dim3(cb, cb), dim3(64), 0, st, boxes, order, n, thresh, mask);
+        int rc = sis3d_check_launch();
+        if (rc) return rc;
+    }
+    const int stage_mask = mask_bytes <= SWEEP_LDS_MASK_MAX ? 1 : 0;
+    const int stage_meta = (SELECT && n <= 4096) ? 1 : 0;
+    const size_t lds = (size_t)cb * 8 + (stage_mask ? mask_bytes : 0) + (stage_meta ? (size_t)n * 8 : 0) + 16;
+    auto kern = nms_sweep_kernel<SELECT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, mask, n, max_keep, keep, num_keep, boxes, level_all, scores_sorted, order,
+                       rois, roi_scores, roi_levels, stage_mask, stage_meta);
     return sis3d_check_launch();
 }
 
@@ -304,8 +224,7 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
 
 extern "C" size_t sis3d_nms_workspace_bytes(int n)
 {
-    if (n <= SMALL_N) return 0;
-    return (size_t)n * ((n + 63) / 64) * 8;
+    return n > 0 ? (size_t)n * ((n + 63) / 64) * 8 : 0;
 }
 
 extern "C" int sis3d_nms(const float *boxes, int n, float thresh, int max_keep, int64_t *keep, int32_t *num_keep, void *ws,
