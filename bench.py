@@ -69,17 +69,20 @@ def build_net(workload):
 
 
 def time_dominant_kernel(net, iters=50):
-    """mean duration of the rpn_net k3 128->256 conv launch, HIP events on the launch (current) stream"""
+    """mean duration of the rpn_net k3 128->256 conv launch (12.23 GFLOP), HIP events on the launch (current) stream.
+    Runs BEFORE any graph is captured, on its own input: on ROCm 7.2 eager launches of these kernels between replays
+    of a captured graph were observed to fault the next replay, so the bench never interleaves them."""
     from sis3d import ops
-    l1 = net._net_conv[0]
+    x = ops.new_act(128, (24, 12, 24), torch.device("cuda"))
+    x.normal_().clamp_(min=0)                      # post-ReLU-like activations
     conv = net.rpn_net_level1
     for _ in range(5):
-        conv(l1)
+        conv(x)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        conv(l1)
+        conv(x)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
@@ -150,6 +153,7 @@ def main():
     from sis3d.engine import PipelinedEngines
     ops.lib()
     net, cfg, sd = build_net(args.workload)
+    kt = time_dominant_kernel(net) if rank == 0 else 0.0
     stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
     nfl = max(1, args.inflight)
     eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph)
@@ -160,7 +164,10 @@ def main():
             eng.load(i, data, feats, i3d, i2d)
         else:
             eng.load(i, data)
+    dbg = bool(os.environ.get("SIS3D_BENCH_DEBUG"))
     eng.prepare(warmup=2)
+    if dbg:
+        print("[bench] prepared", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         eng.run()
 
@@ -176,6 +183,8 @@ def main():
         eng.run()
     barrier()
     dt = time.perf_counter() - t0
+    if dbg:
+        print("[bench] timed loop done", file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,13 +193,13 @@ def main():
     value = world * nfl * VOXELS * args.steps / dt
 
     if rank == 0:
-        kt = time_dominant_kernel(net)
         algo = {k: v * nfl for k, v in ALGO[args.workload].items()}
         # latency of ONE chunk on an otherwise idle GPU (single stream), for reference
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(50):
             eng.run(0)
+            torch.cuda.synchronize()               # latency of ONE chunk: serialised on purpose
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 50 * 1e3
         line = {
