@@ -35,6 +35,7 @@ ALGO = {
     "backbone_rpn": dict(bytes=261.4e6, flops=42.58e9),
     "detect": dict(bytes=261.4e6 + 2 * 3.54e6 + 200 * 32768 + 8.4e6, flops=42.58e9 + 0.9e9),
     "images": dict(bytes=517e6 + 28.3e6 + 59.8e6 + 226.5e6, flops=29.1e9 + 24.86e9),
+    "scene": dict(bytes=261.4e6 + 2 * 3.54e6 + 200 * 32768 + 8.4e6, flops=42.58e9 + 0.9e9),
 }
 DOMINANT_FLOPS = 2.0 * 6912 * 256 * 128 * 27        # rpn_net_level{1,2}: 12.23 GFLOP per launch
 FP32_PEAK_TF = 157.3
@@ -46,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images"])
+    ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=2, help="independent chunks in flight per GPU (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,9 +153,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    use_dist = world > 1 or bool(os.environ.get("SIS3D_FORCE_DIST"))     # FORCE: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
@@ -164,65 +169,91 @@ def main():
     ops.lib()
     net, cfg, sd = build_net(args.workload)
     kt = time_dominant_kernel(net) if rank == 0 else 0.0
-    stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
-    nfl = max(1, args.inflight)
-    eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph)
-    for i in range(nfl):
-        data = synthetic.synth_chunk(rank * nfl + i)
-        if args.workload == "images":
-            feats, i3d, i2d = synthetic.synth_views(rank * nfl + i)
-            eng.load(i, data, feats, i3d, i2d)
-        else:
-            eng.load(i, data)
     dbg = bool(os.environ.get("SIS3D_BENCH_DEBUG"))
-    eng.prepare(warmup=2)
-    if dbg:
-        print("[bench] prepared", file=sys.stderr, flush=True)
-    for _ in range(args.warmup):
-        eng.run()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dbg:
-        print("[bench] timed loop done", file=sys.stderr, flush=True)
-    if world > 1:
+    single_ms = None
+    if args.workload == "scene":
+        # BASELINE config 5: 32 chunks of one scene (4 x 1 x 8 grid of 96x48x96 tiles), chunk c -> rank c mod W, per-chunk
+        # detection, ONE all-gather of the record blocks, whole-scene NMS on every rank.  A step = one whole scene.
+        from sis3d.scene import SceneRunner
+        n_chunks = 32
+        runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph)
+        chunks = []
+        for c in range(n_chunks):
+            payload = synthetic.synth_chunk(c).cuda() if c % world == rank else None     # resident in HBM, own shard only
+            chunks.append((c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), payload))
+        torch.cuda.synchronize()
+        for _ in range(max(1, args.warmup // 10)):
+            recs, keep = runner.infer(chunks)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            recs, keep = runner.infer(chunks)
+        barrier()
+        dt = time.perf_counter() - t0
+        nfl, vox_per_step = 1, n_chunks * VOXELS
+        extra_cfg = {"scene_chunks": n_chunks, "records": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel())}
+    else:
+        stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
+        nfl = max(1, args.inflight)
+        eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph)
+        for i in range(nfl):
+            data = synthetic.synth_chunk(rank * nfl + i)
+            if args.workload == "images":
+                feats, i3d, i2d = synthetic.synth_views(rank * nfl + i)
+                eng.load(i, data, feats, i3d, i2d)
+            else:
+                eng.load(i, data)
+        eng.prepare(warmup=2)
+        if dbg:
+            print("[bench] prepared", file=sys.stderr, flush=True)
+        for _ in range(args.warmup):
+            eng.run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.run()
+        barrier()
+        dt = time.perf_counter() - t0
+        vox_per_step = world * nfl * VOXELS
+        extra_cfg = {}
+        if rank == 0:
+            # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                eng.run(0)
+                torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t1) / 50 * 1e3
+    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
-    value = world * nfl * VOXELS * args.steps / dt
+    value = vox_per_step * args.steps / dt
 
     if rank == 0:
-        algo = {k: v * nfl for k, v in ALGO[args.workload].items()}
-        # latency of ONE chunk on an otherwise idle GPU (single stream), for reference
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            eng.run(0)
-            torch.cuda.synchronize()               # latency of ONE chunk: serialised on purpose
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - t1) / 50 * 1e3
+        nchunk_step = vox_per_step / VOXELS / world           # chunks per GPU per step
+        algo = {k: v * nchunk_step for k, v in ALGO[args.workload].items()}
         line = {
             "metric": "voxels/sec forward on 96x48x96 chunks",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": ("strong" if args.workload == "scene" else "weak"), "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"backbone_rpn": "config[1]: one 96x48x96 chunk per GPU, geometry-only, HIP 3D-conv backbone + RPN "
                                                     "(convs, heads, softmax), weights seeded synthetic",
                                     "detect": "config[2] minus mask head: backbone + RPN + decode/sort/NMS + RoI pooling + classifier",
-                                    "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN"}[args.workload],
+                                    "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN",
+                                    "scene": "config[4]: 32-chunk scene sharded chunk->rank, per-chunk detection, one RCCL all-gather of "
+                                             "record blocks, whole-scene 3D NMS on every rank"}[args.workload],
                        "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world,
-                       "chunks_per_step_per_gpu": nfl, "streams_per_gpu": nfl, "single_chunk_latency_ms": single_ms},
+                       "chunks_per_step_per_gpu": nchunk_step, "streams_per_gpu": nfl, "single_chunk_latency_ms": single_ms, **extra_cfg},
             "roofline": {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,1,...> rpn_net 128->256 (fp32 v_mfma_f32_32x32x2_f32)",
                          "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": DOMINANT_FLOPS / kt / 1e12 / FP32_PEAK_TF, "traffic": pmc_traffic(),
@@ -234,10 +265,20 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd, cfg, args.cpu_seconds)
-        print(json.dumps(line))
-    if world > 1:
+        out_line = json.dumps(line)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST thing on stdout: RCCL printf()s a version banner into C stdio's buffer, which
+        # would otherwise be flushed at exit, after our line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(out_line, flush=True)
 
 
 if __name__ == "__main__":
