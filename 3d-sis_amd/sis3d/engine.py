@@ -29,6 +29,7 @@ class ChunkEngine:
             self.feats = torch.zeros(self.n_views, cfg.NUM_IMAGE_CHANNELS, h, w, device=self.device)
             self.i3d = torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device)
             self.i2d = torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device)
+        self.origin = torch.zeros(RECORD_WIDTH, device=self.device)   # chunk origin (x,y,z,x,y,z,0...) added to the boxes
         self.graph = None
         self.out = None
         self.records = None
@@ -50,6 +51,11 @@ class ChunkEngine:
             z = torch.zeros_like(d["scores"]).view(-1, 1)
             rec = torch.cat([d["rois"], d["scores"].view(-1, 1), d["levels"].view(-1, 1), z, z], 1)
         d["records"] = rec
+        # fixed-size record block of this chunk in scene coordinates: [count, K x RECORD_WIDTH rows], rows >= count zeroed
+        k = rec.shape[0]
+        n = d["num"].to(rec.dtype).view(1)
+        valid = (torch.arange(k, device=rec.device).to(rec.dtype) < n).view(-1, 1)
+        d["block"] = torch.cat([n, torch.where(valid, rec + self.origin, torch.zeros_like(rec)).reshape(-1)])
         return d
 
     def prepare(self, warmup=2):
@@ -77,6 +83,11 @@ class ChunkEngine:
         # async only where it is safe: device sources or pinned host memory (a pageable source may be recycled by
         # the caller while an "async" staged copy is still reading it)
         dst.copy_(src, non_blocking=bool(src.is_cuda or src.is_pinned()))
+
+    def set_origin(self, origin):
+        """chunk origin in scene voxels (host tuple): written into the static buffer the captured graph reads"""
+        o = torch.tensor([origin[0], origin[1], origin[2], origin[0], origin[1], origin[2]] + [0.0] * (RECORD_WIDTH - 6))
+        self.origin.copy_(o)
 
     def load(self, data, feats=None, i3d=None, i2d=None):
         self._copy(self.scene, data)

@@ -1,30 +1,46 @@
-"""Whole-scene inference over chunk grids (BASELINE config 5) on top of ChunkEngine + parallel.
+"""Whole-scene inference over chunk grids (BASELINE config 5) on top of PipelinedEngines + parallel.
 
-Each rank owns chunks c with c mod W == rank and runs the captured per-chunk graph on them; the fixed-size
-record blocks are all-gathered once per scene and every rank runs the same whole-scene 3D NMS (HIP kernels)."""
+Each rank owns chunks c with c mod W == rank and runs the captured per-chunk graph on them, two chunks in flight on
+two HIP streams; the fixed-size record blocks are all-gathered once per scene (RCCL) and every rank runs the same
+whole-scene 3D NMS (HIP kernels)."""
 import torch
+import torch.distributed as dist
 
 from . import ops, parallel
-from .engine import ChunkEngine
+from .engine import PipelinedEngines
 
 
 class SceneRunner:
-    def __init__(self, net, dims, use_graph=True):
+    def __init__(self, net, dims, use_graph=True, inflight=2):
         self.net = net
         self.k_rows = int(net.cfg.TEST.RPN_POST_NMS_TOP_N)
-        self.engine = ChunkEngine(net, dims=dims, stage="detect", use_graph=use_graph).prepare()
-
-    def _detect(self, payload):
-        if isinstance(payload, (tuple, list)):
-            self.engine.load(*payload)
-        else:
-            self.engine.load(payload)
-        out = self.engine.run()
-        return out["records"], out["num"]            # static buffers: consumed (packed) before the next run, stream-ordered
+        self.pipes = PipelinedEngines(net, inflight, dims=dims, stage="detect", use_graph=use_graph).prepare()
 
     def infer(self, chunks, thresh=None, group=None, max_keep=0):
-        """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d))] for the whole scene.
-        -> (records (N,10) sorted by score, keep LongTensor) on the GPU, identical on every rank."""
+        """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d) or None)] for the whole scene (entries of other
+        ranks' chunks may carry None).  -> (records (N,10) sorted by score, keep LongTensor) on the GPU, identical on
+        every rank."""
         thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        n_chunks = len(chunks)
+        main = torch.cuda.current_stream()
+        local = []
         with torch.no_grad():
-            return parallel.infer_scene(chunks, self._detect, ops.nms, self.k_rows, thresh, group=group, max_keep=max_keep)
+            for j, c in enumerate(parallel.shard_chunks(n_chunks, rank, world)):
+                cid, origin, payload = chunks[c]
+                e = j % len(self.pipes.engines)
+                if isinstance(payload, (tuple, list)):
+                    self.pipes.load(e, *payload)
+                else:
+                    self.pipes.load(e, payload)
+                with torch.cuda.stream(self.pipes.streams[e]):
+                    self.pipes.engines[e].set_origin(origin)
+                out = self.pipes.run(e)
+                with torch.cuda.stream(self.pipes.streams[e]):
+                    blk = out["block"].clone()                 # packed inside the captured graph; copy out of the static buffer
+                blk.record_stream(main)
+                local.append(blk)
+            self.pipes.join()
+            blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group)
+            return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep)
