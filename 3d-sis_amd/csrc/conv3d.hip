@@ -38,6 +38,15 @@ struct PwStage {
     int cout, res_stride, out_stride, flags;
 };
 
+// ragged batch: many independent problems of DIFFERENT grid sizes in one launch (the per-box mask-head convs)
+struct RaggedDesc {
+    int X, Y, Z;          // grid of this problem (stride-1 convs: output grid == input grid)
+    int nbx, nby, nbz;    // bricks per axis for the launched tiling
+    int block0;           // first block of this problem in the launch
+    int pad;
+    int64_t in_off, out_off;   // element offsets of this problem's activations inside the packed in / out buffers
+};
+
 constexpr int MAXP = 4;   // independent same-shape problems per launch (e.g. the two RPN levels)
 
 struct ConvArgs {
@@ -62,6 +71,9 @@ struct ConvArgs {
     int npw;
     PwStage pw[2];
     // batched launch: problems 1..nprob-1 share every shape field and differ only in these pointers
+    const RaggedDesc *rag;   // device array, nrag entries (nrag == 0: regular launch)
+    int nrag;
+    int64_t ragged_blocks;   // total blocks of a ragged launch
     int nprob;
     const float *b_in[MAXP], *b_wp[MAXP], *b_bias[MAXP], *b_res[MAXP];
     float *b_out[MAXP], *b_out2[MAXP];
@@ -108,9 +120,24 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
     }
     // batched launch: the work list is problem-major; pick this block's pointer set (uniform -> scalar loads;
     // never copy the argument struct into a local, dynamic indexing would push it to scratch)
-    const int nbricks = a.nbx * a.nby * a.nbz;
     const float *p_in = a.in, *p_wp = a.wp, *p_bias = a.bias, *p_res = a.res;
     float *p_out = a.out, *p_out2 = a.out2;
+    int gX = a.X, gY = a.Y, gZ = a.Z, gOX = a.OX, gOY = a.OY, gOZ = a.OZ, nbx = a.nbx, nby = a.nby, nbz = a.nbz;
+    if (a.nrag > 0) {
+        // ragged batch: find this block's problem (block0 is ascending) -- all uniform, scalar loads
+        int lo = 0, hi = a.nrag - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.rag[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+        }
+        const RaggedDesc d = a.rag[lo];
+        bid -= d.block0;
+        gX = gOX = d.X; gY = gOY = d.Y; gZ = gOZ = d.Z;
+        nbx = d.nbx; nby = d.nby; nbz = d.nbz;
+        p_in += d.in_off;
+        if (p_out) p_out += d.out_off;
+    }
+    const int nbricks = nbx * nby * nbz;
     if (a.nprob > 1) {
         const int per = nbricks * a.ngroups;
         const int prob = bid / per;
@@ -120,7 +147,7 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
     }
     const int group = bid / nbricks;
     bid -= group * nbricks;
-    const int bz = bid % a.nbz, by = (bid / a.nbz) % a.nby, bx = bid / (a.nbz * a.nby);
+    const int bz = bid % nbz, by = (bid / nbz) % nby, bx = bid / (nbz * nby);
     const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;           // output brick origin
     const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD, iz0 = oz0 * S - PAD;
 
@@ -180,8 +207,8 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
             const int gx = ix0 + hx, gy = iy0 + hy, gz = iz0 + hz;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z)
-                v = *reinterpret_cast<const float4 *>(p_in + ((size_t)(gx * a.Y + gy) * a.Z + gz) * a.cin_stride + q * CK + c4 * 4);
+            if (gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ)
+                v = *reinterpret_cast<const float4 *>(p_in + ((size_t)(gx * gY + gy) * gZ + gz) * a.cin_stride + q * CK + c4 * 4);
             *reinterpret_cast<float4 *>(lds + row * RS + c4 * 4) = v;
         }
         __syncthreads();
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
     }
 
     // ---- epilogue.  D layout: column (cout) = lane&31, row (voxel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int64_t nvox_out = (int64_t)a.OX * a.OY * a.OZ;
+    const int64_t nvox_out = (int64_t)gOX * gOY * gOZ;
     constexpr int MROWS = 32 * MW;
     const int npw = PW ? a.npw : 0;
     const int c0s = a.cout + 4;                             // padded row stride of the on-chip output tile
@@ -248,8 +275,8 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             for (int r = 0; r < 16; ++r) {
                 const int mm = 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
-                const bool inside = ox < a.OX && oy < a.OY && oz < a.OZ;
-                const int64_t vox = ((int64_t)ox * a.OY + oy) * a.OZ + oz;
+                const bool inside = ox < gOX && oy < gOY && oz < gOZ;
+                const int64_t vox = ((int64_t)ox * gOY + oy) * gOZ + oz;
                 float v = acc[t][r] + bv;
                 if ((a.flags & SIS3D_EPI_RESIDUAL) && inside) v += p_res[vox * a.res_stride + co];
                 if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
@@ -297,8 +324,8 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             for (int r = 0; r < 16; ++r) {
                 const int mm = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
-                const bool inside = ox < a.OX && oy < a.OY && oz < a.OZ;
-                const int64_t vox = ((int64_t)ox * a.OY + oy) * a.OZ + oz;
+                const bool inside = ox < gOX && oy < gOY && oz < gOZ;
+                const int64_t vox = ((int64_t)ox * gOY + oy) * gOZ + oz;
                 float v = c2[r] + bb;
                 if ((st.flags & SIS3D_EPI_RESIDUAL) && inside) v += st.res[vox * st.res_stride + co];
                 if (st.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
@@ -401,7 +428,7 @@ int launch_cfg_(ConvArgs &a, hipStream_t st)
         static size_t set_to = 0;
         if (lds > set_to) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_to = lds; }
     }
-    const int64_t blocks = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups * (a.nprob > 1 ? a.nprob : 1);
+    const int64_t blocks = a.nrag > 0 ? a.ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * a.ngroups * (a.nprob > 1 ? a.nprob : 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * MW * NW * KW), lds, st, a);
     return sis3d_check_launch();
 }
@@ -529,6 +556,7 @@ extern "C" int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int c
     ConvArgs a;
     a.nprob = 1;
     a.npw = 0;
+    a.rag = nullptr; a.nrag = 0; a.ragged_blocks = 0;
     a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = (cout + 31) / 32;
     a.flags = flags; a.res = residual; a.res_stride = res_stride;
@@ -549,6 +577,7 @@ extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin,
     if (flags & (SIS3D_EPI_RPN_HEAD | SIS3D_EPI_RESIDUAL)) return SIS3D_EUNSUPPORTED;
     ConvArgs a;
     a.nprob = 1;
+    a.rag = nullptr; a.nrag = 0; a.ragged_blocks = 0;
     a.npw = nstages;
     int cprev = cout;
     for (int i = 0; i < nstages; ++i) {
@@ -580,6 +609,7 @@ extern "C" int sis3d_conv3d_batched(int nprob, const float *const *ins, int X, i
     if (flags & SIS3D_EPI_RPN_HEAD) return SIS3D_EUNSUPPORTED;
     ConvArgs a;
     a.npw = 0;
+    a.rag = nullptr; a.nrag = 0; a.ragged_blocks = 0;
     a.nprob = nprob;
     for (int p = 0; p < nprob; ++p) {
         if (!ins[p] || !packed_ws[p] || !outs[p]) return SIS3D_EINVAL;
@@ -596,6 +626,107 @@ extern "C" int sis3d_conv3d_batched(int nprob, const float *const *ins, int X, i
     if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
     if (ksize == 2 && stride == 2) { a.OX = X / 2; a.OY = Y / 2; a.OZ = Z / 2; if (!a.OX || !a.OY || !a.OZ) return SIS3D_EINVAL; return dispatch<2, 2>(a, st); }
     return SIS3D_EUNSUPPORTED;
+}
+
+// ---- ragged batches (mask head: one launch for all detected boxes) ---------------------------------------------
+struct PlanarDesc {
+    int x0, y0, z0;       // window origin in the planar grid
+    int dx, dy, dz;       // window (= output) size
+    int pad0, pad1;
+    int64_t t0;           // first work item (voxel x cout/4) of this problem
+    int64_t out_off;      // element offset of this problem's output rows
+};
+
+// k3 p1 on windows of the planar 2-channel grid, zero padding at each WINDOW border (what nn.Conv3d on the sliced
+// tensor computes, lib/nets/network.py:307-310 + backbones.py:241)
+__global__ __launch_bounds__(256) void conv_planar2_ragged_kernel(const float *__restrict__ in, int64_t is_c, int64_t is_x, int64_t is_y,
+                                                                  const PlanarDesc *__restrict__ desc, int ndesc, int64_t total,
+                                                                  const float *__restrict__ w, int cout, int flags,
+                                                                  float *__restrict__ out, int out_stride)
+{
+    constexpr int KS = 3, T = 27, K = 54;
+    extern __shared__ __attribute__((aligned(16))) float wl[];     // [K][cout]
+    for (int i = threadIdx.x; i < K * cout; i += blockDim.x) {
+        const int co = i % cout, k = i / cout;
+        wl[i] = w[(int64_t)co * K + k];
+    }
+    __syncthreads();
+    const int cq = cout / 4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = ndesc - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (desc[mid].t0 <= t) lo = mid; else hi = mid - 1;
+        }
+        const PlanarDesc d = desc[lo];
+        const int64_t tl = t - d.t0;
+        const int c4 = (int)(tl % cq) * 4;
+        const int64_t v = tl / cq;
+        const int oz = (int)(v % d.dz), oy = (int)((v / d.dz) % d.dy), ox = (int)(v / ((int64_t)d.dz * d.dy));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int ddx = 0; ddx < KS; ++ddx)
+#pragma unroll
+                for (int ddy = 0; ddy < KS; ++ddy)
+#pragma unroll
+                    for (int ddz = 0; ddz < KS; ++ddz) {
+                        const int wx = ox + ddx - 1, wy = oy + ddy - 1, wz = oz + ddz - 1;
+                        float xv = 0.0f;
+                        if (wx >= 0 && wx < d.dx && wy >= 0 && wy < d.dy && wz >= 0 && wz < d.dz)
+                            xv = in[ci * is_c + (int64_t)(d.x0 + wx) * is_x + (int64_t)(d.y0 + wy) * is_y + (d.z0 + wz)];
+                        const float4 wv = *reinterpret_cast<const float4 *>(wl + (ci * T + (ddx * KS + ddy) * KS + ddz) * cout + c4);
+                        acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+                        acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+                    }
+        if (flags & SIS3D_EPI_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4 *>(out + d.out_off + v * out_stride + c4) = acc;
+    }
+}
+
+extern "C" int sis3d_ragged_tiling(int cin, int cout, int ksize, int *bx, int *by, int *bz, int *ngroups)
+{
+    if (!bx || !by || !bz || !ngroups) return SIS3D_EINVAL;
+    const int ntiles = (cout + 31) / 32;
+    *bx = 2; *by = 4; *bz = 4;
+    if (ksize == 3 && cin % 32 == 0 && ntiles <= 2) { *ngroups = 1; return SIS3D_OK; }
+    if (ksize == 1 && cin == 64 && ntiles == 1) { *ngroups = 1; return SIS3D_OK; }
+    return SIS3D_EUNSUPPORTED;
+}
+
+extern "C" int sis3d_conv3d_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                                   int ksize, int flags, float *out, int out_stride, const void *desc_dev, int ndesc,
+                                   int64_t total_blocks, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || !desc_dev || ndesc <= 0 || total_blocks <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
+    if ((cin % 8) || (cin_stride % 4) || cin_stride < cin) return SIS3D_EINVAL;
+    if (flags & (SIS3D_EPI_RPN_HEAD | SIS3D_EPI_RESIDUAL)) return SIS3D_EUNSUPPORTED;
+    int bx, by, bz, ng;
+    int rc = sis3d_ragged_tiling(cin, cout, ksize, &bx, &by, &bz, &ng);
+    if (rc) return rc;
+    ConvArgs a;
+    a.nprob = 1; a.npw = 0;
+    a.rag = (const RaggedDesc *)desc_dev; a.nrag = ndesc;
+    a.in = in; a.X = a.Y = a.Z = a.OX = a.OY = a.OZ = 1; a.cin = cin; a.cin_stride = cin_stride;
+    a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = (cout + 31) / 32;
+    a.flags = flags; a.res = nullptr; a.res_stride = 0;
+    a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.anchors = 0;
+    a.ragged_blocks = total_blocks;
+    hipStream_t st = as_stream(stream);
+    if (ksize == 3) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);
+    return launch_cfg<1, 1, 2, 4, 4, 1, 1, 4, 1, 64>(a, st);
+}
+
+extern "C" int sis3d_conv3d_planar2_ragged(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, const void *desc_dev, int ndesc,
+                                           int64_t total_items, const float *w, int cout, int flags, float *out, int out_stride,
+                                           sis3d_stream_t stream)
+{
+    if (!in || !w || !out || !desc_dev || ndesc <= 0 || total_items <= 0 || cout <= 0 || (cout % 4) || (out_stride % 4)) return SIS3D_EINVAL;
+    const unsigned blocks = (unsigned)((total_items + 255) / 256 < 8192 ? (total_items + 255) / 256 : 8192);
+    hipLaunchKernelGGL(conv_planar2_ragged_kernel, dim3(blocks), dim3(256), sizeof(float) * 54 * cout, as_stream(stream), in, is_c, is_x,
+                       is_y, (const PlanarDesc *)desc_dev, ndesc, total_items, w, cout, flags, out, out_stride);
+    return sis3d_check_launch();
 }
 
 extern "C" int sis3d_conv3d_planar2(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, int X, int Y, int Z, int x0, int y0,

@@ -243,6 +243,16 @@ class MaskBackbone(nn.Module):
         return last(x)
 
 
+def _mask_forward_batched(self, scene, windows):
+    """all boxes at once: one launch per layer over the ragged batch of crops (ops.mask_head_batched)"""
+    g = self.geometry
+    pcs = [g[i]._packed.get(g[i]) for i in (2, 4, 6, 8)]
+    return ops.mask_head_batched(scene, windows, g[0].weight, pcs, g[10]._packed.get(g[10]), sigmoid=not self.training)
+
+
+MaskBackbone.forward_batched = _mask_forward_batched
+
+
 def state_dict_shapes(cfg=None):
     """{name: shape} of the checkpoint for cfg (meta-device build: no allocation, no RNG use)."""
     cfg = cfg or _default_cfg

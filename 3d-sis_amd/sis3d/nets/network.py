@@ -30,6 +30,7 @@ class Network(nn.Module):
         self._proposals = ProposalEngine(self.cfg)
         self._head_cache = {}
         self.batch_rpn = True             # both RPN k3 convs in one batched launch
+        self.batch_masks = True           # mask head of all detected boxes as one ragged launch per layer
 
     # network.py:35-64
     def init_modules(self):
@@ -107,12 +108,13 @@ class Network(nn.Module):
             if round(box[0]) >= round(box[3]) or round(box[1]) >= round(box[4]) or round(box[2]) >= round(box[5]):
                 sel[idx] = False
         self.mask_backbone.eval()
-        masks = []
+        windows = []
         for ind, roi in enumerate(pred_box):
             if sel[ind]:
-                b = [int(round(roi[k])) for k in range(6)]      # Python round: half-to-even, as the reference
-                masks.append(self.mask_backbone(self._scene, None, window=tuple(b)))
-        return [masks]
+                windows.append(tuple(int(round(roi[k])) for k in range(6)))      # Python round: half-to-even, as the reference
+        if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
+            return [self.mask_backbone.forward_batched(self._scene, windows)]   # one launch per layer for ALL boxes
+        return [[self.mask_backbone(self._scene, None, window=w) for w in windows]]
 
     # ------------------------------------------------------------------ forward --
     def _rpn_level(self, lv, feat, rpn=None):

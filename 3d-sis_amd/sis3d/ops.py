@@ -442,6 +442,83 @@ def classifier_forward(x, pk):
     return cls_score, cls_pred, cls_prob, bbox_pred
 
 
+_RAG_DT = None
+
+
+def _rag_dtypes():
+    global _RAG_DT
+    if _RAG_DT is None:
+        import numpy as np
+        _RAG_DT = (np.dtype([("X", "i4"), ("Y", "i4"), ("Z", "i4"), ("nbx", "i4"), ("nby", "i4"), ("nbz", "i4"), ("block0", "i4"),
+                             ("pad", "i4"), ("in_off", "i8"), ("out_off", "i8")]),
+                   np.dtype([("x0", "i4"), ("y0", "i4"), ("z0", "i4"), ("dx", "i4"), ("dy", "i4"), ("dz", "i4"), ("p0", "i4"),
+                             ("p1", "i4"), ("t0", "i8"), ("out_off", "i8")]))
+    return _RAG_DT
+
+
+def mask_head_batched(scene, windows, w0, pcs, pc_last, sigmoid=True):
+    """The MaskBackbone (lib/nets/backbones.py:236-287) on ALL detected boxes at once: one launch per layer over a
+    ragged batch of crops (sis3d_conv3d_planar2_ragged + 4 x sis3d_conv3d_ragged k3 + 1 x k1).
+    scene (1,2,X,Y,Z) planar; windows [(x0,y0,z0,x1,y1,z1)]; w0 = conv0 weight (64,2,3,3,3); pcs = 4 PackedConv (64->64 k3);
+    pc_last = PackedConv (64->NC, k1).  Returns a list of logical (1,NC,dx,dy,dz) tensors (views of one buffer)."""
+    import numpy as np
+    scene = _dev(scene, "scene")
+    if scene.dim() != 5 or scene.shape[0] != 1 or scene.shape[1] != 2 or scene.stride(4) != 1:
+        raise _lib.Sis3dError("mask_head_batched expects the planar (1,2,X,Y,Z) grid")
+    n = len(windows)
+    if n == 0:
+        return []
+    dev = scene.device
+    C, NC = pcs[0].cout, pc_last.cout
+    bx, by, bz, ng = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
+    check(lib().sis3d_ragged_tiling(C, C, 3, ctypes.byref(bx), ctypes.byref(by), ctypes.byref(bz), ctypes.byref(ng)), "sis3d_ragged_tiling")
+    bx, by, bz, ng = bx.value, by.value, bz.value, ng.value
+    rdt, pdt = _rag_dtypes()
+    d3 = np.zeros(n, dtype=rdt)
+    d1 = np.zeros(n, dtype=rdt)
+    dp = np.zeros(n, dtype=pdt)
+    voff = blk = t0 = 0
+    dims = []
+    for i, (x0, y0, z0, x1, y1, z1) in enumerate(windows):
+        dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
+        dims.append((dx, dy, dz))
+        nb = (-(-dx // bx), -(-dy // by), -(-dz // bz))
+        for d, ostr in ((d3, C), (d1, NC)):
+            d["X"][i], d["Y"][i], d["Z"][i] = dx, dy, dz
+            d["nbx"][i], d["nby"][i], d["nbz"][i] = nb
+            d["block0"][i] = blk
+            d["in_off"][i] = voff * C
+            d["out_off"][i] = voff * ostr
+        dp["x0"][i], dp["y0"][i], dp["z0"][i] = x0, y0, z0
+        dp["dx"][i], dp["dy"][i], dp["dz"][i] = dx, dy, dz
+        dp["t0"][i] = t0
+        dp["out_off"][i] = voff * C
+        voff += dx * dy * dz
+        blk += nb[0] * nb[1] * nb[2] * ng
+        t0 += dx * dy * dz * (C // 4)
+    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
+    g3, g1, gp = up(d3), up(d1), up(dp)
+    a = torch.empty(voff, C, device=dev)
+    b = torch.empty(voff, C, device=dev)
+    out = torch.empty(voff, NC, device=dev)
+    st = scene.stride()
+    check(lib().sis3d_conv3d_planar2_ragged(_ptr(scene), st[1], st[2], st[3], _ptr(gp), n, t0, _ptr(_dev(w0.detach(), "w0").contiguous()), C,
+                                            EPI_RELU, _ptr(a), C, _stream()), "sis3d_conv3d_planar2_ragged")
+    src, dst = a, b
+    for pc in pcs:
+        check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(g3), n, blk,
+                                        _stream()), "sis3d_conv3d_ragged")
+        src, dst = dst, src
+    check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
+                                    _ptr(out), NC, _ptr(g1), n, blk, _stream()), "sis3d_conv3d_ragged")
+    res, voff = [], 0
+    for dx, dy, dz in dims:
+        nv = dx * dy * dz
+        res.append(out[voff:voff + nv].view(dx, dy, dz, NC).permute(3, 0, 1, 2).unsqueeze(0))
+        voff += nv
+    return res
+
+
 def maxpool3(x):
     if not is_cl(x):
         raise _lib.Sis3dError("maxpool3 expects a channels-last activation")

@@ -204,6 +204,21 @@ int sis3d_conv3d_planar2(const float *in, int64_t is_c, int64_t is_x, int64_t is
                          int z0, int OX, int OY, int OZ, const float *w, int cout, int ksize, int flags, float *out,
                          int out_stride, sis3d_stream_t stream);
 
+/* ---- ragged batches: the mask head of lib/nets/network.py:303-317 (one conv stack per detected box, each on a
+ * different dx x dy x dz crop) as ONE launch per layer for all boxes.  Activations of all problems are packed back to
+ * back in one channels-last buffer; `desc_dev` is a device array of
+ *   struct { int32 X,Y,Z, nbx,nby,nbz, block0, pad; int64 in_off, out_off; }           (48 bytes, sis3d_conv3d_ragged)
+ *   struct { int32 x0,y0,z0, dx,dy,dz, pad,pad; int64 t0, out_off; }                  (48 bytes, sis3d_conv3d_planar2_ragged)
+ * built by the host: nb? = ceil(dim / b?) with the brick of sis3d_ragged_tiling, block0 = running sum of
+ * nbx*nby*nbz*ngroups; t0 = running sum of dx*dy*dz*cout/4; offsets in elements. */
+int sis3d_ragged_tiling(int cin, int cout, int ksize, int *bx, int *by, int *bz, int *ngroups);
+int sis3d_conv3d_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout, int ksize,
+                        int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks,
+                        sis3d_stream_t stream);
+int sis3d_conv3d_planar2_ragged(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, const void *desc_dev, int ndesc,
+                                int64_t total_items, const float *w, int cout, int flags, float *out, int out_stride,
+                                sis3d_stream_t stream);
+
 /* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding */
 int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream);
 
