@@ -63,6 +63,7 @@ struct ConvArgs {
     float *out;
     int out_stride, out_coff;
     float *out2;
+    float *out3;          // RPN head: softmax over the two class planes, same layout as the score map (may be NULL)
     int anchors;
     int nbx, nby, nbz;    // bricks per axis
     int ngroups;          // cout groups per brick
@@ -282,11 +283,28 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
                 if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
                 if (a.flags & SIS3D_EPI_SIGMOID) v = sigmoidf_(v);
                 if (PW && npw > 0) lds[mm * c0s + co] = v;        // keep the tile on chip for the fused 1x1x1 stages
-                if (!inside || !p_out) continue;
                 if (a.flags & SIS3D_EPI_RPN_HEAD) {
+                    // score channel c pairs with c +- A (background / foreground of the same anchor): both live in this
+                    // wave's first tile, same accumulator row -> the 2-way softmax of network.py:546 is one lane exchange
                     const int A = a.anchors;
-                    if (co < 2 * A) p_out[((int64_t)(co / A) * nvox_out + vox) * A + (co % A)] = v;
-                    else p_out2[vox * (6 * A) + (co - 2 * A)] = v;
+                    const int pl = co < A ? li + A : (co < 2 * A ? li - A : li);
+                    const float pv = __shfl(v, (lane & 32) | pl);
+                    if (!inside) continue;
+                    if (co < 2 * A) {
+                        const int64_t o = ((int64_t)(co / A) * nvox_out + vox) * A + (co % A);
+                        p_out[o] = v;
+                        if (a.out3) {
+                            const float mx = fmaxf(v, pv);
+                            const float e = expf(v - mx), ep = expf(pv - mx);
+                            a.out3[o] = e / (e + ep);
+                        }
+                    } else {
+                        p_out2[vox * (6 * A) + (co - 2 * A)] = v;
+                    }
+                    continue;
+                }
+                if (!inside || !p_out) continue;
+                if (false) {
                 } else {
                     p_out[vox * a.out_stride + a.out_coff + co] = v;
                 }
@@ -547,7 +565,7 @@ extern "C" int sis3d_conv_pack_weight(const float *w, int cout, int cin, int ksi
 
 extern "C" int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
                             int cout, int ksize, int stride, int flags, const float *residual, int res_stride, float *out,
-                            int out_stride, int out_coff, float *out2, int anchors, sis3d_stream_t stream)
+                            int out_stride, int out_coff, float *out2, float *out3, int anchors, sis3d_stream_t stream)
 {
     if (!in || !packed_w || !out || X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
     if ((cin % 8) || (cin_stride % 4) || cin_stride < cin) return SIS3D_EINVAL;
@@ -560,7 +578,8 @@ extern "C" int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int c
     a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = (cout + 31) / 32;
     a.flags = flags; a.res = residual; a.res_stride = res_stride;
-    a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = out2; a.anchors = anchors;
+    a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = out2; a.out3 = out3; a.anchors = anchors;
+    if ((flags & SIS3D_EPI_RPN_HEAD) && 2 * anchors > 32) return SIS3D_EUNSUPPORTED;   // class pairs must share one 32-wide tile
     hipStream_t st = as_stream(stream);
     if (ksize == 1 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<1, 1>(a, st); }
     if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
@@ -592,7 +611,7 @@ extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin,
     a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = cout / 32;
     a.flags = flags; a.res = nullptr; a.res_stride = 0;
-    a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.anchors = 0;
+    a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.out3 = nullptr; a.anchors = 0;
     hipStream_t st = as_stream(stream);
     if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
     if (ksize == 2 && stride == 2) { a.OX = X / 2; a.OY = Y / 2; a.OZ = Z / 2; if (!a.OX || !a.OY || !a.OZ) return SIS3D_EINVAL; return dispatch<2, 2>(a, st); }
@@ -620,7 +639,7 @@ extern "C" int sis3d_conv3d_batched(int nprob, const float *const *ins, int X, i
     a.in = ins[0]; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_ws[0]; a.bias = a.b_bias[0]; a.cout = cout; a.ntiles = (cout + 31) / 32;
     a.flags = flags; a.res = a.b_res[0]; a.res_stride = res_stride;
-    a.out = outs[0]; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = nullptr; a.anchors = 0;
+    a.out = outs[0]; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = nullptr; a.out3 = nullptr; a.anchors = 0;
     hipStream_t st = as_stream(stream);
     if (ksize == 1 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<1, 1>(a, st); }
     if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
@@ -711,7 +730,7 @@ extern "C" int sis3d_conv3d_ragged(const float *in, int cin, int cin_stride, con
     a.in = in; a.X = a.Y = a.Z = a.OX = a.OY = a.OZ = 1; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = (cout + 31) / 32;
     a.flags = flags; a.res = nullptr; a.res_stride = 0;
-    a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.anchors = 0;
+    a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.out3 = nullptr; a.anchors = 0;
     a.ragged_blocks = total_blocks;
     hipStream_t st = as_stream(stream);
     if (ksize == 3) return launch_cfg<3, 1, 2, 4, 4, 1, 2, 3, 1, 32>(a, st);

@@ -33,7 +33,7 @@ SIGNATURES = {
     "sis3d_conv_packed_floats": (c_sz, [c_int, c_int, c_int]),
     "sis3d_conv_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
-                             c_int, c_int, c_vp, c_int, c_vp]),
+                             c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "sis3d_conv3d_chain": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int,
                                    c_vp, c_vp]),
     "sis3d_conv3d_batched": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int,

@@ -123,8 +123,7 @@ class Network(nn.Module):
         A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
         if rpn is None:
             rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
-        score, bbox = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)
-        prob = ops.softmax2(score)
+        score, bbox, prob = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)     # softmax fused into the head epilogue
         self._predictions["rpn_cls_score_level%d" % lv] = score
         self._predictions["rpn_cls_prob_level%d" % lv] = prob
         self._predictions["rpn_bbox_pred_level%d" % lv] = bbox

@@ -266,7 +266,7 @@ class PackedConv:
 
 def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, out_coff=0, rpn_anchors=0):
     """x: channels-last (1,Cin,X,Y,Z).  -> channels-last (1,Cout,OX,OY,OZ) (or writes `out` at channel
-    offset out_coff).  rpn_anchors=A: returns (score (1,2,X,Y,Z,A), bbox (1,X,Y,Z,6A)) contiguous."""
+    offset out_coff).  rpn_anchors=A: returns (score (1,2,X,Y,Z,A), bbox (1,X,Y,Z,6A), prob = softmax(score, 1)) contiguous."""
     if not is_cl(x):
         raise _lib.Sis3dError("conv3d expects a channels-last activation (use ops.to_cl)")
     _, cin_t, X, Y, Z = x.shape
@@ -282,13 +282,16 @@ def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, 
         od = (X, Y, Z)
     flags = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_SIGMOID if sigmoid else 0)
     out2 = None
+    o3_ptr = None
     if rpn_anchors:
         A = rpn_anchors
         flags |= EPI_RPN_HEAD
         score = torch.empty((1, 2) + od + (A,), device=x.device)
         bbox = torch.empty((1,) + od + (6 * A,), device=x.device)
+        prob = torch.empty_like(score)
         o_ptr, o2_ptr, ostride = _ptr(score), _ptr(bbox), 0
-        ret = (score, bbox)
+        o3_ptr = _ptr(prob)
+        ret = (score, bbox, prob)
     else:
         if out is None:
             out = new_act(pc.cout, od, x.device)
@@ -302,7 +305,7 @@ def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, 
             raise _lib.Sis3dError("conv3d: residual must be channels-last with the output's grid")
         res_stride = residual.shape[1]
     check(lib().sis3d_conv3d(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed), _ptr(pc.bias), pc.cout, pc.k, stride, flags,
-                             _ptr(residual), res_stride, o_ptr, ostride, out_coff, o2_ptr, rpn_anchors, _stream()), "sis3d_conv3d")
+                             _ptr(residual), res_stride, o_ptr, ostride, out_coff, o2_ptr, o3_ptr, rpn_anchors, _stream()), "sis3d_conv3d")
     return ret
 
 

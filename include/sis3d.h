@@ -164,10 +164,11 @@ int sis3d_conv_pack_weight(const float *w, int cout, int cin, int ksize, float *
  * ksize/stride/pad in {(1,1,0),(3,1,1),(2,2,0)}.  in: (X,Y,Z,cin_stride>=cin) channels-last,
  * reading channels [0,cin).  out: (OX,OY,OZ) voxels, row stride out_stride floats, channel offset
  * out_coff (lets two convs write one concatenated tensor, backbones.py:109).
- * bias may be NULL.  For SIS3D_EPI_RPN_HEAD: out = score base, out2 = bbox base, anchors = A. */
+ * bias may be NULL.  For SIS3D_EPI_RPN_HEAD: out = score base, out2 = bbox base, out3 = softmax(score) over the two
+ * class planes (F.softmax of lib/nets/network.py:546; may be NULL), anchors = A (2A <= 32). */
 int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
                  int cout, int ksize, int stride, int flags, const float *residual, int res_stride, float *out,
-                 int out_stride, int out_coff, float *out2, int anchors, sis3d_stream_t stream);
+                 int out_stride, int out_coff, float *out2, float *out3, int anchors, sis3d_stream_t stream);
 
 /* A k=3 (or k=2/s=2) convolution followed by up to two fused 1x1x1 convolutions applied to the output tile
  * while it is still on chip: the Bottleneck of lib/nets/backbones.py:27-40 as ONE launch --

@@ -81,13 +81,15 @@ def test_rpn_head_layout(ops, A):
     wc, bc = _w(2 * A, 256, 1, g), torch.randn(2 * A, generator=g)
     wb, bb = _w(6 * A, 256, 1, g), torch.randn(6 * A, generator=g)
     pc = ops.PackedConv(torch.cat([wc, wb]).cuda(), torch.cat([bc, bb]).cuda())
-    score, bbox = ops.conv3d(cl(x), pc, rpn_anchors=A)
+    score, bbox, prob = ops.conv3d(cl(x), pc, rpn_anchors=A)
     want_b = F.conv3d(x, wb, bb).permute(0, 2, 3, 4, 1).contiguous()
     want_s = F.conv3d(x, wc, bc).view(1, 2, A, *dims).permute(0, 1, 3, 4, 5, 2).contiguous()
     assert score.shape == want_s.shape and bbox.shape == want_b.shape
     assert score.is_contiguous() and bbox.is_contiguous()
     assert (score.cpu() - want_s).abs().max() <= TOL
     assert (bbox.cpu() - want_b).abs().max() <= TOL
+    assert (prob.cpu() - torch.softmax(want_s, 1)).abs().max() <= 1e-5          # fused 2-way softmax (network.py:546)
+    assert torch.equal(prob, ops.softmax2(score))                               # bitwise the standalone kernel
 
 
 @pytest.mark.parametrize("k,cout,dims,window", [(2, 32, (96, 48, 96), None), (3, 64, (96, 48, 96), (10, 5, 20, 22, 25, 33)),
