@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "sis3d", "libsis3d_hip.so")
 OBJ = os.path.join(HERE, "build")
 
-EXACT = ["nms.hip", "roi_pool.hip", "projection.hip", "proposal.hip", "pool_misc.hip", "api.hip", "topk.hip"]
+EXACT = ["nms.hip", "roi_pool.hip", "projection.hip", "frustum.hip", "proposal.hip", "pool_misc.hip", "api.hip", "topk.hip"]
 FAST = ["conv3d.hip", "mlp.hip"]
 
 

@@ -175,6 +175,32 @@ def project_views_max(feats, lin3d, lin2d, volume_dims, killing_inds=(), channel
     return out
 
 
+VIEW_PARAM_FLOATS = 40
+
+
+def compute_projection(depths, view_params, volume_dims, image_dims, intrinsic, depth_min, depth_max, voxel_size, out=None):
+    """Device form of ProjectionHelper.compute_projection for V views (projection.py:52-121).
+    depths (V,H,W) fp32 cuda, view_params (V,40) fp32 cuda (see include/sis3d.h) -> (lin3d, lin2d) int64 (V,nvox+1)."""
+    depths = _dev(depths, "depths").contiguous()
+    view_params = _dev(view_params, "view_params").contiguous()
+    V = depths.shape[0]
+    W, H = int(image_dims[0]), int(image_dims[1])
+    if depths[0].numel() != W * H or tuple(view_params.shape) != (V, VIEW_PARAM_FLOATS):
+        raise _lib.Sis3dError("compute_projection: depths must be (V,%d,%d) and view_params (V,%d)" % (H, W, VIEW_PARAM_FLOATS))
+    X, Y, Z = (int(v) for v in volume_dims)
+    nvox = X * Y * Z
+    if out is None:
+        out = (torch.empty(V, nvox + 1, dtype=torch.int64, device=depths.device),
+               torch.empty(V, nvox + 1, dtype=torch.int64, device=depths.device))
+    wsb = lib().sis3d_compute_projection_workspace_bytes(V, nvox)
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=depths.device)
+    check(lib().sis3d_compute_projection(_ptr(depths), _ptr(view_params), V, X, Y, Z, W, H, float(intrinsic[0][0]),
+                                         float(intrinsic[1][1]), float(intrinsic[0][2]), float(intrinsic[1][2]), float(depth_min),
+                                         float(depth_max), float(voxel_size), _ptr(out[0]), _ptr(out[1]), _ptr(ws), wsb,
+                                         _stream()), "sis3d_compute_projection")
+    return out
+
+
 # ------------------------------------------------------------------ proposals --
 def proposal_decode(anchors, deltas, prob_fg, inside, dims, level_id, out_boxes, out_scores, out_levels):
     n = int(inside.numel())

@@ -75,3 +75,36 @@ def synth_views(chunk_id=0, n_views=5, n_per_view=3000, channels=128, image_hw=(
         i3d[v, 1:1 + n] = vox
         i2d[v, 1:1 + n] = pix
     return feats, i3d, i2d
+
+
+def synth_cameras(chunk_id=0, n_views=5, dims=CHUNK_DIMS, voxel_size=0.046875, image_hw=(32, 41), depth_range=(1.0, 3.5)):
+    """Seeded camera rig for ProjectionHelper.compute_projection: depth maps (V,h,w), camera_to_world (V,4,4),
+    world_to_grid (V,4,4).  Cameras stand 1-2.5 m outside a random face of the volume and look at a jittered point
+    inside it; ~10 % of the depth pixels are invalid (0), as in sensor data."""
+    g = torch.Generator().manual_seed(977 + int(chunk_id))
+    ext = torch.tensor([float(d) for d in dims]) * voxel_size
+    depths, c2ws, w2gs = [], [], []
+    for _ in range(n_views):
+        origin = (torch.rand(3, generator=g) - 0.5) * 2.0               # world position of grid voxel (0,0,0)
+        w2g = torch.eye(4)
+        w2g[0, 0] = w2g[1, 1] = w2g[2, 2] = 1.0 / voxel_size
+        w2g[:3, 3] = -origin / voxel_size
+        target = origin + ext * (0.25 + 0.5 * torch.rand(3, generator=g))
+        axis = int(torch.randint(0, 3, (1,), generator=g))
+        side = float(torch.randint(0, 2, (1,), generator=g)) * 2.0 - 1.0
+        pos = origin + ext * torch.rand(3, generator=g)
+        pos[axis] = origin[axis] + (ext[axis] if side > 0 else 0.0) + side * (1.0 + 1.5 * float(torch.rand(1, generator=g)))
+        fwd = target - pos
+        fwd = fwd / fwd.norm()
+        up = torch.tensor([0.0, 1.0, 0.0]) if abs(float(fwd[1])) < 0.9 else torch.tensor([1.0, 0.0, 0.0])
+        right = torch.linalg.cross(up, fwd)
+        right = right / right.norm()
+        down = torch.linalg.cross(fwd, right)
+        c2w = torch.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
+        depth = depth_range[0] + (depth_range[1] - depth_range[0]) * torch.rand(*image_hw, generator=g)
+        depth[torch.rand(*image_hw, generator=g) < 0.1] = 0.0
+        depths.append(depth)
+        c2ws.append(c2w)
+        w2gs.append(w2g)
+    return torch.stack(depths), torch.stack(c2ws), torch.stack(w2gs)

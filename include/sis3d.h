@@ -109,6 +109,23 @@ int sis3d_project_views_max(const float *feats, int V, int C, int64_t npix, cons
                             const uint8_t *kill_host, int X, int Y, int Z, float *out, int64_t os_c, int64_t os_x,
                             int64_t os_y, int64_t os_z, void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
 
+/* Replaces ProjectionHelper.compute_projection (lib/layer_utils/projection.py:52-121) and its
+ * call sites' per-view loop (lib/model/trainval.py:336-337,464-465,663-667,799-803) for V views of
+ * one volume.  depth [V][W*H]; view_params [V][SIS3D_VIEW_PARAM_FLOATS] = grid_to_world (16,
+ * row-major), world_to_camera (16), frustum voxel bounds min (3) and max (3) already clamped to
+ * [0, dims] (projection.py:59-61), 2 pad -- both device pointers.  fx..cy = INTRINSIC[0][0],
+ * [1][1], [0][2], [1][2]; W,H = DEPTH_SHAPE.  Outputs lin3d/lin2d [V][nvox+1] int64 in the
+ * reference's packing: slot 0 = count n, slots 1..n = ascending linear voxel index
+ * (z*X*Y + y*X + x) / pixel index (v*W + u); slots > n are zeroed (the reference leaves them
+ * uninitialised).  n == 0 is the reference's `return None`.  No host synchronisation.
+ * workspace: sis3d_compute_projection_workspace_bytes(V, nvox). */
+#define SIS3D_VIEW_PARAM_FLOATS 40
+size_t sis3d_compute_projection_workspace_bytes(int V, int64_t nvox);
+int sis3d_compute_projection(const float *depth, const float *view_params, int V, int X, int Y, int Z, int W, int H,
+                             float fx, float fy, float cx, float cy, float depth_min, float depth_max, float voxel_size,
+                             int64_t *lin3d, int64_t *lin2d, void *workspace, size_t workspace_bytes,
+                             sis3d_stream_t stream);
+
 /* ------------------------------------------------------- proposal decoding --
  * Replaces proposal_layer.py:96-103 + bbox_transform_inv / clip_boxes
  * (lib/utils/bbox_transform.py:59-99,4-21) for one level:

@@ -149,6 +149,33 @@ def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3)
           "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
 
 
+def compute_projection_cases(ns):
+    """ProjectionHelper.compute_projection of the reference (under torch-0.4 integer division, ref_harness) on seeded
+    camera rigs; lists stored up to the count (the reference's tail is uninitialised memory)."""
+    cfg = ns.cfg
+    out = {}
+    for name, dims, cid, nv in (("small", (40, 24, 32), 1, 6), ("odd", (31, 70, 17), 2, 4), ("chunk", (96, 48, 96), 3, 5)):
+        depth, c2w, w2g = synthetic.synth_cameras(cid, nv, dims, cfg.VOXEL_SIZE, (cfg.DEPTH_SHAPE[1], cfg.DEPTH_SHAPE[0]))
+        if name == "small":
+            depth[4] = 0.0                                    # no valid depth   -> None (projection.py:105-107)
+            c2w[5, :3, 2] = -c2w[5, :3, 2]                    # looks away       -> None (:75-77 or :95-97)
+            c2w[5, :3, 0] = -c2w[5, :3, 0]
+        counts = []
+        for v in range(nv):
+            r = rh.ref_compute_projection(ns, depth[v], c2w[v], w2g[v], dims)
+            n = 0 if r is None else int(r[0][0])
+            counts.append(n)
+            out["%s_l3_%d" % (name, v)] = (r[0][1:1 + n] if n else torch.zeros(0)).numpy().astype(np.int32)
+            out["%s_l2_%d" % (name, v)] = (r[1][1:1 + n] if n else torch.zeros(0)).numpy().astype(np.int32)
+        out[name + "_dims"] = np.array(dims)
+        out[name + "_depth"] = depth.numpy()
+        out[name + "_c2w"] = c2w.numpy()
+        out[name + "_w2g"] = w2g.numpy()
+        out[name + "_counts"] = np.array(counts)
+        print("compute_projection", name, counts)
+    np.savez_compressed(os.path.join(OUT, "compute_projection_cases.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
@@ -156,6 +183,9 @@ def main():
     roi_cases(ns)
     projection_cases(ns)
     anchors_case(ns)
+    compute_projection_cases(ns)
+    if "--only-new" in sys.argv:
+        return
     e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)
     e2e(ns, "e2e_geometry_small", False, (64, 32, 48), 1, sub=2)
     e2e(ns, "e2e_images_small", True, (64, 32, 48), 2, n_views=3, n_per_view=400, sub=2)

@@ -229,3 +229,31 @@ def forward(ns, net, blobs, killing_inds=()):
     with in_reference_dir(), torch.no_grad():
         net.forward(blobs, "TEST", list(killing_inds))
     return net._predictions
+
+
+@contextlib.contextmanager
+def legacy_int_division():
+    """torch 0.4 semantics for `LongTensor / int` (floor division): the reference's compute_projection
+    (lib/layer_utils/projection.py:68-70,80-82) relies on it; under torch >= 1.5 `/` is true division and the function
+    returns None for every camera.  Patched only while the reference code runs -- the reference itself is unmodified."""
+    orig = torch.Tensor.__truediv__
+
+    def div(a, b):
+        if isinstance(a, torch.Tensor) and not a.is_floating_point() and not isinstance(b, float) and \
+                (not isinstance(b, torch.Tensor) or not b.is_floating_point()):
+            return torch.div(a, b, rounding_mode="floor")
+        return orig(a, b)
+    torch.Tensor.__truediv__ = div
+    try:
+        yield
+    finally:
+        torch.Tensor.__truediv__ = orig
+
+
+def ref_compute_projection(ns, depth, camera_to_world, world_to_grid, volume_dims):
+    """ProjectionHelper(...).compute_projection of the reference, run in place (CPU)."""
+    cfg = ns.cfg
+    helper = ns.projection.ProjectionHelper(cfg.INTRINSIC, cfg.PROJ_DEPTH_MIN, cfg.PROJ_DEPTH_MAX, cfg.DEPTH_SHAPE,
+                                            list(volume_dims), cfg.VOXEL_SIZE)
+    with legacy_int_division(), contextlib.redirect_stdout(None):
+        return helper.compute_projection(depth, camera_to_world, world_to_grid)

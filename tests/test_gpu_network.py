@@ -148,3 +148,23 @@ def test_mask_head_batched_equals_per_box(oracle):
         single = net.mask_backbone(data.cuda(), None, window=w)
         assert (g - single).abs().max() <= 1e-6
     assert net.mask_backbone.forward_batched(data.cuda(), []) == []
+
+
+@pytest.mark.parametrize("dims", [(70, 46, 58), (128, 64, 40)])
+def test_whole_scene_odd_grid_vs_oracle(oracle, dims):
+    """the reference's benchmark mode convolves whole (non-chunked) scene grids of arbitrary size
+    (lib/datasets/dataset.py:192-205): odd extents (floor at each stride-2 conv), bricks overhanging the volume"""
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_MASK = False
+    net, sd = build(cfg, seed=5)
+    data = synthetic.synth_chunk(21, dims)
+    p = net.forward(blobs_for(data), "TEST", [])
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data)
+    l1, l2 = net._net_conv
+    assert l1.shape == o["level1"].shape and l2.shape == o["level2"].shape
+    assert (l1.cpu() - o["level1"]).abs().max() <= TOL and (l2.cpu() - o["level2"]).abs().max() <= TOL
+    for lv in (1, 2):
+        assert (p["rpn_cls_prob_level%d" % lv].cpu() - o["rpn_cls_prob_level%d" % lv]).abs().max() <= TOL
+        assert (p["rpn_bbox_pred_level%d" % lv].cpu() - o["rpn_bbox_pred_level%d" % lv]).abs().max() <= TOL
+    assert match_boxes(p["rois"][0].cpu(), o["rois"][0]) >= 0.9
+    assert abs(p["cls_score"].shape[0] - o["cls_score"].shape[0]) <= max(3, o["cls_score"].shape[0] // 10)

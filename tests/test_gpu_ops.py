@@ -164,6 +164,66 @@ def test_project_views_single_view_is_plain_copy(ops, oracle):
     assert (want < 0).any()                                               # negatives survive: no zero clamp with one view
 
 
+# --------------------------------------------------------------- voxel -> pixel visibility
+def _helper(dims):
+    from sis3d.layer_utils.projection import ProjectionHelper
+    c = config.scannet_benchmark_cfg()
+    return c, ProjectionHelper(c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX, c.DEPTH_SHAPE, list(dims), c.VOXEL_SIZE)
+
+
+def test_compute_projection_golden_bit_exact(ops, golden):
+    """HIP compute_projection == the reference's own output (fixtures from oracle/make_golden.py), None exits included,
+    single-view reference signature and the batched form."""
+    g = golden("compute_projection_cases")
+    for name in ("small", "odd", "chunk"):
+        dims = tuple(int(v) for v in g[name + "_dims"])
+        _, helper = _helper(dims)
+        depth, c2w, w2g = (torch.from_numpy(g[name + k]) for k in ("_depth", "_c2w", "_w2g"))
+        counts = g[name + "_counts"]
+        l3, l2 = helper.compute_projection_views(dev(depth), c2w, w2g)
+        assert l3.shape == (len(counts), dims[0] * dims[1] * dims[2] + 1) and l3.dtype == torch.int64
+        for v, n in enumerate(counts):
+            one = helper.compute_projection(dev(depth[v]), dev(c2w[v]), dev(w2g[v]))
+            assert int(l3[v, 0]) == n and int(l2[v, 0]) == n
+            if n == 0:
+                assert one is None
+                continue
+            assert one[0].is_cuda and torch.equal(one[0], l3[v]) and torch.equal(one[1], l2[v])
+            assert np.array_equal(l3[v, 1:1 + n].cpu().numpy(), g["%s_l3_%d" % (name, v)])
+            assert np.array_equal(l2[v, 1:1 + n].cpu().numpy(), g["%s_l2_%d" % (name, v)])
+            assert not l3[v, 1 + n:].any() and not l2[v, 1 + n:].any()
+
+
+@pytest.mark.parametrize("dims,cid,nv", [((96, 48, 96), 5, 8), ((33, 17, 1025), 6, 3), ((160, 64, 224), 7, 4)])
+def test_compute_projection_vs_oracle(ops, oracle, dims, cid, nv):
+    """fresh seeded rigs, incl. a whole-scene-sized grid (2.3 M voxels): bit-exact lists vs the CPU oracle"""
+    c, helper = _helper(dims)
+    depth, c2w, w2g = synthetic.synth_cameras(cid, nv, dims, c.VOXEL_SIZE)
+    l3, l2 = helper.compute_projection_views(dev(depth), c2w, w2g)
+    total = 0
+    for v in range(nv):
+        o = oracle.compute_projection(depth[v], c2w[v], w2g[v], c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX,
+                                      c.DEPTH_SHAPE, dims, c.VOXEL_SIZE)
+        if o is None:
+            assert int(l3[v, 0]) == 0 and not l3[v].any() and not l2[v].any()
+            continue
+        total += int(o[0][0])
+        assert torch.equal(l3[v].cpu(), o[0]) and torch.equal(l2[v].cpu(), o[1]), v
+    assert total > 0
+
+
+def test_compute_projection_feeds_project_views(ops, oracle):
+    """row f-1 -> row a13: device-built lists drive the fused view max exactly like oracle-built ones"""
+    dims = (64, 32, 48)
+    c, helper = _helper(dims)
+    depth, c2w, w2g = synthetic.synth_cameras(11, 3, dims, c.VOXEL_SIZE)
+    feats = torch.randn(3, 16, 32, 41, generator=torch.Generator().manual_seed(5))
+    l3, l2 = helper.compute_projection_views(dev(depth), c2w, w2g)
+    got = ops.project_views_max(dev(feats), l3, l2, dims, channels_last=True)
+    want = oracle.project_views_max(feats, l3.cpu(), l2.cpu(), dims)
+    assert torch.equal(got.cpu(), want) and want.abs().sum() > 0
+
+
 # --------------------------------------------------------------------------------- decode
 def test_proposal_decode_and_softmax(ops, oracle):
     c = config.scannet_benchmark_cfg()

@@ -78,6 +78,49 @@ def test_projection_matches_reference(golden, oracle):
     assert torch.equal(fused_k[0].permute(0, 3, 2, 1), ref_k)
 
 
+def _oracle_compute_projection(oracle, c, depth, c2w, w2g, dims):
+    return oracle.compute_projection(depth, c2w, w2g, c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX, c.DEPTH_SHAPE, dims,
+                                     c.VOXEL_SIZE)
+
+
+def test_compute_projection_matches_reference(golden, oracle):
+    """ProjectionHelper.compute_projection (projection.py:52-121) incl. its three None exits."""
+    g = golden("compute_projection_cases")
+    c = config.scannet_benchmark_cfg()
+    for name in ("small", "odd", "chunk"):
+        dims = tuple(int(v) for v in g[name + "_dims"])
+        depth, c2w, w2g = (torch.from_numpy(g[name + k]) for k in ("_depth", "_c2w", "_w2g"))
+        for v, n in enumerate(g[name + "_counts"]):
+            r = _oracle_compute_projection(oracle, c, depth[v], c2w[v], w2g[v], dims)
+            if n == 0:
+                assert r is None
+                continue
+            assert int(r[0][0]) == n and int(r[1][0]) == n
+            assert np.array_equal(r[0][1:1 + n].numpy(), g["%s_l3_%d" % (name, v)])
+            assert np.array_equal(r[1][1:1 + n].numpy(), g["%s_l2_%d" % (name, v)])
+            assert not r[0][1 + n:].any() and not r[1][1 + n:].any()
+
+
+def test_compute_projection_vs_live_reference(oracle):
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("reference tree not present on this machine")
+    ns = rh.install()
+    c = config.scannet_benchmark_cfg()
+    dims = (52, 30, 44)
+    depth, c2w, w2g = synthetic.synth_cameras(21, 6, dims, c.VOXEL_SIZE)
+    hits = 0
+    for v in range(6):
+        r = rh.ref_compute_projection(ns, depth[v], c2w[v], w2g[v], dims)
+        o = _oracle_compute_projection(oracle, c, depth[v], c2w[v], w2g[v], dims)
+        assert (r is None) == (o is None)
+        if r is not None:
+            n = int(r[0][0])
+            hits += n
+            assert torch.equal(r[0][:n + 1], o[0][:n + 1]) and torch.equal(r[1][:n + 1], o[1][:n + 1])
+    assert hits > 1000
+
+
 def test_anchors_match_reference(golden, oracle):
     g = golden("anchors")
     c = config.scannet_benchmark_cfg()
