@@ -69,6 +69,7 @@ def scannet_benchmark_cfg():
     c.MASK_THRESH = 0.5
     c.MAX_VOLUME = 2000000
     c.MAX_IMAGE = 400
+    c.TEST_SAVE_DIR = ""
     c.TRUNCATED = 3.0
     return c
 

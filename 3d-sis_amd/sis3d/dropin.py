@@ -90,6 +90,10 @@ def install(ref_cfg=None):
     patch(r_net, "RoIPoolFunction", _roi_pool.RoIPoolFunction)
     patch(r_proj, "Projection", _projection.Projection)
     patch(r_net, "Projection", _projection.Projection)
+    patch(r_proj, "ProjectionHelper", _projection.ProjectionHelper)
+    r_tv = sys.modules.get("lib.model.trainval")          # `from ... import ProjectionHelper` binds by name (trainval.py:17)
+    if r_tv is not None and hasattr(r_tv, "ProjectionHelper"):
+        patch(r_tv, "ProjectionHelper", _projection.ProjectionHelper)
 
     def bind(cls):
         class _Bound(cls):

@@ -80,11 +80,40 @@ class ProjectionHelper(object):
                                       self.depth_max, self.voxel_size, out=out)
 
     def compute_projection(self, depth, camera_to_world, world_to_grid):
-        l3, l2 = self.compute_projection_views(depth.reshape(1, self.image_dims[1], self.image_dims[0]),
+        """A host depth map (the reference's big-volume branch, lib/model/trainval.py:664-665) is uploaded, processed
+        on the GPU and the lists returned on the host: the result lives where `depth` lives, as in the reference."""
+        d = depth if depth.is_cuda else depth.cuda()
+        l3, l2 = self.compute_projection_views(d.reshape(1, self.image_dims[1], self.image_dims[0]),
                                                camera_to_world.reshape(1, 4, 4), world_to_grid.reshape(1, 4, 4))
         if int(l3[0, 0].item()) == 0:                       # the reference's three `return None` exits (:75-77,95-97,105-107)
             return None
-        return l3[0], l2[0]
+        return (l3[0], l2[0]) if depth.is_cuda else (l3[0].cpu(), l2[0].cpu())
+
+
+def prepare_projection(blobs, cfg, helper=None):
+    """The colour-projection block every TEST/benchmark loop of the reference runs before net.forward
+    (lib/model/trainval.py:659-683, 795-819): builds blobs['proj_ind_3d'/'proj_ind_2d'] from
+    blobs['nearest_images']['depths'/'poses'/'world2grid'][0] and returns killing_inds (views with no visible voxel;
+    the stacked lists hold only the surviving views, as in the reference).  All views go through one device launch
+    sequence; one V-int readback replaces the reference's 3 x V `.any()` syncs."""
+    grid_shape = [int(v) for v in blobs["data"].shape[-3:]]
+    helper = helper or ProjectionHelper(cfg.INTRINSIC, cfg.PROJ_DEPTH_MIN, cfg.PROJ_DEPTH_MAX, cfg.DEPTH_SHAPE, grid_shape,
+                                        cfg.VOXEL_SIZE)
+    ni = blobs["nearest_images"]
+    depths = ni["depths"][0]
+    depths = depths if torch.is_tensor(depths) else torch.stack(list(depths))
+    V = min(depths.shape[0], len(ni["poses"][0]), len(ni["world2grid"][0]))      # zip() truncation
+    l3, l2 = helper.compute_projection_views(depths[:V].cuda(), ni["poses"][0], ni["world2grid"][0])
+    counts = l3[:, 0].cpu().tolist()
+    killing_inds = [v for v, n in enumerate(counts) if n == 0]
+    if len(killing_inds) == V:
+        raise Sis3dError("no view projects into the chunk (the reference fails in zip(*[]) here, trainval.py:680)")
+    if killing_inds:
+        keep = torch.tensor([v for v in range(V) if counts[v] > 0], device=l3.device)
+        l3, l2 = l3.index_select(0, keep), l2.index_select(0, keep)
+    blobs["proj_ind_3d"] = [l3]
+    blobs["proj_ind_2d"] = [l2]
+    return killing_inds
 
 
 class Projection(object):

@@ -91,27 +91,11 @@ class Network(nn.Module):
 
     # network.py:283-317
     def _mask_branch(self, n):
-        cfg = self.cfg
-        rois = self._predictions["rois"][0].cpu()
-        box_reg_pre = self._predictions["bbox_pred"].cpu().numpy()
-        pred_class = self._predictions["cls_pred"].cpu().numpy()
-        cls_prob = self._predictions["cls_prob"].cpu().numpy()
-        box_reg = np.zeros((box_reg_pre.shape[0], 6))
-        pred_conf = np.zeros((pred_class.shape[0]))
-        for i in range(pred_class.shape[0]):
-            box_reg[i, :] = box_reg_pre[i, pred_class[i] * 6:(pred_class[i] + 1) * 6]
-            pred_conf[i] = cls_prob[i, pred_class[i]]
-        from ..utils.bbox_transform import bbox_transform_inv, clip_boxes
-        pred_box = clip_boxes(bbox_transform_inv(rois, torch.from_numpy(box_reg).float()), self._scene_info[:3]).numpy()
-        sel = pred_conf > cfg.CLASS_THRESH
-        for idx, box in enumerate(pred_box):
-            if round(box[0]) >= round(box[3]) or round(box[1]) >= round(box[4]) or round(box[2]) >= round(box[5]):
-                sel[idx] = False
+        """network.py:290-317: mask head on the crops of the confident, non-degenerate final boxes"""
+        from ..model.trainval import final_detections, mask_windows
+        _, _, pred_box, keep = final_detections(self._predictions, self._scene_info, self.cfg)
         self.mask_backbone.eval()
-        windows = []
-        for ind, roi in enumerate(pred_box):
-            if sel[ind]:
-                windows.append(tuple(int(round(roi[k])) for k in range(6)))      # Python round: half-to-even, as the reference
+        windows = mask_windows(pred_box, keep)
         if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
             return [self.mask_backbone.forward_batched(self._scene, windows)]   # one launch per layer for ALL boxes
         return [[self.mask_backbone(self._scene, None, window=w) for w in windows]]

@@ -176,6 +176,42 @@ def compute_projection_cases(ns):
     np.savez_compressed(os.path.join(OUT, "compute_projection_cases.npz"), **out)
 
 
+def benchmark_case(ns_unused):
+    """SolverWrapper.benchmark of the reference (trainval.py:634-767) on a small synthetic scene, geometry-only and
+    with colour from depth maps + poses (one view sees nothing -> killing_inds)."""
+    import tempfile
+    ns = rh.install(with_trainval=True)
+    dims = (48, 24, 40)
+    out = {"dims": np.array(dims)}
+    for tag, use_images in (("geo", False), ("img", True)):
+        net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=True)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict(synthetic.synth_state_dict(shapes, seed=3, gains=synthetic.DEFAULT_GAINS))
+        data = synthetic.synth_chunk(9, dims)
+        blobs = rh.make_blobs(data, scene_id="/data/scenes/scene0707_00__0.scene")
+        if use_images:
+            depth, c2w, w2g = synthetic.synth_cameras(5, 4, dims, ns.cfg.VOXEL_SIZE)
+            depth[2] = 0
+            feats = torch.randn(4, 128, 32, 41, generator=torch.Generator().manual_seed(1))
+            blobs["nearest_images"] = {"images": [feats], "depths": [depth], "poses": [c2w], "world2grid": [w2g]}
+        thresh = 0.975 if use_images else 0.5             # 0.975: about half of the detections fall under the keep rule
+        old, ns.cfg.CLASS_THRESH = ns.cfg.CLASS_THRESH, thresh
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                r = rh.ref_benchmark(ns, net, [blobs], td)["scene0707_00"]
+        finally:
+            ns.cfg.CLASS_THRESH = old
+        out[tag + "_class_thresh"] = np.array(thresh)
+        for k in ("pred_class", "pred_conf", "pred_box"):
+            out[tag + "_" + k] = r[k]
+        out[tag + "_keep"] = np.array(r["pred_mask_index"])
+        out[tag + "_scene_sha"] = np.array(sha(r["scene"]))
+        out[tag + "_mask_shapes"] = np.array([m.shape for m in r["pred_mask"]]).reshape(-1, 3)
+        out[tag + "_mask_bits"] = np.packbits(np.concatenate([m.reshape(-1) for m in r["pred_mask"]]).astype(np.uint8))
+        print("benchmark", tag, "R=%d kept=%d" % (len(r["pred_class"]), int(out[tag + "_keep"].sum())))
+    np.savez_compressed(os.path.join(OUT, "benchmark_small.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
@@ -184,6 +220,7 @@ def main():
     projection_cases(ns)
     anchors_case(ns)
     compute_projection_cases(ns)
+    benchmark_case(ns)
     if "--only-new" in sys.argv:
         return
     e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)

@@ -156,23 +156,25 @@ def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=Fal
         # the two cffi extension packages (prebuilt cpython-36/sm_61 .so files are unusable)
         _stub("lib.layer_utils.roi_pooling._ext", roi_pooling=None).__path__ = []
         _stub("lib.layer_utils.nms._ext", nms=None).__path__ = []
-        if with_trainval:
-            _stub("h5py")
-            import scipy
-            scipy.misc = _stub("scipy.misc")
-            tv = _stub("torchvision")
-            tv.transforms = _stub("torchvision.transforms")
-            tn = _stub("torchnet")
-            tn.meter = _stub("torchnet.meter")
-            tn.meter.confusionmeter = _stub("torchnet.meter.confusionmeter", ConfusionMeter=None)
-            _stub("reprint", output=None)
-            _stub("tensorflow")
         # neutralise .cuda(): the reference forward calls it unconditionally
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
         torch.cuda.empty_cache = lambda: None
         torch.cuda.synchronize = lambda *a, **k: None
         _installed = True
+
+    if with_trainval and "reprint" not in sys.modules:
+        # import-time dependencies of lib/model/trainval.py that are not installable offline
+        _stub("h5py")
+        import scipy
+        scipy.misc = _stub("scipy.misc")
+        tv = _stub("torchvision")
+        tv.transforms = _stub("torchvision.transforms")
+        tn = _stub("torchnet")
+        tn.meter = _stub("torchnet.meter")
+        tn.meter.confusionmeter = _stub("torchnet.meter.confusionmeter", ConfusionMeter=None)
+        _stub("reprint", output=None)
+        _stub("tensorflow")
 
     with in_reference_dir():
         from lib.utils.config import cfg, cfg_from_file
@@ -196,7 +198,10 @@ def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=Fal
         from lib.layer_utils.roi_pooling import roi_pool
         from lib.utils import bbox_transform
         network.RoIPoolFunction = RefRoIPoolCallable
-    ns = types.SimpleNamespace(cfg=cfg, backbones=backbones, network=network, proposal_layer=pl_mod,
+        trainval = None
+        if with_trainval:
+            from lib.model import trainval
+    ns = types.SimpleNamespace(trainval=trainval, cfg=cfg, backbones=backbones, network=network, proposal_layer=pl_mod,
                                generate_anchors=ga_mod, projection=proj_mod, pth_nms=pth_nms,
                                roi_pool=roi_pool, bbox_transform=bbox_transform)
     return ns
@@ -257,3 +262,25 @@ def ref_compute_projection(ns, depth, camera_to_world, world_to_grid, volume_dim
                                             list(volume_dims), cfg.VOXEL_SIZE)
     with legacy_int_division(), contextlib.redirect_stdout(None):
         return helper.compute_projection(depth, camera_to_world, world_to_grid)
+
+
+def ref_benchmark(ns, net, blobs_list, save_dir):
+    """SolverWrapper.benchmark of the reference (lib/model/trainval.py:634-767), run in place on CPU over a list of
+    blobs; returns {scene_dir_name: {file: array / unpickled object}}.  `ns` must come from install(with_trainval=True)."""
+    import pickle
+    cfg = ns.cfg
+    cfg.TEST_SAVE_DIR = save_dir
+    with in_reference_dir(), legacy_int_division(), torch.no_grad(), contextlib.redirect_stdout(None):
+        ns.trainval.SolverWrapper.benchmark(net, blobs_list, None)
+    out = {}
+    for name in sorted(os.listdir(save_dir)):
+        d = os.path.join(save_dir, name)
+        files = {}
+        for f in sorted(os.listdir(d)):
+            if f.endswith(".npy"):
+                files[f[:-4]] = np.load(os.path.join(d, f))
+            else:
+                with open(os.path.join(d, f), "rb") as fh:
+                    files[f] = pickle.load(fh)
+        out[name] = files
+    return out

@@ -168,3 +168,39 @@ def test_whole_scene_odd_grid_vs_oracle(oracle, dims):
         assert (p["rpn_bbox_pred_level%d" % lv].cpu() - o["rpn_bbox_pred_level%d" % lv]).abs().max() <= TOL
     assert match_boxes(p["rois"][0].cpu(), o["rois"][0]) >= 0.9
     assert abs(p["cls_score"].shape[0] - o["cls_score"].shape[0]) <= max(3, o["cls_score"].shape[0] // 10)
+
+
+@pytest.mark.parametrize("kill_view", [None, 1])
+def test_forward_from_depth_maps_vs_oracle(oracle, kill_view):
+    """SURVEY 8f row 1 -> 8a: depth maps + poses -> device compute_projection -> forward, against the oracle running the
+    reference's caller block (trainval.py:659-683) with its own compute_projection; incl. a view that sees nothing."""
+    from sis3d.layer_utils.projection import prepare_projection
+    dims = (64, 32, 48)
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES = True
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(4, dims)
+    V = 4
+    depth, c2w, w2g = synthetic.synth_cameras(31, V, dims, cfg.VOXEL_SIZE)
+    if kill_view is not None:
+        depth[kill_view] = 0.0
+    feats = torch.randn(V, 128, 32, 41, generator=torch.Generator().manual_seed(17))
+    # oracle side: per-view lists, None -> killing_inds, stack of the survivors
+    maps = [oracle.compute_projection(depth[v], c2w[v], w2g[v], cfg.INTRINSIC, cfg.PROJ_DEPTH_MIN, cfg.PROJ_DEPTH_MAX,
+                                      cfg.DEPTH_SHAPE, dims, cfg.VOXEL_SIZE) for v in range(V)]
+    want_kill = [v for v, m in enumerate(maps) if m is None]
+    o3 = torch.stack([m[0] for m in maps if m is not None])
+    o2 = torch.stack([m[1] for m in maps if m is not None])
+    blobs = {"data": data, "id": ["syn0"], "gt_box": [torch.zeros(0, 7)], "gt_mask": [[]],
+             "nearest_images": {"images": [feats], "depths": [depth], "poses": [c2w], "world2grid": [w2g]}}
+    kill = prepare_projection(blobs, cfg)
+    assert kill == want_kill == ([] if kill_view is None else [kill_view])
+    assert torch.equal(blobs["proj_ind_3d"][0].cpu(), o3) and torch.equal(blobs["proj_ind_2d"][0].cpu(), o2)
+    p = net.forward(blobs, "TEST", kill)
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data, feats, o3, o2,
+                                                                                                 killing_inds=want_kill)
+    assert torch.equal(net._imageft.cpu(), o["imageft"]) and o["imageft"].abs().sum() > 0
+    for lv in (1, 2):
+        k = "rpn_cls_prob_level%d" % lv
+        assert (p[k].cpu() - o[k]).abs().max() <= TOL
+    assert match_boxes(p["rois"][0].cpu(), o["rois"][0]) >= 0.9
