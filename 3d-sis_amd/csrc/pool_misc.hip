@@ -80,7 +80,47 @@ __global__ void transpose_kernel(const float *__restrict__ src, int64_t rows, in
     }
 }
 
+// raw signed distance field (file order: x fastest, then y, then z) -> the network's 2-channel input
+// (lib/datasets/dataset.py:54-70): c0 = |clamp(v, -T, T)| (T - that with FLIP_TSDF, log of it with LOG_TSDF), c1 = v > -1.
+// One (x,z) tile per block and y slice: reads coalesced along x, writes coalesced along z (the innermost spatial axis of the
+// conv stack's channels-last layout), both channels of a voxel in one 8-byte store.
+__global__ void tsdf_encode_kernel(const float *__restrict__ sdf, int X, int Y, int Z, float trunc, int mode,
+                                   float *__restrict__ out, int64_t os_c, int64_t os_x, int64_t os_y, int64_t os_z)
+{
+    __shared__ float tile[32][33];
+    const int y = blockIdx.z;
+    const int x0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int z = z0 + j, x = x0 + threadIdx.x;
+        tile[j][threadIdx.x] = (z < Z && x < X) ? sdf[((int64_t)z * Y + y) * X + x] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int x = x0 + j, z = z0 + threadIdx.x;
+        if (x >= X || z >= Z) continue;
+        const float v = tile[threadIdx.x][j];
+        float a = fabsf(fminf(fmaxf(v, -trunc), trunc));
+        if (mode == 1) a = trunc - a;
+        else if (mode == 2) a = logf(a);
+        const float occ = v > -1.0f ? 1.0f : 0.0f;
+        float *dst = out + x * os_x + y * os_y + z * os_z;
+        if (os_c == 1) *reinterpret_cast<float2 *>(dst) = make_float2(a, occ);
+        else { dst[0] = a; dst[os_c] = occ; }
+    }
+}
+
 } // namespace
+
+extern "C" int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout, float truncated, int mode, float *out,
+                                 int64_t os_c, int64_t os_x, int64_t os_y, int64_t os_z, sis3d_stream_t stream)
+{
+    if (!sdf || !out || X <= 0 || Y <= 0 || Z <= 0 || Yout <= 0 || Yout > Y || mode < 0 || mode > 2) return SIS3D_EINVAL;
+    if (Yout > 65535 || cdiv(Z, 32) > 65535) return SIS3D_EUNSUPPORTED;
+    if (os_c == 1 && ((os_x | os_y | os_z) & 1)) return SIS3D_EINVAL;      // 8-byte stores need even strides
+    hipLaunchKernelGGL(tsdf_encode_kernel, dim3(cdiv(X, 32), cdiv(Z, 32), Yout), dim3(32, 8), 0, as_stream(stream), sdf, X, Y, Z,
+                       truncated, mode, out, os_c, os_x, os_y, os_z);
+    return sis3d_check_launch();
+}
 
 extern "C" int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream)
 {

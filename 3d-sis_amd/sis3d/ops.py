@@ -201,6 +201,28 @@ def compute_projection(depths, view_params, volume_dims, image_dims, intrinsic, 
     return out
 
 
+TSDF_MODES = {"abs": 0, "flip": 1, "log": 2}
+
+
+def tsdf_encode(sdf, dims, truncated=3.0, mode="abs", max_height=None, channels_last=True):
+    """raw sdf grid in file order (flat, x fastest; numel X*Y*Z, cuda) -> network input, logical (1,2,X,Yout,Z)
+    (dataset.py:54-70 + the max-height crop :196-211)."""
+    sdf = _dev(sdf, "sdf").contiguous()
+    X, Y, Z = (int(v) for v in dims)
+    if sdf.numel() != X * Y * Z:
+        raise _lib.Sis3dError("tsdf_encode: sdf has %d elements, dims say %d" % (sdf.numel(), X * Y * Z))
+    Yo = Y if max_height is None else min(Y, int(max_height))
+    if channels_last:
+        out = new_act(2, (X, Yo, Z), sdf.device)
+        st = (1, Yo * Z * 2, Z * 2, 2)
+    else:
+        out = torch.empty(1, 2, X, Yo, Z, device=sdf.device)
+        st = (X * Yo * Z, Yo * Z, Z, 1)
+    check(lib().sis3d_tsdf_encode(_ptr(sdf), X, Y, Z, Yo, float(truncated), TSDF_MODES[mode], _ptr(out), st[0], st[1], st[2],
+                                  st[3], _stream()), "sis3d_tsdf_encode")
+    return out
+
+
 # ------------------------------------------------------------------ proposals --
 def proposal_decode(anchors, deltas, prob_fg, inside, dims, level_id, out_boxes, out_scores, out_levels):
     n = int(inside.numel())

@@ -126,6 +126,15 @@ int sis3d_compute_projection(const float *depth, const float *view_params, int V
                              int64_t *lin3d, int64_t *lin2d, void *workspace, size_t workspace_bytes,
                              sis3d_stream_t stream);
 
+/* Replaces the TSDF encoding of Dataset.__getitem__ (lib/datasets/dataset.py:54-70) plus the
+ * max-height crop (:196-211, data[:, :, :maxHeight, :]) and the upload: sdf is the raw f32 grid of
+ * a .chunk/.scene file (x fastest, then y, then z; writer datagen/SceneSampler/main.cpp:348-415),
+ * already on the device.  out element (c,x,y,z), c in {0,1}, y < Yout <= Y, at
+ * c*os_c + x*os_x + y*os_y + z*os_z.  c0 = |clamp(v,-T,T)| (mode 0), T - that (mode 1, FLIP_TSDF),
+ * log of it (mode 2, LOG_TSDF); c1 = v > -1 ? 1 : 0. */
+int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout, float truncated, int mode, float *out,
+                      int64_t os_c, int64_t os_x, int64_t os_y, int64_t os_z, sis3d_stream_t stream);
+
 /* ------------------------------------------------------- proposal decoding --
  * Replaces proposal_layer.py:96-103 + bbox_transform_inv / clip_boxes
  * (lib/utils/bbox_transform.py:59-99,4-21) for one level:

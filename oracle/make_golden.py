@@ -212,6 +212,66 @@ def benchmark_case(ns_unused):
     np.savez_compressed(os.path.join(OUT, "benchmark_small.npz"), **out)
 
 
+def dataset_case(ns_unused):
+    """Dataset.__getitem__ of the reference (lib/datasets/dataset.py:45-218) on a synthetic .chunk container written by
+    sis3d.datasets.scene_file.write_scene_file (committed as tests/golden/synthetic.chunk + synthetic_labels.csv)."""
+    from sis3d.datasets import scene_file
+    ns = rh.install(with_trainval=True)
+    from lib.datasets.dataset import Dataset as RefDataset
+    g = np.random.default_rng(5)
+    dims = (20, 52, 12)                                            # Y > 48: exercises the chunk-mode height crop
+    sdf = (g.standard_normal(dims) * 3).astype(np.float32)
+    sdf[g.random(dims) < 0.2] = -np.inf                            # unobserved voxels
+    sdf[0, 0, 0], sdf[1, 0, 0], sdf[2, 0, 0] = -1.0, 3.0, -3.0      # boundaries of `> -1` and the clamp
+    boxes = np.array([[1.5, 2.2, 0.7, 9.1, 20.9, 7.5], [-3.0, 4.0, 2.0, 6.0, 30.0, 9.0], [4.0, 40.2, 1.0, 12.0, 51.5, 8.0],
+                      [10.2, 1.0, 3.0, 18.8, 12.0, 11.0], [2.0, 2.0, 2.0, 5.0, 5.0, 5.0]], dtype=np.float32)
+    labels = [3, 5, 7, 4, 38]                                       # 38: zero-weight class in the synthetic map
+    masks = []
+    for b, lab in zip(boxes, labels):
+        md = tuple(int(np.ceil(b[3 + k]) - np.floor(b[k])) for k in range(3))
+        m = g.integers(0, 2, md).astype(np.uint16)
+        m.reshape(-1)[:3] = [2, 257, 256]                           # > 1 cleared; 257 wraps to 1, 256 to 0 (uint8 cast)
+        masks.append((lab, m))
+    part = [1.0, 0.4, 1.0, 0.97, 1.0]
+    w2c = np.eye(4, dtype=np.float32) * 21.333
+    w2c[:3, 3] = [3.0, -2.0, 8.5]
+    w2c[3, 3] = 1
+    path = os.path.join(OUT, "synthetic.chunk")
+    scene_file.write_scene_file(path, sdf, boxes, labels, masks, part, w2c, [17, 420, 9000])
+    csv_path = os.path.join(OUT, "synthetic_labels.csv")
+    with open(csv_path, "w") as f:
+        f.write("nyu40id,nyu40class,mappedIdConsecutive,weight\n")
+        for nyu, cons, w in ((3, 1, 1.5), (4, 2, 0.8), (5, 3, 2.0), (7, 4, 1.1), (38, 5, 0.0)):
+            f.write("%d,c%d,%d,%g\n" % (nyu, nyu, cons, w))
+    lst = os.path.join(OUT, "synthetic_filelist.txt")
+    with open(lst, "w") as f:
+        f.write("synthetic.chunk\n")
+    out = {}
+    cfg = ns.cfg
+    saved = (cfg.LABEL_MAP, cfg.USE_IMAGES, cfg.USE_MASK, cfg.KEEP_THRESH)
+    try:
+        cfg.LABEL_MAP, cfg.USE_IMAGES, cfg.USE_MASK = csv_path, False, True
+        for mode, keep in (("chunk", 0.5), ("benchmark", 1.0), ("scene", 0.0)):
+            cfg.KEEP_THRESH = keep
+            old = os.getcwd()
+            os.chdir(OUT)
+            try:
+                ds = RefDataset(lst, mode)
+                r = ds[0]
+            finally:
+                os.chdir(old)
+            out[mode + "_keep_thresh"] = np.array(keep)
+            out[mode + "_data"] = r["data"]
+            out[mode + "_gt_box"] = r["gt_box"]
+            out[mode + "_n_mask"] = np.array(len(r["gt_mask"]))
+            for i, m in enumerate(r["gt_mask"]):
+                out["%s_mask_%d" % (mode, i)] = m
+            print("dataset", mode, r["data"].shape, r["data"].dtype, r["gt_box"].shape, len(r["gt_mask"]))
+    finally:
+        cfg.LABEL_MAP, cfg.USE_IMAGES, cfg.USE_MASK, cfg.KEEP_THRESH = saved
+    np.savez_compressed(os.path.join(OUT, "dataset_cases.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
@@ -221,6 +281,7 @@ def main():
     anchors_case(ns)
     compute_projection_cases(ns)
     benchmark_case(ns)
+    dataset_case(ns)
     if "--only-new" in sys.argv:
         return
     e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)
