@@ -78,6 +78,12 @@ struct ConvArgs {
     int nprob;
     const float *b_in[MAXP], *b_wp[MAXP], *b_bias[MAXP], *b_res[MAXP];
     float *b_out[MAXP], *b_out2[MAXP];
+    // projected input (sis3d_conv3d_chain_projected): the input volume is never materialised; a voxel's channel
+    // vector is gathered while the halo brick is staged: max over the view slots of (visible ? feature row : 0)
+    const int32_t *ptab = nullptr;   // [pslots][X*Y*Z] voxel -> pixel (-1 = not visible), linear voxel index z*X*Y + y*X + x
+    const float *pfeat = nullptr;    // [pslots][pnpix][cin] pixel-major feature rows
+    int pslots = 0;
+    int64_t pnpix = 0;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -87,7 +93,8 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // output tile and are summed through LDS at the end (intra-workgroup split-K: no atomics, deterministic);
 // CK channels per LDS chunk (k=1: CK == cin, a single chunk).
 // PW: compile the fused pointwise stages in (separate instantiation so the plain kernels keep their register budget)
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4>
+// PROJ: the input is a back-projected image volume given as (voxel->pixel table, pixel-major features), see ConvArgs::ptab
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4, bool PROJ = false>
 __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const ConvArgs a)
 {
     static_assert(BX * BY * BZ == 32 * MW, "brick must hold 32*MW voxels");
@@ -196,6 +203,30 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
         const int dz = tap % KS, dy = (tap / KS) % KS, dx = tap / (KS * KS);
         dst = *reinterpret_cast<const float4 *>(aptr + ((dx * IBY + dy) * IBZ + dz) * RS + 8 * g);
     };
+    // projected input: >98 % of the voxels are seen by no view; a brick without a single visible voxel contributes
+    // exactly zero, so its workgroup skips the whole reduction and goes straight to the epilogue (bias, ReLU, fused stages)
+    bool brick_live = true;
+    constexpr int PSL = 8;                                 // view slots whose per-row pixel index is cached in LDS
+    __shared__ int32_t ppix[PROJ ? PSL * ROWS : 1];
+    if constexpr (PROJ) {
+        // one pass over the brick's (row, slot) table entries: cache them for the four channel-chunk refills, and find
+        // out whether anything is visible at all
+        const int64_t pnvox = (int64_t)gX * gY * gZ;
+        int seen = 0;
+        for (int idx = tid; idx < ROWS * a.pslots; idx += NTHREADS) {
+            const int row = idx % ROWS, sl = idx / ROWS;
+            const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
+            const int gx = ix0 + hx, gy = iy0 + hy, gz = iz0 + hz;
+            int pix = -1;
+            if (gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ)
+                pix = a.ptab[sl * pnvox + ((int64_t)gz * gY + gy) * gX + gx];
+            if (sl < PSL) ppix[sl * ROWS + row] = pix;
+            seen |= pix >= 0;
+        }
+        brick_live = __syncthreads_or(seen) != 0;
+    }
+
+    if (brick_live) {
 #pragma unroll
     for (int d = 0; d < (DB > 1 ? DB - 1 : 1); ++d)
         if (d < NS) load_b(bq[d], 0, d);
@@ -208,8 +239,25 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
             const int gx = ix0 + hx, gy = iy0 + hy, gz = iz0 + hz;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ)
-                v = *reinterpret_cast<const float4 *>(p_in + ((size_t)(gx * gY + gy) * gZ + gz) * a.cin_stride + q * CK + c4 * 4);
+            if (gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ) {
+                if constexpr (PROJ) {
+                    // network.py:216-239 per voxel: max over the views, an invisible view counts as 0
+                    const int64_t pnvox = (int64_t)gX * gY * gZ, vox = ((int64_t)gz * gY + gy) * gX + gx;
+                    int cnt = 0;
+                    for (int sl = 0; sl < a.pslots; ++sl) {
+                        const int pix = sl < PSL ? ppix[sl * ROWS + row] : a.ptab[sl * pnvox + vox];
+                        if (pix >= 0) {
+                            const float4 f = *reinterpret_cast<const float4 *>(a.pfeat + ((size_t)sl * a.pnpix + pix) * a.cin + q * CK + c4 * 4);
+                            if (cnt == 0) v = f;
+                            else { v.x = fmaxf(v.x, f.x); v.y = fmaxf(v.y, f.y); v.z = fmaxf(v.z, f.z); v.w = fmaxf(v.w, f.w); }
+                            ++cnt;
+                        }
+                    }
+                    if (cnt > 0 && cnt < a.pslots) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                } else {
+                    v = *reinterpret_cast<const float4 *>(p_in + ((size_t)(gx * gY + gy) * gZ + gz) * a.cin_stride + q * CK + c4 * 4);
+                }
+            }
             *reinterpret_cast<float4 *>(lds + row * RS + c4 * 4) = v;
         }
         __syncthreads();
@@ -235,9 +283,10 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    }   // brick_live
 
     // ---- split-K reduction through LDS: waves kw>0 publish, waves kw==0 accumulate and run the epilogue
-    if constexpr (KW > 1) {
+    if (KW > 1 && brick_live) {
         __syncthreads();                                   // everyone is done reading the A image
         if (kw > 0) {
             float *red = lds + ((size_t)((kw - 1) * (MW * NW) + nw * MW + mw) * NTW) * 1024;
@@ -420,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restri
     }
 }
 
-template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4>
+template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4, bool PROJ = false>
 int launch_cfg_(ConvArgs &a, hipStream_t st)
 {
     constexpr int IBX = (BX - 1) * S + KS, IBY = (BY - 1) * S + KS, IBZ = (BZ - 1) * S + KS;
@@ -441,7 +490,7 @@ int launch_cfg_(ConvArgs &a, hipStream_t st)
     static_assert(64 * MW * NW * KW <= 1024, "workgroup too large");
     a.nbx = cdiv(a.OX, BX); a.nby = cdiv(a.OY, BY); a.nbz = cdiv(a.OZ, BZ);
     a.ngroups = cdiv(a.ntiles, NW * NTW);
-    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, PW, PF>;
+    auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, PW, PF, PROJ>;
     if (lds > 64 * 1024) {
         static size_t set_to = 0;
         if (lds > set_to) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_to = lds; }
@@ -455,6 +504,14 @@ template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW
 int launch_cfg(ConvArgs &a, hipStream_t st)
 {
     static const int pf_override = [] { const char *e = getenv("SIS3D_PF"); return e ? atoi(e) : 0; }();
+    if constexpr (KS == 2 && S == 2 && CK == 32 && NW * NTW <= 4) {
+        if (a.ptab) {                                      // projected input: only the colour stem (k2 s2 + fused conv1) uses it
+            if (a.npw == 0) return SIS3D_EUNSUPPORTED;
+            return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true, 4, true>(a, st);
+        }
+    } else {
+        if (a.ptab) return SIS3D_EUNSUPPORTED;
+    }
     if constexpr (KS != 1 && CK == 32 && NW * NTW <= 4) {
         if (a.npw > 0) {
             if (PF >= 12 && pf_override == 12) return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true, 12>(a, st);
@@ -587,14 +644,13 @@ extern "C" int sis3d_conv3d(const float *in, int X, int Y, int Z, int cin, int c
     return SIS3D_EUNSUPPORTED;
 }
 
-extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
-                                  int cout, int ksize, int stride, int flags, float *out, int out_stride, int nstages,
-                                  const sis3d_pw_stage *stages, sis3d_stream_t stream)
+static int chain_common(ConvArgs &a, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                        int ksize, int stride, int flags, float *out, int out_stride, int nstages, const sis3d_pw_stage *stages,
+                        sis3d_stream_t stream)
 {
-    if (!in || !packed_w || X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nstages < 1 || nstages > 2 || !stages) return SIS3D_EINVAL;
+    if (!packed_w || X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nstages < 1 || nstages > 2 || !stages) return SIS3D_EINVAL;
     if ((cin % 8) || (cin_stride % 4) || cin_stride < cin || (cout % 32) || cout > 128) return SIS3D_EINVAL;
     if (flags & (SIS3D_EPI_RPN_HEAD | SIS3D_EPI_RESIDUAL)) return SIS3D_EUNSUPPORTED;
-    ConvArgs a;
     a.nprob = 1;
     a.rag = nullptr; a.nrag = 0; a.ragged_blocks = 0;
     a.npw = nstages;
@@ -608,7 +664,7 @@ extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin,
         a.pw[i].cout = s.cout; a.pw[i].res_stride = s.res_stride; a.pw[i].out_stride = s.out_stride; a.pw[i].flags = s.flags;
         cprev = s.cout;
     }
-    a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
+    a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
     a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = cout / 32;
     a.flags = flags; a.res = nullptr; a.res_stride = 0;
     a.out = out; a.out_stride = out_stride; a.out_coff = 0; a.out2 = nullptr; a.out3 = nullptr; a.anchors = 0;
@@ -616,6 +672,27 @@ extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin,
     if (ksize == 3 && stride == 1) { a.OX = X; a.OY = Y; a.OZ = Z; return dispatch<3, 1>(a, st); }
     if (ksize == 2 && stride == 2) { a.OX = X / 2; a.OY = Y / 2; a.OZ = Z / 2; if (!a.OX || !a.OY || !a.OZ) return SIS3D_EINVAL; return dispatch<2, 2>(a, st); }
     return SIS3D_EUNSUPPORTED;
+}
+
+extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                                  int cout, int ksize, int stride, int flags, float *out, int out_stride, int nstages,
+                                  const sis3d_pw_stage *stages, sis3d_stream_t stream)
+{
+    if (!in) return SIS3D_EINVAL;
+    ConvArgs a;
+    a.in = in;
+    return chain_common(a, X, Y, Z, cin, cin_stride, packed_w, bias, cout, ksize, stride, flags, out, out_stride, nstages, stages, stream);
+}
+
+extern "C" int sis3d_conv3d_chain_projected(const int32_t *vox2pix, const float *feat_rows, int nslots, int64_t npix, int X, int Y, int Z,
+                                            int cin, const float *packed_w, const float *bias, int cout, int flags, float *out,
+                                            int out_stride, int nstages, const sis3d_pw_stage *stages, sis3d_stream_t stream)
+{
+    if (!vox2pix || !feat_rows || nslots <= 0 || npix <= 0 || (cin % 32)) return SIS3D_EINVAL;
+    ConvArgs a;
+    a.in = feat_rows;                                    // never dereferenced as a volume
+    a.ptab = vox2pix; a.pfeat = feat_rows; a.pslots = nslots; a.pnpix = npix;
+    return chain_common(a, X, Y, Z, cin, cin, packed_w, bias, cout, 2, 2, flags, out, out_stride, nstages, stages, stream);
 }
 
 extern "C" int sis3d_conv3d_batched(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,

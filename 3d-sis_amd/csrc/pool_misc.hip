@@ -10,9 +10,10 @@
 namespace {
 
 // thread = (x, y, z-segment of ZSEG voxels, 4 channels): the 3x3 (x,y) column maxima of ZSEG+2 consecutive z are
-// computed once and reused by three outputs each -> 9*(ZSEG+2)/ZSEG = 11 loads per output instead of 27
-constexpr int ZSEG = 8;
-
+// computed once and reused by three outputs each -> 9*(ZSEG+2)/ZSEG loads per output instead of 27.  The maps of this
+// network are small (6912 voxels x 16..32 float4 channels), so the launcher trades that reuse for parallelism: the
+// largest ZSEG that still puts >= ~100k threads on the chip (ZSEG = 8 on a 24x12x24x128 map left 3/4 of the CUs idle).
+template <int ZSEG>
 __global__ __launch_bounds__(256) void maxpool3_kernel(const float4 *__restrict__ in, int X, int Y, int Z, int C4,
                                                        float4 *__restrict__ out)
 {
@@ -125,11 +126,18 @@ extern "C" int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout
 extern "C" int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream)
 {
     if (!in || !out || X <= 0 || Y <= 0 || Z <= 0 || C <= 0 || (C % 4)) return SIS3D_EINVAL;
-    const int64_t total = (int64_t)X * Y * ((Z + ZSEG - 1) / ZSEG) * (C / 4);
-    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
-    hipLaunchKernelGGL(maxpool3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4 *)in, X, Y, Z, C / 4,
-                       (float4 *)out);
-    return sis3d_check_launch();
+    auto threads = [&](int zseg) { return (int64_t)X * Y * ((Z + zseg - 1) / zseg) * (C / 4); };
+    auto go = [&](auto kern, int zseg) {
+        const int64_t total = threads(zseg);
+        const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4 *)in, X, Y, Z, C / 4, (float4 *)out);
+        return sis3d_check_launch();
+    };
+    const int64_t want = 100000;
+    if (threads(8) >= want) return go(maxpool3_kernel<8>, 8);
+    if (threads(4) >= want) return go(maxpool3_kernel<4>, 4);
+    if (threads(2) >= want) return go(maxpool3_kernel<2>, 2);
+    return go(maxpool3_kernel<1>, 1);
 }
 
 // planar (C, nvox) -> channels-last (nvox, C): a transpose of a [C][nvox] matrix

@@ -189,3 +189,28 @@ extern "C" int sis3d_project_views_max(const float *feats, int V, int C, int64_t
     }
     return sis3d_check_launch();
 }
+
+// Table + pixel-major feature rows only (no volume): the input of sis3d_conv3d_chain_projected.
+extern "C" int sis3d_project_views_prepare(const float *feats, int V, int C, int64_t npix, const int64_t *lin3d, const int64_t *lin2d,
+                                           const uint8_t *kill_host, int64_t nvox, int32_t *vox2pix, float *feat_rows, int *nslots_out,
+                                           sis3d_stream_t stream)
+{
+    if (!feats || !lin3d || !lin2d || !vox2pix || !feat_rows || !nslots_out || V <= 0 || C <= 0 || npix <= 0 || nvox <= 0) return SIS3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    ViewIds ids;
+    ids.n = 0;
+    for (int v = 0; v < V; ++v)
+        if (!kill_host || !kill_host[v]) {
+            if (ids.n >= MAX_VIEWS) return SIS3D_EUNSUPPORTED;
+            ids.id[ids.n++] = v;
+        }
+    *nslots_out = ids.n;
+    if (ids.n == 0) return SIS3D_EINVAL;
+    if (hipMemsetAsync(vox2pix, 0xFF, sizeof(int32_t) * (size_t)ids.n * (size_t)nvox, st) != hipSuccess) return SIS3D_ELAUNCH;
+    hipLaunchKernelGGL(proj_table_kernel, dim3(64, ids.n), dim3(256), 0, st, lin3d, lin2d, nvox, ids, vox2pix);
+    int rc = sis3d_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(proj_transpose_kernel, dim3(cdiv(npix, 32), cdiv(C, 32), ids.n), dim3(32, 8), 0, st, feats, C, npix, ids,
+                       feat_rows);
+    return sis3d_check_launch();
+}

@@ -40,6 +40,9 @@ SIGNATURES = {
                              c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "sis3d_conv3d_chain": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int,
                                    c_vp, c_vp]),
+    "sis3d_conv3d_chain_projected": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp,
+                                             c_int, c_int, c_vp, c_vp]),
+    "sis3d_project_views_prepare": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_conv3d_batched": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int,
                                      c_vp, c_int, c_int, c_vp]),
     "sis3d_conv3d_planar2": (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -38,7 +38,8 @@ class ChunkEngine:
         net = self.net
         imageft = None
         if self.use_images:
-            imageft = ops.project_views_max(self.feats, self.i3d, self.i2d, self.dims, (), channels_last=True)
+            project = ops.project_views_prepare if getattr(net, "fuse_projection", False) else ops.project_views_max
+            imageft = project(self.feats, self.i3d, self.i2d, self.dims, ())
         if self.stage == "rpn":
             net.backbone_rpn(self.scene, imageft)
             return {k: v for k, v in net._predictions.items() if k.startswith("rpn_")}

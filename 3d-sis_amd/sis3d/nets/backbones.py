@@ -128,8 +128,12 @@ class FusedSequential(nn.Sequential):
                                                [dict(pc=nb.conv1._packed.get(nb.conv1), relu=True)], relu=m.fuse_relu, want_main=True)
                     y1 = outs[0]
                 except ops.Sis3dUnsupported:
+                    if isinstance(x, ops.ProjectedVolume):
+                        x = x.dense()
                     x, y1 = m(x), None
             else:
+                if isinstance(x, ops.ProjectedVolume):
+                    x = x.dense()
                 x, y1 = m(x), None
         return x
 
@@ -156,11 +160,11 @@ class Base_Backbone(Network):
     def _backbone_level1(self):
         cfg = self.cfg
         if cfg.USE_IMAGES and cfg.ONLY_IMAGES:
-            return self.color(self._imageft)
+            return self.color(self._image_input)
         if cfg.USE_IMAGES:
             # torch.cat([color, geometry], 1) (backbones.py:109): the last geometry Bottleneck writes its
             # channel range of the concatenated tensor directly (conv epilogue channel offset)
-            col = self.color(self._imageft)
+            col = self.color(self._image_input)
             cc, gc = col.shape[1], list(self.geometry1)[-1].conv3.out_channels
             l1 = ops.new_act(cc + gc, col.shape[2:], col.device)
             l1[:, :cc] = col

@@ -31,6 +31,24 @@ class Network(nn.Module):
         self._head_cache = {}
         self.batch_rpn = True             # both RPN k3 convs in one batched launch
         self.batch_masks = True           # mask head of all detected boxes as one ragged launch per layer
+        self.fuse_projection = True       # colour stem reads the views through a voxel->pixel table; no 226 MB volume
+        self._image_input = None
+        self._image_dense = self._image_dense_of = None
+
+    @property
+    def _imageft(self):
+        """network.py:239 `self._imageft`: the back-projected volume, logical (1,C,X,Y,Z).  With fuse_projection it is
+        only materialised when somebody asks for it."""
+        v = self._image_input
+        if isinstance(v, ops.ProjectedVolume):
+            if self._image_dense_of is not v:
+                self._image_dense, self._image_dense_of = v.dense(), v
+            return self._image_dense
+        return v
+
+    @_imageft.setter
+    def _imageft(self, value):
+        self._image_input = value
 
     # network.py:35-64
     def init_modules(self):
@@ -179,7 +197,8 @@ class Network(nn.Module):
                 feats = blobs["nearest_images"]["images"][0].to(dev, non_blocking=True)
                 p3 = blobs["proj_ind_3d"][0].to(dev, non_blocking=True)
                 p2 = blobs["proj_ind_2d"][0].to(dev, non_blocking=True)
-                imageft = ops.project_views_max(feats, p3, p2, self._scene_info, killing_inds or (), channels_last=True)
+                project = ops.project_views_prepare if self.fuse_projection else ops.project_views_max
+                imageft = project(feats, p3, p2, self._scene_info, killing_inds or ())
             d = self.detect(scene, imageft)
             # the only host sync of the detection path: number of surviving RoIs
             n = int(d["num"].item())

@@ -175,6 +175,41 @@ def project_views_max(feats, lin3d, lin2d, volume_dims, killing_inds=(), channel
     return out
 
 
+class ProjectedVolume(object):
+    """The back-projected image volume WITHOUT the volume: a voxel->pixel table per included view plus pixel-major
+    feature rows (sis3d_project_views_prepare).  Logical shape (1,C,X,Y,Z); `conv3d_chain` reads it directly
+    (sis3d_conv3d_chain_projected), `dense()` materialises the tensor `project_views_max` would have produced."""
+
+    def __init__(self, table, rows, nslots, C, npix, dims, src):
+        self.table, self.rows, self.nslots, self.C, self.npix, self.dims, self._src = table, rows, nslots, C, npix, tuple(dims), src
+        self.shape = (1, C) + self.dims
+        self.device = table.device
+
+    def dense(self, channels_last=True):
+        feats, a, b, kill = self._src
+        return project_views_max(feats, a, b, self.dims, kill, channels_last=channels_last)
+
+
+def project_views_prepare(feats, lin3d, lin2d, volume_dims, killing_inds=()):
+    """network.py:216-239 as (table, feature rows) -> ProjectedVolume; same arguments as project_views_max."""
+    feats = _dev(feats, "feats").contiguous()
+    a = _dev(lin3d, "proj_ind_3d", torch.int64).contiguous()
+    b = _dev(lin2d, "proj_ind_2d", torch.int64).contiguous()
+    X, Y, Z = (int(v) for v in volume_dims)
+    nvox = X * Y * Z
+    V = min(feats.shape[0], a.shape[0], b.shape[0])
+    C = feats.shape[1]
+    npix = feats.shape[2] * feats.shape[3]
+    kills = set(killing_inds or ())
+    kill = (ctypes.c_uint8 * V)(*[1 if k in kills else 0 for k in range(V)])
+    table = torch.empty(V, nvox, dtype=torch.int32, device=feats.device)
+    rows = torch.empty(V, npix, C, device=feats.device)
+    ns = ctypes.c_int(0)
+    check(lib().sis3d_project_views_prepare(_ptr(feats), V, C, npix, _ptr(a), _ptr(b), kill, nvox, _ptr(table), _ptr(rows),
+                                            ctypes.byref(ns), _stream()), "sis3d_project_views_prepare")
+    return ProjectedVolume(table, rows, ns.value, C, npix, (X, Y, Z), (feats, a, b, tuple(killing_inds or ())))
+
+
 VIEW_PARAM_FLOATS = 40
 
 
@@ -268,6 +303,8 @@ def is_cl(t):
 
 def to_cl(t):
     """any (1,C,X,Y,Z) float tensor -> channels-last memory (HIP transpose kernel when planar)."""
+    if isinstance(t, ProjectedVolume):
+        return t
     t = _dev(t, "activation")
     if is_cl(t):
         return t
@@ -361,7 +398,10 @@ def conv3d_chain(x, pc, stride, stages, relu=True, want_main=False):
     """Main conv (k3 / k2s2, + bias, ReLU) followed by fused 1x1x1 stages on the on-chip tile (sis3d_conv3d_chain).
     stages: list of dicts(pc=PackedConv(k=1), relu=bool, residual=tensor|None, keep=bool).  Returns
     (main_out | None, [stage outputs | None]).  Raises Sis3dUnsupported if no tiling can fuse this shape."""
-    if not is_cl(x):
+    proj = isinstance(x, ProjectedVolume)
+    if proj and (pc.k != 2 or stride != 2 or pc.cin != x.C):
+        raise Sis3dUnsupported("a projected volume feeds Conv3d(C, *, k=2, s=2) only")
+    if not proj and not is_cl(x):
         raise _lib.Sis3dError("conv3d_chain expects a channels-last activation")
     _, cin_t, X, Y, Z = x.shape
     od = (X // 2, Y // 2, Z // 2) if pc.k == 2 else (X, Y, Z)
@@ -396,8 +436,13 @@ def conv3d_chain(x, pc, stride, stages, relu=True, want_main=False):
         if spc.cin != cprev or spc.k != 1:
             raise _lib.Sis3dError("conv3d_chain: stage %d expects %d input channels, k=1" % (i, cprev))
         cprev = spc.cout
-    rc = lib().sis3d_conv3d_chain(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed), _ptr(pc.bias), pc.cout, pc.k, stride,
-                                  EPI_RELU if relu else 0, _ptr(main), pc.cout, len(stages), arr, _stream())
+    if proj:
+        rc = lib().sis3d_conv3d_chain_projected(_ptr(x.table), _ptr(x.rows), x.nslots, x.npix, X, Y, Z, pc.cin, _ptr(pc.packed),
+                                                _ptr(pc.bias), pc.cout, EPI_RELU if relu else 0, _ptr(main), pc.cout, len(stages),
+                                                arr, _stream())
+    else:
+        rc = lib().sis3d_conv3d_chain(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed), _ptr(pc.bias), pc.cout, pc.k, stride,
+                                      EPI_RELU if relu else 0, _ptr(main), pc.cout, len(stages), arr, _stream())
     if rc == -4:
         raise Sis3dUnsupported("no fused tiling for this shape")
     check(rc, "sis3d_conv3d_chain")

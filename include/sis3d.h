@@ -109,6 +109,17 @@ int sis3d_project_views_max(const float *feats, int V, int C, int64_t npix, cons
                             const uint8_t *kill_host, int X, int Y, int Z, float *out, int64_t os_c, int64_t os_x,
                             int64_t os_y, int64_t os_z, void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
 
+/* The same view max WITHOUT materialising the volume (226 MB at 128 ch x 96x48x96), for the colour
+ * stem: sis3d_project_views_prepare builds vox2pix [nslots][nvox] int32 (-1 = invisible; nslots =
+ * views not killed, returned through *nslots_out) and feat_rows [nslots][npix][C] (pixel-major);
+ * sis3d_conv3d_chain_projected (below) is Conv3d(C, cout, k=2, s=2) + fused stages reading its
+ * input voxels through that table: value(voxel, c) = max over slots of (visible ? row[c] : 0), and
+ * workgroups whose input brick holds no visible voxel skip the reduction (lib/nets/network.py:216-239
+ * + backbones.py color[0]).  Caller allocates vox2pix (V*nvox) and feat_rows (V*npix*C). */
+int sis3d_project_views_prepare(const float *feats, int V, int C, int64_t npix, const int64_t *lin3d, const int64_t *lin2d,
+                                const uint8_t *kill_host, int64_t nvox, int32_t *vox2pix, float *feat_rows, int *nslots_out,
+                                sis3d_stream_t stream);
+
 /* Replaces ProjectionHelper.compute_projection (lib/layer_utils/projection.py:52-121) and its
  * call sites' per-view loop (lib/model/trainval.py:336-337,464-465,663-667,799-803) for V views of
  * one volume.  depth [V][W*H]; view_params [V][SIS3D_VIEW_PARAM_FLOATS] = grid_to_world (16,
@@ -213,6 +224,11 @@ typedef struct sis3d_pw_stage {
 int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
                        int cout, int ksize, int stride, int flags, float *out, int out_stride, int nstages,
                        const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
+/* sis3d_conv3d_chain for Conv3d(cin, cout, k=2, s=2) whose input is a back-projected image volume given as
+ * (vox2pix, feat_rows) from sis3d_project_views_prepare instead of a tensor; X,Y,Z = volume dims, cin % 32 == 0. */
+int sis3d_conv3d_chain_projected(const int32_t *vox2pix, const float *feat_rows, int nslots, int64_t npix, int X, int Y, int Z,
+                                 int cin, const float *packed_w, const float *bias, int cout, int flags, float *out,
+                                 int out_stride, int nstages, const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
 
 /* nprob (<= 4) INDEPENDENT convolutions of identical shape in ONE launch (different input / weights / bias /
  * residual / output pointers; host arrays of device pointers, read at call time).  Used for the two RPN levels

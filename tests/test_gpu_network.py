@@ -204,3 +204,29 @@ def test_forward_from_depth_maps_vs_oracle(oracle, kill_view):
         k = "rpn_cls_prob_level%d" % lv
         assert (p[k].cpu() - o[k]).abs().max() <= TOL
     assert match_boxes(p["rois"][0].cpu(), o["rois"][0]) >= 0.9
+
+
+@pytest.mark.parametrize("n_per_view,kill", [(400, ()), (3000, (1,)), (0, ())])
+def test_fused_projection_equals_materialised_volume(oracle, n_per_view, kill):
+    """colour stem reading the views through the voxel->pixel table (no 226 MB volume, empty bricks skipped) ==
+    the same network on the materialised volume, bit for bit; and the lazily materialised `_imageft` is the oracle's."""
+    from sis3d import ops
+    dims = (96, 48, 96) if n_per_view == 3000 else (64, 32, 48)
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES = True
+    cfg.USE_MASK = False
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(6, dims)
+    feats, i3d, i2d = synthetic.synth_views(6, n_views=4, n_per_view=n_per_view, dims=dims)
+    outs = []
+    for fuse in (True, False):
+        net.fuse_projection = fuse
+        net.delete_intermediate_states()
+        p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", list(kill))
+        assert isinstance(net._image_input, ops.ProjectedVolume) == fuse
+        outs.append((net._net_conv[0].clone(), net._net_conv[1].clone(), p["rpn_cls_prob_level1"].clone(), p["rois"][0].clone(),
+                     net._imageft.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    want = oracle.project_views_max(feats, i3d, i2d, dims, kill)
+    assert torch.equal(outs[0][4].cpu(), want)
