@@ -15,8 +15,12 @@ RECORD_WIDTH = 10     # x1,y1,z1,x2,y2,z2, rpn score, level, class id, class pro
 
 
 class ChunkEngine:
-    def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None):
-        """stage: 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect' (+ proposals, RoI pooling, classifier)."""
+    def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False):
+        """stage: 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect' (+ proposals, RoI pooling, classifier).
+        from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
+        blobs['nearest_images'], lib/datasets/dataloader.py:17-38) and the voxel->pixel lists are computed inside the
+        captured graph (sis3d_compute_projection) instead of being loaded; `view_counts()` reports views that saw
+        nothing -- the caller's cue to take the reference's killing_inds route (layer_utils.projection.prepare_projection)."""
         self.net, self.dims, self.stage, self.use_graph = net, tuple(dims), stage, use_graph
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         cfg = net.cfg
@@ -29,6 +33,13 @@ class ChunkEngine:
             self.feats = torch.zeros(self.n_views, cfg.NUM_IMAGE_CHANNELS, h, w, device=self.device)
             self.i3d = torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device)
             self.i2d = torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device)
+            self.from_depth = bool(from_depth)
+            if self.from_depth:
+                from .layer_utils.projection import ProjectionHelper
+                self.helper = ProjectionHelper(cfg.INTRINSIC, cfg.PROJ_DEPTH_MIN, cfg.PROJ_DEPTH_MAX, cfg.DEPTH_SHAPE,
+                                               list(self.dims), cfg.VOXEL_SIZE)
+                self.depths = torch.zeros(self.n_views, h, w, device=self.device)
+                self.view_params = torch.zeros(self.n_views, ops.VIEW_PARAM_FLOATS, device=self.device)
         self.origin = torch.zeros(RECORD_WIDTH, device=self.device)   # chunk origin (x,y,z,x,y,z,0...) added to the boxes
         self.graph = None
         self.out = None
@@ -38,6 +49,10 @@ class ChunkEngine:
         net = self.net
         imageft = None
         if self.use_images:
+            if self.from_depth:
+                h = self.helper
+                ops.compute_projection(self.depths, self.view_params, self.dims, h.image_dims, h.intrinsic, h.depth_min,
+                                       h.depth_max, h.voxel_size, out=(self.i3d, self.i2d))
             project = ops.project_views_prepare if getattr(net, "fuse_projection", False) else ops.project_views_max
             imageft = project(self.feats, self.i3d, self.i2d, self.dims, ())
         if self.stage == "rpn":
@@ -96,6 +111,18 @@ class ChunkEngine:
             self._copy(self.feats, feats)
             self._copy(self.i3d, i3d)
             self._copy(self.i2d, i2d)
+
+    def load_views(self, data, feats, depths, poses, world2grid):
+        """from_depth engines: grid, feature maps, depth maps (V,h,w), camera_to_world and world_to_grid (V,4,4)"""
+        self._copy(self.scene, data)
+        self._copy(self.feats, feats)
+        self._copy(self.depths, depths)
+        rows = torch.stack([self.helper.view_params(poses[v], world2grid[v]) for v in range(self.n_views)])
+        self.view_params.copy_(rows)                      # 40 floats per view of host geometry; blocking (pageable source)
+
+    def view_counts(self):
+        """visible voxels per view of the last pass (host list; synchronises)"""
+        return self.i3d[:, 0].cpu().tolist()
 
     def run(self):
         """one pass over the chunk currently in the static buffers; returns the (static) output dict"""

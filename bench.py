@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=2, help="independent chunks in flight per GPU (HIP streams)")
+    ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
+                    "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -202,10 +204,16 @@ def main():
     else:
         stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
         nfl = max(1, args.inflight)
-        eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph)
+        from_depth = args.workload == "images" and args.from_depth
+        eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph, **({"from_depth": True} if from_depth else {}))
         for i in range(nfl):
             data = synthetic.synth_chunk(rank * nfl + i)
-            if args.workload == "images":
+            if from_depth:
+                feats = synthetic.synth_views(rank * nfl + i, n_per_view=0)[0]
+                depth, c2w, w2g = synthetic.synth_cameras(rank * nfl + i, feats.shape[0], voxel_size=cfg.VOXEL_SIZE)
+                with torch.cuda.stream(eng.streams[i]):
+                    eng.engines[i].load_views(data, feats, depth, c2w, w2g)
+            elif args.workload == "images":
                 feats, i3d, i2d = synthetic.synth_views(rank * nfl + i)
                 eng.load(i, data, feats, i3d, i2d)
             else:
@@ -223,6 +231,10 @@ def main():
         dt = time.perf_counter() - t0
         vox_per_step = world * nfl * VOXELS
         extra_cfg = {}
+        if from_depth:
+            torch.cuda.synchronize()
+            extra_cfg = {"views_from": "depth maps + poses (lists computed on device inside the step)",
+                         "visible_voxels_per_view": eng.engines[0].view_counts()}
         if rank == 0:
             # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose)
             torch.cuda.synchronize()

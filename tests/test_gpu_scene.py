@@ -56,3 +56,40 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
     assert float((d.min(1).values <= 1e-3).float().mean()) >= 0.9
     # boxes were shifted to scene coordinates
     assert float(recs[:, 3].max()) > dims[0] and float(recs[:, 5].max()) > dims[2]
+
+
+def test_engine_from_depth_maps_equals_loaded_lists(oracle):
+    """ChunkEngine(from_depth=True): lists computed inside the captured graph == lists loaded from the oracle's
+    compute_projection; same RPN maps bit for bit, and per-view counts are reported."""
+    from sis3d import config, synthetic
+    from sis3d.engine import ChunkEngine
+    from sis3d.nets import backbones
+    dims = (64, 32, 48)
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES = True
+    cfg.USE_MASK = False
+    net = getattr(backbones, cfg.NET)(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS))
+    net = net.cuda().eval()
+    V = 3
+    data = synthetic.synth_chunk(2, dims)
+    feats = torch.randn(V, 128, 32, 41, generator=torch.Generator().manual_seed(3))
+    depth, c2w, w2g = synthetic.synth_cameras(41, V, dims, cfg.VOXEL_SIZE)
+    maps = [oracle.compute_projection(depth[v], c2w[v], w2g[v], cfg.INTRINSIC, cfg.PROJ_DEPTH_MIN, cfg.PROJ_DEPTH_MAX,
+                                      cfg.DEPTH_SHAPE, dims, cfg.VOXEL_SIZE) for v in range(V)]
+    assert all(m is not None for m in maps)
+    i3d, i2d = torch.stack([m[0] for m in maps]), torch.stack([m[1] for m in maps])
+    a = ChunkEngine(net, dims=dims, stage="rpn", n_views=V, from_depth=True)
+    a.load_views(data, feats, depth, c2w, w2g)
+    a.prepare()
+    oa = {k: v.clone() for k, v in a.run().items()}
+    assert a.view_counts() == [int(m[0][0]) for m in maps]
+    assert torch.equal(a.i3d.cpu(), i3d) and torch.equal(a.i2d.cpu(), i2d)
+    b = ChunkEngine(net, dims=dims, stage="rpn", n_views=V)
+    b.load(data, feats, i3d, i2d)
+    b.prepare()
+    ob = b.run()
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
