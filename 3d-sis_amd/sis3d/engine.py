@@ -139,8 +139,9 @@ class PipelinedEngines:
 
     The layers of this network have only 216..1728 output tiles, so no single kernel fills the 256 CUs evenly
     (a 432-workgroup launch leaves 80 CUs one workgroup short) and every dependent kernel boundary drains the
-    chip.  Two captured graphs replaying on two streams fill each other's gaps: +22 % chunk throughput measured
-    (0.598 -> 0.491 ms per chunk, backbone+RPN).  More than 2 brings nothing further."""
+    chip.  Captured graphs replaying on separate streams fill each other's gaps: backbone+RPN 0.60 ms per chunk
+    alone, 0.466 with two, 0.449 with three in flight; the detect pass (long single-workgroup tail kernels) gains
+    11 % from the third stream; a fourth loses again."""
 
     def __init__(self, net, n=2, **kw):
         self.streams = [torch.cuda.Stream() for _ in range(n)]

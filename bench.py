@@ -5,7 +5,7 @@
 
 One process per GPU (for N>1 the driver launches this under torch.distributed.run; RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* come from the env).  A step = one pass of the hot path over one batch of
-`--inflight` (default 2) independent synthetic 96x48x96 chunks per rank, each on its own HIP stream / captured
+`--inflight` (default 3) independent synthetic 96x48x96 chunks per rank, each on its own HIP stream / captured
 graph, inputs already resident in HBM (static buffers of the ChunkEngine); weights
 are seeded synthetic (no checkpoints exist offline).  Chunks are independent, so ranks share nothing
 on the data path (scaling: weak); the per-scene proposal all-gather is exercised by `--workload scene`.
@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="independent chunks in flight per GPU (HIP streams)")
+    ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
+                    "measured best: 3")
     ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
                     "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,12 +181,14 @@ def main():
             torch.cuda.synchronize()
 
     single_ms = None
+    if args.inflight <= 0:
+        args.inflight = 3
     if args.workload == "scene":
         # BASELINE config 5: 32 chunks of one scene (4 x 1 x 8 grid of 96x48x96 tiles), chunk c -> rank c mod W, per-chunk
         # detection, ONE all-gather of the record blocks, whole-scene NMS on every rank.  A step = one whole scene.
         from sis3d.scene import SceneRunner
         n_chunks = 32
-        runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph)
+        runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph, inflight=args.inflight)
         chunks = []
         for c in range(n_chunks):
             payload = synthetic.synth_chunk(c).cuda() if c % world == rank else None     # resident in HBM, own shard only
