@@ -6,13 +6,14 @@
 // skipped, which is the -inf padding of the reference.
 #include "common.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
 // thread = (x, y, z-segment of ZSEG voxels, 4 channels): the 3x3 (x,y) column maxima of ZSEG+2 consecutive z are
 // computed once and reused by three outputs each -> 9*(ZSEG+2)/ZSEG loads per output instead of 27.  The maps of this
-// network are small (6912 voxels x 16..32 float4 channels), so the launcher trades that reuse for parallelism: the
-// largest ZSEG that still puts >= ~100k threads on the chip (ZSEG = 8 on a 24x12x24x128 map left 3/4 of the CUs idle).
+// network are small (6912 voxels x 16..32 float4 channels), so the launcher trades that reuse for parallelism
+// (ZSEG = 8 on a 24x12x24x128 map left 3/4 of the CUs idle): ZSEG 2 on maps with >= 200k (voxel, float4) pairs, else 1.
 template <int ZSEG>
 __global__ __launch_bounds__(256) void maxpool3_kernel(const float4 *__restrict__ in, int X, int Y, int Z, int C4,
                                                        float4 *__restrict__ out)
@@ -133,10 +134,14 @@ extern "C" int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4 *)in, X, Y, Z, C / 4, (float4 *)out);
         return sis3d_check_launch();
     };
-    const int64_t want = 100000;
-    if (threads(8) >= want) return go(maxpool3_kernel<8>, 8);
-    if (threads(4) >= want) return go(maxpool3_kernel<4>, 4);
-    if (threads(2) >= want) return go(maxpool3_kernel<2>, 2);
+    static const int force = [] { const char *e = getenv("SIS3D_POOL_ZSEG"); return e ? atoi(e) : 0; }();   // tuning hook
+    if (force == 8) return go(maxpool3_kernel<8>, 8);
+    if (force == 4) return go(maxpool3_kernel<4>, 4);
+    if (force == 2) return go(maxpool3_kernel<2>, 2);
+    if (force == 1) return go(maxpool3_kernel<1>, 1);
+    // measured (tools/pool_time.py): 48x24x48x64 map 27.6 / 24.4 / 25.3 / 33.6 us for ZSEG 1/2/4/8, 24x12x24x128 map
+    // 10.2 / 9.8 / 11.6 / 14.6 us, 24x12x24x64 map 7.6 / 8.9 / 11.0 / 14.6 us
+    if (threads(2) >= 200000) return go(maxpool3_kernel<2>, 2);
     return go(maxpool3_kernel<1>, 1);
 }
 
