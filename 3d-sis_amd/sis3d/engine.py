@@ -15,50 +15,62 @@ RECORD_WIDTH = 10     # x1,y1,z1,x2,y2,z2, rpn score, level, class id, class pro
 
 
 class ChunkEngine:
-    def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False):
+    def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1):
         """stage: 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect' (+ proposals, RoI pooling, classifier).
         from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
         blobs['nearest_images'], lib/datasets/dataloader.py:17-38) and the voxel->pixel lists are computed inside the
         captured graph (sis3d_compute_projection) instead of being loaded; `view_counts()` reports views that saw
-        nothing -- the caller's cue to take the reference's killing_inds route (layer_utils.projection.prepare_projection)."""
+        nothing -- the caller's cue to take the reference's killing_inds route (layer_utils.projection.prepare_projection).
+        group (1 or 2): chunks per captured graph.  With 2, the four 12-GFLOP RPN convs of the pair go out as one batched
+        launch (Network.backbone_rpn_group); slots are addressed by the `slot` argument of load / set_origin and `run()`
+        returns a list of per-chunk outputs."""
         self.net, self.dims, self.stage, self.use_graph = net, tuple(dims), stage, use_graph
         self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.group = int(group)
         cfg = net.cfg
-        self.scene = torch.zeros((1, 2) + self.dims, device=self.device)
+        G = self.group
+        self.scenes = [torch.zeros((1, 2) + self.dims, device=self.device) for _ in range(G)]
         self.use_images = bool(cfg.USE_IMAGES)
+        self.from_depth = False
         if self.use_images:
             nvox = self.dims[0] * self.dims[1] * self.dims[2]
             h, w = cfg.DEPTH_SHAPE[1], cfg.DEPTH_SHAPE[0]
             self.n_views = n_views or cfg.NUM_IMAGES
-            self.feats = torch.zeros(self.n_views, cfg.NUM_IMAGE_CHANNELS, h, w, device=self.device)
-            self.i3d = torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device)
-            self.i2d = torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device)
+            self.feats_ = [torch.zeros(self.n_views, cfg.NUM_IMAGE_CHANNELS, h, w, device=self.device) for _ in range(G)]
+            self.i3d_ = [torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device) for _ in range(G)]
+            self.i2d_ = [torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device) for _ in range(G)]
             self.from_depth = bool(from_depth)
             if self.from_depth:
                 from .layer_utils.projection import ProjectionHelper
                 self.helper = ProjectionHelper(cfg.INTRINSIC, cfg.PROJ_DEPTH_MIN, cfg.PROJ_DEPTH_MAX, cfg.DEPTH_SHAPE,
                                                list(self.dims), cfg.VOXEL_SIZE)
-                self.depths = torch.zeros(self.n_views, h, w, device=self.device)
-                self.view_params = torch.zeros(self.n_views, ops.VIEW_PARAM_FLOATS, device=self.device)
-        self.origin = torch.zeros(RECORD_WIDTH, device=self.device)   # chunk origin (x,y,z,x,y,z,0...) added to the boxes
+                self.depths_ = [torch.zeros(self.n_views, h, w, device=self.device) for _ in range(G)]
+                self.view_params_ = [torch.zeros(self.n_views, ops.VIEW_PARAM_FLOATS, device=self.device) for _ in range(G)]
+        # chunk origin (x,y,z,x,y,z,0...) added to the boxes
+        self.origins = [torch.zeros(RECORD_WIDTH, device=self.device) for _ in range(G)]
         self.graph = None
         self.out = None
         self.records = None
 
-    def _step(self):
-        net = self.net
-        imageft = None
-        if self.use_images:
-            if self.from_depth:
-                h = self.helper
-                ops.compute_projection(self.depths, self.view_params, self.dims, h.image_dims, h.intrinsic, h.depth_min,
-                                       h.depth_max, h.voxel_size, out=(self.i3d, self.i2d))
-            project = ops.project_views_prepare if getattr(net, "fuse_projection", False) else ops.project_views_max
-            imageft = project(self.feats, self.i3d, self.i2d, self.dims, ())
-        if self.stage == "rpn":
-            net.backbone_rpn(self.scene, imageft)
-            return {k: v for k, v in net._predictions.items() if k.startswith("rpn_")}
-        d = net.detect(self.scene, imageft)
+    # slot-0 views of the static buffers (the single-chunk API)
+    scene = property(lambda self: self.scenes[0])
+    feats = property(lambda self: self.feats_[0])
+    i3d = property(lambda self: self.i3d_[0])
+    i2d = property(lambda self: self.i2d_[0])
+    origin = property(lambda self: self.origins[0])
+
+    def _imageft(self, g):
+        if not self.use_images:
+            return None
+        if self.from_depth:
+            h = self.helper
+            ops.compute_projection(self.depths_[g], self.view_params_[g], self.dims, h.image_dims, h.intrinsic, h.depth_min,
+                                   h.depth_max, h.voxel_size, out=(self.i3d_[g], self.i2d_[g]))
+        project = ops.project_views_prepare if getattr(self.net, "fuse_projection", False) else ops.project_views_max
+        return project(self.feats_[g], self.i3d_[g], self.i2d_[g], self.dims, ())
+
+    def _finish(self, d, g):
+        """pack one chunk's detections: records + the fixed-size block in scene coordinates"""
         if "cls_pred" in d:
             conf = d["cls_prob"].gather(1, d["cls_pred"].view(-1, 1))[:, 0]
             rec = torch.cat([d["rois"], d["scores"].view(-1, 1), d["levels"].view(-1, 1),
@@ -71,8 +83,22 @@ class ChunkEngine:
         k = rec.shape[0]
         n = d["num"].to(rec.dtype).view(1)
         valid = (torch.arange(k, device=rec.device).to(rec.dtype) < n).view(-1, 1)
-        d["block"] = torch.cat([n, torch.where(valid, rec + self.origin, torch.zeros_like(rec)).reshape(-1)])
+        d["block"] = torch.cat([n, torch.where(valid, rec + self.origins[g], torch.zeros_like(rec)).reshape(-1)])
         return d
+
+    def _step(self):
+        net = self.net
+        if self.group == 1:
+            imageft = self._imageft(0)
+            if self.stage == "rpn":
+                net.backbone_rpn(self.scenes[0], imageft)
+                return {k: v for k, v in net._predictions.items() if k.startswith("rpn_")}
+            return self._finish(net.detect(self.scenes[0], imageft), 0)
+        fts = [self._imageft(g) for g in range(self.group)] if self.use_images else None
+        if self.stage == "rpn":
+            return [{k: v for k, v in pred.items() if k.startswith("rpn_")}
+                    for _, _, _, pred in net.backbone_rpn_group(self.scenes, fts)]
+        return [self._finish(d, g) for g, d in enumerate(net.detect_group(self.scenes, fts))]
 
     def prepare(self, warmup=2):
         """warm caches (weight repack, anchor tables) and capture the graph"""
@@ -100,32 +126,33 @@ class ChunkEngine:
         # the caller while an "async" staged copy is still reading it)
         dst.copy_(src, non_blocking=bool(src.is_cuda or src.is_pinned()))
 
-    def set_origin(self, origin):
+    def set_origin(self, origin, slot=0):
         """chunk origin in scene voxels (host tuple): written into the static buffer the captured graph reads"""
         o = torch.tensor([origin[0], origin[1], origin[2], origin[0], origin[1], origin[2]] + [0.0] * (RECORD_WIDTH - 6))
-        self.origin.copy_(o)
+        self.origins[slot].copy_(o)
 
-    def load(self, data, feats=None, i3d=None, i2d=None):
-        self._copy(self.scene, data)
+    def load(self, data, feats=None, i3d=None, i2d=None, slot=0):
+        self._copy(self.scenes[slot], data)
         if self.use_images:
-            self._copy(self.feats, feats)
-            self._copy(self.i3d, i3d)
-            self._copy(self.i2d, i2d)
+            self._copy(self.feats_[slot], feats)
+            self._copy(self.i3d_[slot], i3d)
+            self._copy(self.i2d_[slot], i2d)
 
-    def load_views(self, data, feats, depths, poses, world2grid):
+    def load_views(self, data, feats, depths, poses, world2grid, slot=0):
         """from_depth engines: grid, feature maps, depth maps (V,h,w), camera_to_world and world_to_grid (V,4,4)"""
-        self._copy(self.scene, data)
-        self._copy(self.feats, feats)
-        self._copy(self.depths, depths)
+        self._copy(self.scenes[slot], data)
+        self._copy(self.feats_[slot], feats)
+        self._copy(self.depths_[slot], depths)
         rows = torch.stack([self.helper.view_params(poses[v], world2grid[v]) for v in range(self.n_views)])
-        self.view_params.copy_(rows)                      # 40 floats per view of host geometry; blocking (pageable source)
+        self.view_params_[slot].copy_(rows)               # 40 floats per view of host geometry; blocking (pageable source)
 
-    def view_counts(self):
+    def view_counts(self, slot=0):
         """visible voxels per view of the last pass (host list; synchronises)"""
-        return self.i3d[:, 0].cpu().tolist()
+        return self.i3d_[slot][:, 0].cpu().tolist()
 
     def run(self):
-        """one pass over the chunk currently in the static buffers; returns the (static) output dict"""
+        """one pass over the chunk(s) currently in the static buffers; returns the (static) output dict (list of dicts
+        for group > 1)"""
         with torch.no_grad():
             if self.graph is not None:
                 self.graph.replay()
@@ -158,12 +185,12 @@ class PipelinedEngines:
         torch.cuda.synchronize()
         return self
 
-    def load(self, i, *a):
+    def load(self, i, *a, **kw):
         """copy a chunk (CPU or GPU tensors) into pipeline i's static buffers, on pipeline i's stream"""
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream())         # GPU inputs may still be in flight on the caller's stream
         with torch.cuda.stream(s):
-            self.engines[i].load(*a)
+            self.engines[i].load(*a, **kw)
         for t in a:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(s)                         # keep the allocator from recycling them under the copy

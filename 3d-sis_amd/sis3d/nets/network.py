@@ -161,6 +161,45 @@ class Network(nn.Module):
                 levels.append(self._rpn_level(2, l2))
         return l1, l2, levels
 
+    def backbone_rpn_group(self, scenes, imagefts=None):
+        """Several independent chunks in one pass: backbones one after the other, then ONE batched launch of all their RPN
+        k3 convs (2 chunks x 2 levels = 4 problems = 1728 workgroups = 6.75 per CU instead of 3.375: the 12-GFLOP convs are
+        where the CU-count quantisation costs most).  -> [(l1, l2, levels, predictions dict)] per chunk."""
+        cfg = self.cfg
+        n = len(scenes)
+        c1, c2 = self.rpn_net_level1, self.rpn_net_level2
+        feats = []
+        for i, sc in enumerate(scenes):
+            self._scene, self._scene_info = sc, sc.shape[2:]
+            if imagefts is not None:
+                self._imageft = imagefts[i]
+            l1 = self._backbone_level1()
+            feats.append((l1, self._backbone_level2(l1)))
+        if not (self.batch_rpn and 2 * n <= 4 and cfg.NUM_ANCHORS_LEVEL1 != 0 and cfg.NUM_ANCHORS_LEVEL2 != 0
+                and all(a.shape == b.shape == feats[0][0].shape for a, b in feats)):
+            raise ops.Sis3dUnsupported("grouped RPN launch needs <= 2 chunks of identical shape and both pyramid levels")
+        rs = ops.conv3d_batched([f for pair in feats for f in pair], [c1._packed.get(c1), c2._packed.get(c2)] * n, relu=True)
+        outs = []
+        for i, (l1, l2) in enumerate(feats):
+            self._scene, self._scene_info = scenes[i], scenes[i].shape[2:]
+            self._predictions = {}
+            self._net_conv = (l1, l2)
+            levels = [self._rpn_level(1, l1, rs[2 * i]), self._rpn_level(2, l2, rs[2 * i + 1])]
+            outs.append((l1, l2, levels, self._predictions))
+        return outs
+
+    def detect_group(self, scenes, imagefts=None):
+        """`detect` for a group of chunks sharing the batched RPN launch -> list of output dicts"""
+        res = []
+        for l1, l2, levels, pred in self.backbone_rpn_group(scenes, imagefts):
+            self._predictions = pred
+            self._prop = self._proposals.run(levels, self._scene_info[:3], "TEST")
+            out = dict(rois=self._prop["rois"], scores=self._prop["scores"], levels=self._prop["levels"], num=self._prop["num"])
+            if self.cfg.USE_CLASS:
+                out["cls_score"], out["cls_pred"], out["cls_prob"], out["bbox_pred"] = self._classify_rois(l1, l2)
+            res.append(out)
+        return res
+
     def detect(self, scene, imageft=None):
         """Device-only, fixed-shape, sync-free detection pass (graph-capturable): backbone -> RPN ->
         decode/sort/NMS -> two-level RoI pooling -> classifier, on K = RPN_POST_NMS_TOP_N padded rows.

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
                     "measured best: 3")
+    ap.add_argument("--group", type=int, default=1, help="chunks per captured graph (2: the pair's four RPN convs in one launch)")
     ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
                     "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,19 +209,22 @@ def main():
         stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
         nfl = max(1, args.inflight)
         from_depth = args.workload == "images" and args.from_depth
-        eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph, **({"from_depth": True} if from_depth else {}))
+        grp = max(1, args.group)
+        eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph, group=grp, **({"from_depth": True} if from_depth else {}))
         for i in range(nfl):
-            data = synthetic.synth_chunk(rank * nfl + i)
+          for g in range(grp):
+            cid = (rank * nfl + i) * grp + g
+            data = synthetic.synth_chunk(cid)
             if from_depth:
-                feats = synthetic.synth_views(rank * nfl + i, n_per_view=0)[0]
-                depth, c2w, w2g = synthetic.synth_cameras(rank * nfl + i, feats.shape[0], voxel_size=cfg.VOXEL_SIZE)
+                feats = synthetic.synth_views(cid, n_per_view=0)[0]
+                depth, c2w, w2g = synthetic.synth_cameras(cid, feats.shape[0], voxel_size=cfg.VOXEL_SIZE)
                 with torch.cuda.stream(eng.streams[i]):
-                    eng.engines[i].load_views(data, feats, depth, c2w, w2g)
+                    eng.engines[i].load_views(data, feats, depth, c2w, w2g, slot=g)
             elif args.workload == "images":
-                feats, i3d, i2d = synthetic.synth_views(rank * nfl + i)
-                eng.load(i, data, feats, i3d, i2d)
+                feats, i3d, i2d = synthetic.synth_views(cid)
+                eng.load(i, data, feats, i3d, i2d, slot=g)
             else:
-                eng.load(i, data)
+                eng.load(i, data, slot=g)
         eng.prepare(warmup=2)
         if dbg:
             print("[bench] prepared", file=sys.stderr, flush=True)
@@ -232,11 +236,11 @@ def main():
             eng.run()
         barrier()
         dt = time.perf_counter() - t0
-        vox_per_step = world * nfl * VOXELS
-        extra_cfg = {}
+        vox_per_step = world * nfl * grp * VOXELS
+        extra_cfg = {"chunks_per_graph": grp}
         if from_depth:
             torch.cuda.synchronize()
-            extra_cfg = {"views_from": "depth maps + poses (lists computed on device inside the step)",
+            extra_cfg = {"chunks_per_graph": grp, "views_from": "depth maps + poses (lists computed on device inside the step)",
                          "visible_voxels_per_view": eng.engines[0].view_counts()}
         if rank == 0:
             # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose)

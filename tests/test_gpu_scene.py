@@ -93,3 +93,37 @@ def test_engine_from_depth_maps_equals_loaded_lists(oracle):
     ob = b.run()
     for k in oa:
         assert torch.equal(oa[k], ob[k]), k
+
+
+@pytest.mark.parametrize("stage", ["rpn", "detect"])
+def test_grouped_engine_equals_single_chunk_engines(stage):
+    """ChunkEngine(group=2): two chunks per captured graph sharing ONE batched launch of their four RPN convs ==
+    two single-chunk engines, bit for bit"""
+    from sis3d import config, synthetic
+    from sis3d.engine import ChunkEngine
+    from sis3d.nets import backbones
+    dims = (64, 32, 48)
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_MASK = False
+    net = getattr(backbones, cfg.NET)(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS))
+    net = net.cuda().eval()
+    chunks = [synthetic.synth_chunk(c, dims) for c in (3, 4)]
+    pair = ChunkEngine(net, dims=dims, stage=stage, group=2)
+    for g, c in enumerate(chunks):
+        pair.load(c, slot=g)
+        pair.set_origin((10.0 * g, 0.0, 5.0), slot=g)
+    pair.prepare()
+    got = [{k: v.clone() for k, v in d.items() if torch.is_tensor(v)} for d in pair.run()]
+    for g, c in enumerate(chunks):
+        one = ChunkEngine(net, dims=dims, stage=stage)
+        one.load(c)
+        one.set_origin((10.0 * g, 0.0, 5.0))
+        one.prepare()
+        want = one.run()
+        keys = [k for k in got[g] if k in want]
+        assert keys and ("block" in keys or stage == "rpn")
+        for k in keys:
+            assert torch.equal(got[g][k], want[k]), (g, k)
