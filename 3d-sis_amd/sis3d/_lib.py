@@ -30,6 +30,7 @@ SIGNATURES = {
     "sis3d_tsdf_encode": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "sis3d_proposal_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_topk_desc": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "sis3d_pack_records": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     "sis3d_softmax2": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "sis3d_classifier_workspace_floats": (c_sz, [c_int, c_int, c_int]),
     "sis3d_classifier_forward": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp,

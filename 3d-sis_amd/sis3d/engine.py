@@ -11,7 +11,7 @@ import torch
 from . import ops
 from .synthetic import CHUNK_DIMS
 
-RECORD_WIDTH = 10     # x1,y1,z1,x2,y2,z2, rpn score, level, class id, class prob
+RECORD_WIDTH = ops.RECORD_WIDTH     # proposal box (6), rpn score, level, class id, class prob, class-regressed final box (6)
 
 
 class ChunkEngine:
@@ -46,8 +46,8 @@ class ChunkEngine:
                                                list(self.dims), cfg.VOXEL_SIZE)
                 self.depths_ = [torch.zeros(self.n_views, h, w, device=self.device) for _ in range(G)]
                 self.view_params_ = [torch.zeros(self.n_views, ops.VIEW_PARAM_FLOATS, device=self.device) for _ in range(G)]
-        # chunk origin (x,y,z,x,y,z,0...) added to the boxes
-        self.origins = [torch.zeros(RECORD_WIDTH, device=self.device) for _ in range(G)]
+        # chunk origin (x,y,z) in scene voxels, added to the boxes of the record block
+        self.origins = [torch.zeros(3, device=self.device) for _ in range(G)]
         self.graph = None
         self.out = None
         self.records = None
@@ -70,20 +70,8 @@ class ChunkEngine:
         return project(self.feats_[g], self.i3d_[g], self.i2d_[g], self.dims, ())
 
     def _finish(self, d, g):
-        """pack one chunk's detections: records + the fixed-size block in scene coordinates"""
-        if "cls_pred" in d:
-            conf = d["cls_prob"].gather(1, d["cls_pred"].view(-1, 1))[:, 0]
-            rec = torch.cat([d["rois"], d["scores"].view(-1, 1), d["levels"].view(-1, 1),
-                             d["cls_pred"].float().view(-1, 1), conf.view(-1, 1)], 1)
-        else:
-            z = torch.zeros_like(d["scores"]).view(-1, 1)
-            rec = torch.cat([d["rois"], d["scores"].view(-1, 1), d["levels"].view(-1, 1), z, z], 1)
-        d["records"] = rec
-        # fixed-size record block of this chunk in scene coordinates: [count, K x RECORD_WIDTH rows], rows >= count zeroed
-        k = rec.shape[0]
-        n = d["num"].to(rec.dtype).view(1)
-        valid = (torch.arange(k, device=rec.device).to(rec.dtype) < n).view(-1, 1)
-        d["block"] = torch.cat([n, torch.where(valid, rec + self.origins[g], torch.zeros_like(rec)).reshape(-1)])
+        """pack one chunk's detections: records + the fixed-size block in scene coordinates (one kernel)"""
+        d["records"], d["block"] = ops.pack_records(d, self.dims, self.origins[g])
         return d
 
     def _step(self):
@@ -128,8 +116,7 @@ class ChunkEngine:
 
     def set_origin(self, origin, slot=0):
         """chunk origin in scene voxels (host tuple): written into the static buffer the captured graph reads"""
-        o = torch.tensor([origin[0], origin[1], origin[2], origin[0], origin[1], origin[2]] + [0.0] * (RECORD_WIDTH - 6))
-        self.origins[slot].copy_(o)
+        self.origins[slot].copy_(torch.tensor([float(origin[0]), float(origin[1]), float(origin[2])]))
 
     def load(self, data, feats=None, i3d=None, i2d=None, slot=0):
         self._copy(self.scenes[slot], data)

@@ -266,6 +266,25 @@ def proposal_decode(anchors, deltas, prob_fg, inside, dims, level_id, out_boxes,
                                       _stream()), "sis3d_proposal_decode")
 
 
+RECORD_WIDTH = 16
+
+
+def pack_records(d, dims, origin=None, want_block=True):
+    """detect() output dict -> (records (K,16), block (1+16K) | None): sis3d_pack_records (include/sis3d.h)"""
+    rois = d["rois"].contiguous()
+    K = rois.shape[0]
+    rec = torch.empty(K, RECORD_WIDTH, device=rois.device)
+    blk = torch.empty(1 + K * RECORD_WIDTH, device=rois.device) if want_block else None
+    has = "cls_pred" in d
+    NC = d["cls_prob"].shape[1] if has else 0
+    check(lib().sis3d_pack_records(_ptr(rois), _ptr(d["scores"].contiguous()), _ptr(d["levels"].contiguous()),
+                                   _ptr(d["cls_pred"].contiguous()) if has else None, _ptr(d["cls_prob"].contiguous()) if has else None,
+                                   _ptr(d["bbox_pred"].contiguous()) if has else None, _ptr(d["num"]), _ptr(origin), K, NC,
+                                   float(dims[0]), float(dims[1]), float(dims[2]), _ptr(rec), _ptr(blk), _stream()),
+          "sis3d_pack_records")
+    return rec, blk
+
+
 def topk_desc(scores, k):
     """stable descending top-k of a 1-D score vector -> (scores_sorted (k,), order (k,) int64); k <= 1024"""
     scores = _dev(scores, "scores").contiguous()

@@ -30,8 +30,8 @@ def pack_block(records, num, origin):
     """records (K, RECORD_WIDTH) padded rows + num (tensor [1] or int) + chunk origin (x,y,z) in scene voxels
     -> flat float block [1 + K*W]: count, then rows with boxes shifted to scene coordinates.  No host sync."""
     k = records.shape[0]
-    off = torch.tensor([origin[0], origin[1], origin[2], origin[0], origin[1], origin[2]] + [0.0] * (RECORD_WIDTH - 6),
-                       dtype=records.dtype, device=records.device)
+    o3 = [float(origin[0]), float(origin[1]), float(origin[2])]
+    off = torch.tensor(o3 + o3 + [0.0] * 4 + o3 + o3, dtype=records.dtype, device=records.device)   # proposal box, ..., final box
     n = num.to(records.dtype).view(1) if isinstance(num, torch.Tensor) else torch.tensor([float(num)], dtype=records.dtype,
                                                                                         device=records.device)
     valid = (torch.arange(k, device=records.device).to(records.dtype) < n).view(-1, 1)
@@ -71,28 +71,72 @@ def gather_blocks(local_blocks, n_chunks, k_rows, group=None):
     return out
 
 
-def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0):
+def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_chunk_ids=False):
     """Whole-scene NMS over the gathered blocks.  Valid rows are taken in (chunk id, row) order and sorted by
     score with a STABLE descending sort, so ties break by (chunk, row) -- deterministic and rank-independent.
-    Returns (records_sorted (N,W), keep LongTensor) with keep indexing records_sorted."""
+    Returns (records_sorted (N,W), keep LongTensor) with keep indexing records_sorted
+    (+ the producing chunk id of every sorted record if with_chunk_ids)."""
     n_chunks = blocks.shape[0]
     counts = blocks[:, 0].round().long().clamp(0, k_rows)
     rows = blocks[:, 1:].reshape(n_chunks, k_rows, RECORD_WIDTH)
     valid = torch.arange(k_rows, device=blocks.device).view(1, -1) < counts.view(-1, 1)
     recs = rows[valid]                                            # (N, W) in (chunk,row) order
+    cids = torch.arange(n_chunks, device=blocks.device).view(-1, 1).expand(n_chunks, k_rows)[valid]
     if recs.shape[0] == 0:
-        return recs, torch.zeros(0, dtype=torch.long, device=blocks.device)
+        keep = torch.zeros(0, dtype=torch.long, device=blocks.device)
+        return (recs, keep, cids) if with_chunk_ids else (recs, keep)
     _, order = torch.sort(recs[:, score_col], descending=True, stable=True)
     recs = recs[order]
     keep = nms_fn(recs[:, :6].contiguous(), thresh)
     if max_keep > 0:
         keep = keep[:max_keep]
-    return recs, keep
+    return (recs, keep, cids[order]) if with_chunk_ids else (recs, keep)
 
 
-def infer_scene(chunks, detect_fn, nms_fn, k_rows, thresh, group=None, max_keep=0):
+def mask_windows_of(rows, origin, class_thresh):
+    """keep rule + integer crop windows of lib/model/trainval.py:702-712,742-745 for record rows (host tensors) of ONE
+    chunk: confidence > CLASS_THRESH and a box that does not collapse when rounded to voxels (Python round: half-to-even).
+    -> [(row position, (x0,y0,z0,x1,y1,z1) in CHUNK voxels, class id)]"""
+    out = []
+    for j, r in enumerate(rows.tolist()):
+        if not r[9] > class_thresh:
+            continue
+        w = [int(round(r[10 + k] - origin[k % 3])) for k in range(6)]
+        if w[0] >= w[3] or w[1] >= w[4] or w[2] >= w[5]:
+            continue
+        out.append((j, tuple(w), int(r[8])))
+    return out
+
+
+def scene_masks(recs, keep, chunk_ids, chunks, mask_fn, class_thresh, group=None):
+    """Instance masks of the detections that survived the whole-scene NMS, computed where the data lives: a detection
+    belongs to the chunk that produced it (its box is clipped to that chunk), so the owner rank of the chunk crops its own
+    grid -- no voxel data crosses ranks.  mask_fn(payload, windows, classes) -> list of binary masks.
+    Returns {position in `keep`: (window in SCENE voxels, mask)} for this rank's chunks only."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    kept = recs[keep].detach().cpu()
+    kcid = chunk_ids[keep].detach().cpu()
+    out = {}
+    for c in shard_chunks(len(chunks), rank, world):
+        pos = (kcid == c).nonzero().view(-1)
+        if pos.numel() == 0:
+            continue
+        origin = [float(v) for v in chunks[c][1]]
+        sel = mask_windows_of(kept[pos], origin, class_thresh)
+        if not sel:
+            continue
+        masks = mask_fn(chunks[c][2], [w for _, w, _ in sel], [k for _, _, k in sel])
+        oi = [int(round(v)) for v in origin]
+        for (j, w, _), m in zip(sel, masks):
+            out[int(pos[j])] = (tuple(w[k] + oi[k % 3] for k in range(6)), m)
+    return out
+
+
+def infer_scene(chunks, detect_fn, nms_fn, k_rows, thresh, group=None, max_keep=0, mask_fn=None, class_thresh=0.5):
     """chunks: list of (chunk_id, origin(x,y,z), payload) for ALL chunks of the scene (every rank sees the list;
-    only its own shard is touched).  detect_fn(payload) -> (records (K,W), num).  Returns (records, keep)."""
+    only its own shard is touched).  detect_fn(payload) -> (records (K,W), num).  Returns (records, keep), plus this
+    rank's share of the instance masks (scene_masks) when mask_fn is given."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_chunks = len(chunks)
@@ -104,4 +148,7 @@ def infer_scene(chunks, detect_fn, nms_fn, k_rows, thresh, group=None, max_keep=
         rec, num = detect_fn(payload)
         local.append(pack_block(rec, num, origin))
     blocks = gather_blocks(local, n_chunks, k_rows, group)
-    return merge_scene(blocks, k_rows, nms_fn, thresh, max_keep=max_keep)
+    if mask_fn is None:
+        return merge_scene(blocks, k_rows, nms_fn, thresh, max_keep=max_keep)
+    recs, keep, cids = merge_scene(blocks, k_rows, nms_fn, thresh, max_keep=max_keep, with_chunk_ids=True)
+    return recs, keep, scene_masks(recs, keep, cids, chunks, mask_fn, class_thresh, group)

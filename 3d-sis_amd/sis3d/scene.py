@@ -16,10 +16,20 @@ class SceneRunner:
         self.k_rows = int(net.cfg.TEST.RPN_POST_NMS_TOP_N)
         self.pipes = PipelinedEngines(net, inflight, dims=dims, stage="detect", use_graph=use_graph).prepare()
 
-    def infer(self, chunks, thresh=None, group=None, max_keep=0):
+    def mask_fn(self, payload, windows, classes):
+        """mask head of one chunk's surviving detections: one ragged launch per layer for all its boxes, then the predicted
+        class's channel thresholded at MASK_THRESH (lib/model/trainval.py:736-759) -> list of {0,1} float32 GPU tensors"""
+        data = payload[0] if isinstance(payload, (tuple, list)) else payload
+        scene = data.cuda().float()
+        with torch.no_grad():
+            preds = self.net.mask_backbone.forward_batched(scene, windows)
+        t = float(self.net.cfg.MASK_THRESH)
+        return [(p[0, k] >= t).float() for p, k in zip(preds, classes)]
+
+    def infer(self, chunks, thresh=None, group=None, max_keep=0, with_masks=False):
         """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d) or None)] for the whole scene (entries of other
-        ranks' chunks may carry None).  -> (records (N,10) sorted by score, keep LongTensor) on the GPU, identical on
-        every rank."""
+        ranks' chunks may carry None).  -> (records (N,16) sorted by score, keep LongTensor) on the GPU, identical on
+        every rank; with_masks adds this rank's {position in keep: (scene window, mask)} (parallel.scene_masks)."""
         thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -43,4 +53,8 @@ class SceneRunner:
                 local.append(blk)
             self.pipes.join()
             blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group)
-            return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep)
+            if not with_masks:
+                return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep)
+            recs, keep, cids = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, with_chunk_ids=True)
+            masks = parallel.scene_masks(recs, keep, cids, chunks, self.mask_fn, float(self.net.cfg.CLASS_THRESH), group)
+            return recs, keep, masks

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
                     "measured best: 3")
+    ap.add_argument("--masks", action="store_true", help="scene workload: also run the mask head on the detections that survive "
+                    "the whole-scene NMS (each on the chunk / rank that produced it)")
     ap.add_argument("--group", type=int, default=1, help="chunks per captured graph (2: the pair's four RPN convs in one launch)")
     ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
                     "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
@@ -196,15 +198,19 @@ def main():
             chunks.append((c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), payload))
         torch.cuda.synchronize()
         for _ in range(max(1, args.warmup // 10)):
-            recs, keep = runner.infer(chunks)
+            res = runner.infer(chunks, with_masks=args.masks)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            recs, keep = runner.infer(chunks)
+            res = runner.infer(chunks, with_masks=args.masks)
         barrier()
+        recs, keep = res[0], res[1]
         dt = time.perf_counter() - t0
         nfl, vox_per_step = 1, n_chunks * VOXELS
         extra_cfg = {"scene_chunks": n_chunks, "records": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel())}
+        if args.masks:
+            extra_cfg["masks_on_this_rank"] = len(res[2])
+            extra_cfg["mask_voxels_on_this_rank"] = int(sum(m.numel() for _, m in res[2].values()))
     else:
         stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
         nfl = max(1, args.inflight)

@@ -161,6 +161,17 @@ int sis3d_proposal_decode(const float *anchors, const float *deltas, const float
  * out_scores [k], out_idx [k] int64.  One launch (radix select + bitonic sort in LDS); k > n is clamped to n;
  * n > 40960 returns SIS3D_EUNSUPPORTED (the score vector is held in registers). */
 int sis3d_topk_desc(const float *scores, int n, int k, float *out_scores, int64_t *out_idx, sis3d_stream_t stream);
+/* One detection record per padded RoI row, SIS3D_RECORD_WIDTH floats: [0:6] proposal box, [6] RPN score, [7] pyramid
+ * level, [8] arg-max class, [9] its probability, [10:16] the class-specific regressed box clipped to the chunk --
+ * box_reg row of the predicted class -> bbox_transform_inv -> clip_boxes, lib/model/trainval.py:686-700 and
+ * lib/nets/network.py:285-294 (there on the host in numpy).  rois (K,6), scores/levels (K), cls_pred (K) int64,
+ * cls_prob (K,NC), bbox_pred (K,6NC) (the three may be NULL together: columns 8,9 = 0, 10:16 = proposal box), num int32[1],
+ * origin float[3] (may be NULL).  records (K,W) in chunk coordinates (may be NULL); block [1 + K*W] = count, then the rows
+ * shifted by `origin` to scene coordinates with rows >= count zeroed: the unit of the per-scene all-gather (may be NULL). */
+#define SIS3D_RECORD_WIDTH 16
+int sis3d_pack_records(const float *rois, const float *scores, const float *levels, const int64_t *cls_pred, const float *cls_prob,
+                       const float *bbox_pred, const int32_t *num, const float *origin, int K, int NC, float dim_x, float dim_y,
+                       float dim_z, float *records, float *block, sis3d_stream_t stream);
 /* softmax over dim 1 of (1,2,...) score maps (network.py:546): n = elements per class plane */
 int sis3d_softmax2(const float *score, float *prob, int64_t n, sis3d_stream_t stream);
 

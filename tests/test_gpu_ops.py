@@ -258,3 +258,36 @@ def test_topk_desc_matches_stable_sort(ops, n, k):
     kk = min(k, n)
     gs, go = ops.topk_desc(s.cuda(), k)
     assert torch.equal(go.cpu(), wo[:kk]) and torch.equal(gs.cpu(), ws[:kk])
+
+
+# ------------------------------------------------------------------------- record packing
+@pytest.mark.parametrize("num", [0, 1, 137, 200])
+def test_pack_records(ops, num):
+    """sis3d_pack_records == the torch glue it replaced (cat / gather / where) + the reference's host-side class-box decode"""
+    from sis3d.utils.bbox_transform import bbox_transform_inv, clip_boxes
+    g = torch.Generator().manual_seed(num)
+    K, NC, dims = 200, 19, (96.0, 48.0, 96.0)
+    lo = torch.rand(K, 3, generator=g) * torch.tensor([80.0, 40.0, 80.0])
+    rois = torch.cat([lo, lo + 2 + torch.rand(K, 3, generator=g) * 30], 1)
+    d = dict(rois=rois, scores=torch.rand(K, generator=g), levels=torch.randint(1, 3, (K,), generator=g).float(),
+             cls_pred=torch.randint(0, NC, (K,), generator=g), cls_prob=torch.rand(K, NC, generator=g),
+             bbox_pred=torch.randn(K, 6 * NC, generator=g) * 0.3, num=torch.tensor([num], dtype=torch.int32))
+    origin = torch.tensor([96.0, 0.0, 192.0])
+    rec, blk = ops.pack_records({k: dev(v) for k, v in d.items()}, dims, dev(origin))
+    rec, blk = rec.cpu(), blk.cpu()
+    conf = d["cls_prob"].gather(1, d["cls_pred"].view(-1, 1))
+    want10 = torch.cat([rois, d["scores"].view(-1, 1), d["levels"].view(-1, 1), d["cls_pred"].float().view(-1, 1), conf], 1)
+    assert torch.equal(rec[:, :10], want10)
+    reg = d["bbox_pred"].view(K, NC, 6)[torch.arange(K), d["cls_pred"]]
+    fb = clip_boxes(bbox_transform_inv(rois, reg), dims)
+    assert (rec[:, 10:] - fb).abs().max() <= 1e-4                       # expf vs torch exp: <= 2 ulp on boxes <= 96
+    assert blk.numel() == 1 + K * ops.RECORD_WIDTH and blk[0] == num
+    rows = blk[1:].view(K, ops.RECORD_WIDTH)
+    o3 = origin.tolist()
+    off = torch.tensor(o3 + o3 + [0.0] * 4 + o3 + o3)
+    assert torch.equal(rows[:num], rec[:num] + off) and not rows[num:].any()
+    # RPN-only engines (USE_CLASS off): class columns zero, final box = proposal box
+    d2 = {k: dev(v) for k, v in d.items() if k in ("rois", "scores", "levels", "num")}
+    rec2, _ = ops.pack_records(d2, dims, None, want_block=False)
+    rec2 = rec2.cpu()
+    assert torch.equal(rec2[:, :8], want10[:, :8]) and not rec2[:, 8:10].any() and torch.equal(rec2[:, 10:], rois)

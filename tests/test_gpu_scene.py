@@ -14,7 +14,6 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
     from sis3d.nets import backbones
     from sis3d.scene import SceneRunner
     cfg = config.scannet_benchmark_cfg()
-    cfg.USE_MASK = False
     net = backbones.ScanNet_Backbone(cfg=cfg)
     net.init_modules()
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -47,6 +46,7 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
         rec[:n, 7] = o["level_inds"][0]
         rec[:n, 8] = o["cls_pred"].float()
         rec[:n, 9] = o["cls_prob"].gather(1, o["cls_pred"].view(-1, 1))[:, 0]
+        rec[:n, 10:16] = torch.from_numpy(oracle.class_boxes(o, data.shape[2:]))
         return rec, n
     orecs, okeep = parallel.infer_scene(chunks, odetect, oracle.nms, cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH)
     # proposal sets agree up to near-tie reordering (fp32 logits differ by ~1e-6 between oneDNN and the MFMA kernel)
@@ -56,6 +56,25 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
     assert float((d.min(1).values <= 1e-3).float().mean()) >= 0.9
     # boxes were shifted to scene coordinates
     assert float(recs[:, 3].max()) > dims[0] and float(recs[:, 5].max()) > dims[2]
+    # class-regressed final boxes of the matched detections agree with the oracle's host-side decode
+    m = d.argmin(1)
+    ok = d.min(1).values <= 1e-3
+    fb_got, fb_want = recs[keep][:, 10:16].cpu()[m[ok]], orecs[okeep][:, 10:16][ok]
+    assert float((fb_got - fb_want).abs().max()) <= 5e-3
+
+    # ---- instance masks of the survivors, computed on the chunk that produced each detection
+    recs3, keep3, masks = runner.infer(chunks, with_masks=True)
+    assert torch.equal(recs3, recs) and torch.equal(keep3, keep)
+    kept = recs[keep].cpu()
+    assert 0 < len(masks) <= kept.shape[0]
+    for i, (w, mk) in masks.items():
+        r = kept[i]
+        assert r[9] > cfg.CLASS_THRESH and tuple(mk.shape) == (w[3] - w[0], w[4] - w[1], w[5] - w[2])
+        c = [c for c in chunks if c[1][0] <= w[0] < c[1][0] + dims[0] and c[1][2] <= w[2] < c[1][2] + dims[2]][0]
+        ox, oz = int(c[1][0]), int(c[1][2])
+        crop = c[2][0:1, :, w[0] - ox:w[3] - ox, w[1]:w[4], w[2] - oz:w[5] - oz]
+        want_m = (on.mask_backbone(crop)[0, int(r[8])] >= cfg.MASK_THRESH).float()
+        assert float((mk.cpu() != want_m).float().mean()) <= 0.01
 
 
 def test_engine_from_depth_maps_equals_loaded_lists(oracle):

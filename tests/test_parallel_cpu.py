@@ -34,7 +34,16 @@ def _fake_detect(payload):
     rec[:, 3:6] = lo + torch.rand(k, 3, generator=g) * 30 + 1
     rec[:, 6] = torch.rand(k, generator=g).round(decimals=1)     # coarse scores -> many ties across chunks
     rec[:, 7] = 1 + (cid % 2)
+    rec[:, 8] = torch.randint(1, 19, (k,), generator=g).float()                  # class id
+    rec[:, 9] = torch.rand(k, generator=g)                                       # class probability, both sides of 0.5
+    rec[:, 10:16] = rec[:, :6] + (torch.rand(k, 6, generator=g) - 0.5) * 4       # class-regressed box
+    rec[0, 13] = rec[0, 10] + 0.3                                                # collapses when rounded to voxels
     return rec, n
+
+
+def _fake_masks(payload, windows, classes):
+    """stands in for the mask head: a tensor determined by (chunk, window, class)"""
+    return [torch.full((w[3] - w[0], w[4] - w[1], w[5] - w[2]), float(100 * payload + k)) for w, k in zip(windows, classes)]
 
 
 def _chunks(n):
@@ -49,8 +58,8 @@ def _worker(rank, world, port, n_chunks, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sis3d import parallel
     import sis3d_oracle as orc
-    recs, keep = parallel.infer_scene(_chunks(n_chunks), _fake_detect, orc.nms, 12, 0.1)
-    torch.save((recs, keep), os.path.join(out_dir, "r%d.pt" % rank))
+    recs, keep, masks = parallel.infer_scene(_chunks(n_chunks), _fake_detect, orc.nms, 12, 0.1, mask_fn=_fake_masks)
+    torch.save((recs, keep, masks), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,14 +67,29 @@ def _worker(rank, world, port, n_chunks, out_dir):
 @pytest.mark.parametrize("world,n_chunks", [(2, 8), (2, 5), (3, 7)])
 def test_sharded_scene_equals_single_process(tmp_path, world, n_chunks, oracle):
     from sis3d import parallel
-    want_recs, want_keep = parallel.infer_scene(_chunks(n_chunks), _fake_detect, oracle.nms, 12, 0.1)
+    want_recs, want_keep, want_masks = parallel.infer_scene(_chunks(n_chunks), _fake_detect, oracle.nms, 12, 0.1,
+                                                            mask_fn=_fake_masks)
     assert want_recs.shape[0] == sum(5 + c % 7 for c in range(n_chunks))
+    # single process: exactly the confident, non-degenerate survivors carry a mask, cropped in scene coordinates
+    kept = want_recs[want_keep]
+    assert 0 < len(want_masks) < kept.shape[0] and set(want_masks) <= set(range(kept.shape[0]))
+    for i, (w, m) in want_masks.items():
+        assert tuple(m.shape) == (w[3] - w[0], w[4] - w[1], w[5] - w[2]) and kept[i, 9] > 0.5
+        assert float(m.flatten()[0]) % 100 == kept[i, 8]
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_chunks, str(tmp_path)), nprocs=world, join=True)
+    union = {}
     for r in range(world):
-        recs, keep = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        recs, keep, masks = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert torch.equal(recs, want_recs), r
         assert torch.equal(keep, want_keep), r
+        assert not set(masks) & set(union)                         # every detection is masked by exactly one rank
+        for i, (w, m) in masks.items():
+            assert int(float(m.flatten()[0])) // 100 % world == r   # ... the owner of the chunk that produced it
+        union.update(masks)
+    assert set(union) == set(want_masks)
+    for i in union:
+        assert union[i][0] == want_masks[i][0] and torch.equal(union[i][1], want_masks[i][1])
 
 
 def test_pack_and_merge_rules(oracle):
