@@ -23,10 +23,18 @@ from ..utils.bbox_transform import bbox_transform_inv, clip_boxes
 def final_detections(predictions, scene_info, cfg):
     """trainval.py:686-712: per-RoI class pick, box regression of that class, keep rule.
     -> pred_class int64 (R,), pred_conf float64 (R,), pred_box float32 (R,6), keep list[bool]."""
-    pred_class = predictions["cls_pred"].detach().cpu().numpy()
-    rois = predictions["rois"][0].detach().cpu()
-    reg_all = predictions["bbox_pred"].detach().cpu().numpy()
-    prob_all = predictions["cls_prob"].detach().cpu().numpy()
+    cls_t, rois_t = predictions["cls_pred"].detach(), predictions["rois"][0].detach()
+    reg_t, prob_t = predictions["bbox_pred"].detach(), predictions["cls_prob"].detach()
+    if cls_t.is_cuda and cls_t.shape[0] > 0:
+        # one D2H instead of four (each is a stream sync): class ids ride along as exact small floats
+        nc = prob_t.shape[1]
+        host = torch.cat([rois_t.float(), reg_t.float(), prob_t.float(), cls_t.view(-1, 1).float()], 1).cpu()
+        rois_t, reg_t, prob_t = host[:, :6], host[:, 6:6 + 6 * nc], host[:, 6 + 6 * nc:6 + 7 * nc]
+        cls_t = host[:, -1].long()
+    pred_class = cls_t.cpu().numpy()
+    rois = rois_t.cpu().contiguous()
+    reg_all = reg_t.cpu().numpy()
+    prob_all = prob_t.cpu().numpy()
     R = pred_class.shape[0]
     rows = np.arange(R)
     cols = pred_class[:, None] * 6 + np.arange(6)[None, :]

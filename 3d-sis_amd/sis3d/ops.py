@@ -589,30 +589,35 @@ def mask_head_batched(scene, windows, w0, pcs, pc_last, sigmoid=True):
     check(lib().sis3d_ragged_tiling(C, C, 3, ctypes.byref(bx), ctypes.byref(by), ctypes.byref(bz), ctypes.byref(ng)), "sis3d_ragged_tiling")
     bx, by, bz, ng = bx.value, by.value, bz.value, ng.value
     rdt, pdt = _rag_dtypes()
+    w = np.asarray(windows, dtype=np.int64).reshape(n, 6)
+    ext = w[:, 3:] - w[:, :3]                                     # (n,3) crop sizes
+    nbk = -(-ext // np.array([bx, by, bz]))                       # bricks per axis
+    nvox = ext.prod(1)
+    voffs = np.concatenate([[0], np.cumsum(nvox)])                # voxel offset of every crop in the packed buffers
+    blks = np.concatenate([[0], np.cumsum(nbk.prod(1) * ng)])
     d3 = np.zeros(n, dtype=rdt)
     d1 = np.zeros(n, dtype=rdt)
     dp = np.zeros(n, dtype=pdt)
-    voff = blk = t0 = 0
-    dims = []
-    for i, (x0, y0, z0, x1, y1, z1) in enumerate(windows):
-        dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
-        dims.append((dx, dy, dz))
-        nb = (-(-dx // bx), -(-dy // by), -(-dz // bz))
-        for d, ostr in ((d3, C), (d1, NC)):
-            d["X"][i], d["Y"][i], d["Z"][i] = dx, dy, dz
-            d["nbx"][i], d["nby"][i], d["nbz"][i] = nb
-            d["block0"][i] = blk
-            d["in_off"][i] = voff * C
-            d["out_off"][i] = voff * ostr
-        dp["x0"][i], dp["y0"][i], dp["z0"][i] = x0, y0, z0
-        dp["dx"][i], dp["dy"][i], dp["dz"][i] = dx, dy, dz
-        dp["t0"][i] = t0
-        dp["out_off"][i] = voff * C
-        voff += dx * dy * dz
-        blk += nb[0] * nb[1] * nb[2] * ng
-        t0 += dx * dy * dz * (C // 4)
-    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
-    g3, g1, gp = up(d3), up(d1), up(dp)
+    for d, ostr in ((d3, C), (d1, NC)):
+        d["X"], d["Y"], d["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
+        d["nbx"], d["nby"], d["nbz"] = nbk[:, 0], nbk[:, 1], nbk[:, 2]
+        d["block0"] = blks[:-1]
+        d["in_off"] = voffs[:-1] * C
+        d["out_off"] = voffs[:-1] * ostr
+    dp["x0"], dp["y0"], dp["z0"] = w[:, 0], w[:, 1], w[:, 2]
+    dp["dx"], dp["dy"], dp["dz"] = ext[:, 0], ext[:, 1], ext[:, 2]
+    dp["t0"] = voffs[:-1] * (C // 4)
+    dp["out_off"] = voffs[:-1] * C
+    voff, blk, t0 = int(voffs[-1]), int(blks[-1]), int(voffs[-1]) * (C // 4)
+    dims = [tuple(int(v) for v in e) for e in ext]
+    # ONE upload for the three descriptor tables (each is a blocking pageable copy)
+    parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1)]
+    pad = [(-p.size) % 16 for p in parts]
+    host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
+    devbuf = torch.from_numpy(host).to(dev)
+    o1 = parts[0].size + pad[0]
+    o2 = o1 + parts[1].size + pad[1]
+    g3, g1, gp = devbuf[:o1], devbuf[o1:o2], devbuf[o2:]
     a = torch.empty(voff, C, device=dev)
     b = torch.empty(voff, C, device=dev)
     out = torch.empty(voff, NC, device=dev)
