@@ -161,6 +161,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
     use_dist = world > 1 or bool(os.environ.get("SIS3D_FORCE_DIST"))     # FORCE: exercise the RCCL path on one GPU
+    if world > 1:
+        # N ranks share one host: keep each rank's torch-CPU helpers (synthetic inputs, weight init) from spawning a thread
+        # per core each; the timed path is GPU-only
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -19,5 +19,8 @@ for wl in backbone_rpn detect images; do
   run rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python "$ROOT/bench.py" --workload $wl --steps 100 --warmup 10 --no-cpu-baseline > /tmp/prof_$wl.log 2>&1
   f=$(find /tmp/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/bench_${wl}_kernel_stats.csv"
+  t=$(find /tmp/prof_$wl -name "*kernel_trace.csv" | head -1)
+  # the stats row of the dominant kernel's template mixes three layers (216 / 432 / 864 workgroups); split the trace by grid
+  [ -n "$t" ] && [ "$wl" = backbone_rpn ] && python "$ROOT/tools/dominant_from_trace.py" "$t" > "$OUT/dominant_kernel_from_trace.json"
 done
 for f in "$OUT"/bench_*.json; do echo "$(basename $f): $(cut -c1-160 $f)"; done
