@@ -61,12 +61,12 @@ def parse():
     return ap.parse_args()
 
 
-def build_net(workload):
+def build_net(workload, masks=False):
     from sis3d import config, synthetic
     from sis3d.nets import backbones
     cfg = config.scannet_benchmark_cfg()
     cfg.USE_IMAGES = workload == "images"
-    cfg.USE_MASK = False
+    cfg.USE_MASK = bool(masks)
     net = backbones.ScanNet_Backbone(cfg=cfg)
     net.init_modules()
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -177,7 +177,7 @@ def main():
     from sis3d import synthetic, ops
     from sis3d.engine import PipelinedEngines
     ops.lib()
-    net, cfg, sd = build_net(args.workload)
+    net, cfg, sd = build_net(args.workload, masks=args.masks)
     kt = time_dominant_kernel(net) if rank == 0 else 0.0
     dbg = bool(os.environ.get("SIS3D_BENCH_DEBUG"))
 
