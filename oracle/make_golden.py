@@ -120,7 +120,7 @@ def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3)
         return r
     net._backbone = grab
     p = rh.forward(ns, net, rh.make_blobs(data, feats, i3d, i2d))
-    out = dict(dims=np.array(dims), chunk_id=np.array(chunk_id), n_views=np.array(n_views), n_per_view=np.array(n_per_view),
+    out = dict(num_classes=np.array(int(ns.cfg.NUM_CLASSES)), dims=np.array(dims), chunk_id=np.array(chunk_id), n_views=np.array(n_views), n_per_view=np.array(n_per_view),
                sub=np.array(sub), shapes_keys=np.array(sorted(shapes.keys())),
                level1_sub=grabbed["l1"][0, :, ::sub, ::sub, ::sub].numpy(), level2_sub=grabbed["l2"][0, :, ::sub, ::sub, ::sub].numpy(),
                level1_sha=np.array(sha(grabbed["l1"].numpy())), level2_sha=np.array(sha(grabbed["l2"].numpy())))
@@ -272,6 +272,17 @@ def dataset_case(ns_unused):
     np.savez_compressed(os.path.join(OUT, "dataset_cases.npz"), **out)
 
 
+def suncg_case():
+    """second model family (SUNCG_Backbone, experiments/cfgs/SUNCG/rpn_class_mask_5.yml: colour + geometry, 3 / 6 anchors,
+    its own label map).  Run in a SUBPROCESS: the reference's cfg is a process-wide singleton."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.argv=['x']; import make_golden as mg, ref_harness as rh; "
+            "ns = rh.install('experiments/cfgs/SUNCG/rpn_class_mask_5.yml'); "
+            "print('SUNCG NUM_CLASSES', ns.cfg.NUM_CLASSES, flush=True); "
+            "mg.e2e(ns, 'e2e_suncg_small', True, (64, 32, 48), 3, n_views=3, n_per_view=400, sub=2)" % HERE)
+    subprocess.check_call([sys.executable, "-c", code])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
@@ -287,6 +298,7 @@ def main():
     e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)
     e2e(ns, "e2e_geometry_small", False, (64, 32, 48), 1, sub=2)
     e2e(ns, "e2e_images_small", True, (64, 32, 48), 2, n_views=3, n_per_view=400, sub=2)
+    suncg_case()
 
 
 if __name__ == "__main__":
