@@ -102,8 +102,12 @@ def anchors_case(ns):
     print("anchors", f1.shape, f2.shape)
 
 
-def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3):
-    net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=True)
+def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3, only_images=False):
+    ns.cfg.ONLY_IMAGES = bool(only_images)
+    try:
+        net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=True)
+    finally:
+        pass
     shapes = {k: v.shape for k, v in net.state_dict().items()}
     sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
     net.load_state_dict(sd)
@@ -144,6 +148,7 @@ def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3)
         out["imageft_nz_xyz"] = nz.numpy().astype(np.int32)
         out["imageft_nz_val"] = ift[0][:, nz[:, 0], nz[:, 1], nz[:, 2]].numpy()
         out["imageft_stride"] = np.array(ift.stride())
+    ns.cfg.ONLY_IMAGES = False
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "R=%d" % out["rois"].shape[0], "masks=%d" % len(masks),
           "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
@@ -298,6 +303,7 @@ def main():
     e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)
     e2e(ns, "e2e_geometry_small", False, (64, 32, 48), 1, sub=2)
     e2e(ns, "e2e_images_small", True, (64, 32, 48), 2, n_views=3, n_per_view=400, sub=2)
+    e2e(ns, "e2e_only_images_small", True, (64, 32, 48), 4, n_views=3, n_per_view=400, sub=2, only_images=True)
     suncg_case()
 
 

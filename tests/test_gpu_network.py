@@ -39,12 +39,13 @@ def match_boxes(got, want, tol=1e-3):
 
 
 @pytest.mark.parametrize("name,use_images", [("e2e_geometry_small", False), ("e2e_images_small", True),
-                                             ("e2e_geometry_full", False), ("e2e_suncg_small", True)])
+                                             ("e2e_geometry_full", False), ("e2e_suncg_small", True), ("e2e_only_images_small", True)])
 def test_forward_vs_oracle_and_golden(oracle, golden, name, use_images):
     g = golden(name)
     dims = tuple(int(v) for v in g["dims"])
     cfg = config.suncg_cfg() if "suncg" in name else config.scannet_benchmark_cfg()    # SUNCG_Backbone: 64-wide stems, 3/6 anchors, 26 classes
     cfg.USE_IMAGES = use_images
+    cfg.ONLY_IMAGES = "only_images" in name                   # colour branch alone feeds level 1 (backbones.py:99-101)
     net, sd = build(cfg)
     data = synthetic.synth_chunk(int(g["chunk_id"]), dims)
     feats = i3d = i2d = None

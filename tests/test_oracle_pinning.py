@@ -144,13 +144,14 @@ def _shapes_from_golden(g):
 
 
 @pytest.mark.parametrize("name,use_images", [("e2e_geometry_small", False), ("e2e_images_small", True),
-                                             ("e2e_geometry_full", False), ("e2e_suncg_small", True)])
+                                             ("e2e_geometry_full", False), ("e2e_suncg_small", True), ("e2e_only_images_small", True)])
 def test_forward_matches_reference_golden(golden, oracle, name, use_images):
     from sis3d.nets.backbones import state_dict_shapes
     g = golden(name)
     dims = tuple(int(v) for v in g["dims"])
     c = config.suncg_cfg() if "suncg" in name else config.scannet_benchmark_cfg()     # second model family: SUNCG_Backbone
     c.USE_IMAGES = use_images
+    c.ONLY_IMAGES = "only_images" in name                      # colour branch alone feeds level 1 (backbones.py:99-101)
     if "num_classes" in g.files:
         assert c.NUM_CLASSES == int(g["num_classes"])
     shapes = state_dict_shapes(c)
