@@ -231,3 +231,46 @@ def test_fused_projection_equals_materialised_volume(oracle, n_per_view, kill):
         assert torch.equal(a, b)
     want = oracle.project_views_max(feats, i3d, i2d, dims, kill)
     assert torch.equal(outs[0][4].cpu(), want)
+
+
+@pytest.mark.parametrize("switch", ["no_class", "level1_only", "level2_only", "sort_fallback", "allow_border"])
+def test_forward_config_switches(oracle, switch):
+    """cfg switches that change the TEST forward (lib/nets/network.py:241-282, proposal_layer.py:36-43,181-197): RPN-only,
+    single pyramid level, > 1024 pre-NMS candidates (torch.sort instead of the top-k kernel), anchors allowed over the border"""
+    dims = (64, 32, 48)
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_MASK = False
+    if switch == "no_class":
+        cfg.USE_CLASS = False
+    elif switch == "level1_only":
+        cfg.NUM_ANCHORS_LEVEL2 = 0
+    elif switch == "level2_only":
+        cfg.NUM_ANCHORS_LEVEL1 = 0
+    elif switch == "sort_fallback":
+        cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 2000, 300
+    elif switch == "allow_border":
+        cfg.ALLOW_BORDER = 8
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(8, dims)
+    p = net.forward(blobs_for(data), "TEST", [])
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data)
+    for lv in (1, 2):
+        k = "rpn_cls_prob_level%d" % lv
+        assert (k in p) == (k in o)
+        if k in o:
+            assert (p[k].cpu() - o[k]).abs().max() <= TOL
+    rois, want = p["rois"][0].cpu(), o["rois"][0]
+    assert want.shape[0] > 0 and abs(rois.shape[0] - want.shape[0]) <= max(3, want.shape[0] // 10)
+    assert match_boxes(rois, want) >= 0.9
+    lv_got = set(p["level_inds"][0].cpu().tolist())
+    assert lv_got <= set(o["level_inds"][0].tolist()) | {1.0, 2.0}
+    if switch == "level1_only":
+        assert lv_got == {1.0}
+    if switch == "level2_only":
+        assert lv_got == {2.0}
+    if switch == "no_class":
+        assert "cls_prob" not in p and "cls_prob" not in o
+    else:
+        assert p["cls_prob"].shape == o["cls_prob"].shape
+    if switch == "sort_fallback":
+        assert want.shape[0] > 200 or rois.shape[0] <= 300
