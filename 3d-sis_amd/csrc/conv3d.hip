@@ -582,6 +582,9 @@ int dispatch(ConvArgs &a, hipStream_t st)
         }
         if (big) {
             if (a.ntiles >= 2) return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 2, 32>(a, st);
+            static const int vbig = [] { const char *e = getenv("SIS3D_K3BIG_VARIANT"); return e ? atoi(e) : 0; }();   // tuning hook
+            if (vbig == 1) return launch_cfg<3, 1, 4, 4, 4, 2, 1, 3, 1, 32>(a, st);      // 64-voxel bricks, 6 waves, 864 workgroups
+            if (vbig == 2) return launch_cfg<3, 1, 2, 4, 4, 1, 1, 3, 1, 32>(a, st);      // 32-voxel bricks, 3 waves, 1728 workgroups
             return launch_cfg<3, 1, 4, 4, 8, 4, 1, 3, 1, 32, 12>(a, st);
         }
         // tuning hook (tools/conv_tune.py): SIS3D_K3_VARIANT selects an alternative tiling for the small-volume k3 layers

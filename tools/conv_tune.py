@@ -43,8 +43,37 @@ def bench_batched():
     print("rpn_x2 batched  %8.1f us  %6.1f TF" % (us, 2 * 2.0 * 6912 * 256 * 128 * 27 / us / 1e6))
 
 
+def bench_bottlenecks():
+    """the fused launches of the backbone: two Bottlenecks as FusedSequential (conv1 | conv2+conv3+res+next conv1 | ...)"""
+    from sis3d.nets import backbones as bb
+    for tag, planes_in, planes, dims in (("g1 32/32 @48x24x48", 32, 32, (48, 24, 48)), ("g1 128/32 @24x12x24", 128, 32, (24, 12, 24)),
+                                         ("g2 128/64 @24x12x24", 128, 64, (24, 12, 24))):
+        seq = bb.FusedSequential(bb.Bottleneck(planes_in, planes), bb.Bottleneck(planes_in, planes)).cuda().eval()
+        x = ops.new_act(planes_in, dims, torch.device("cuda")).normal_()
+        with torch.no_grad():
+            for _ in range(3):
+                seq(x)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(20):
+                    seq(x)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        print("bneck x2 %-22s big=%s small=%s  %8.1f us per pair" % (tag, os.environ.get("SIS3D_K3BIG_VARIANT", "0"),
+                                                                  os.environ.get("SIS3D_K3_VARIANT", "0"), e0.elapsed_time(e1) / 20 * 1e3))
+
+
 def main():
     names = sys.argv[1:] or list(LAYERS)
+    if "bneck" in names:
+        names.remove("bneck")
+        bench_bottlenecks()
     if "rpn_x2" in names:
         names.remove("rpn_x2")
         bench_batched()
