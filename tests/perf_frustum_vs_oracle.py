@@ -1,4 +1,5 @@
-"""time the device compute_projection (5 views, chunk + whole-scene grids) against the torch-CPU oracle"""
+"""Not a test (not collected): times the device compute_projection (5 views, chunk + whole-scene grids) beside the torch-CPU
+oracle.  Lives under tests/ because it executes the oracle, which only tests / smoke() / bench's cpu_baseline may do."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
