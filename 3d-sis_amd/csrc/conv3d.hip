@@ -353,10 +353,7 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
                     continue;
                 }
                 if (!inside || !p_out) continue;
-                if (false) {
-                } else {
-                    p_out[vox * a.out_stride + a.out_coff + co] = v;
-                }
+                p_out[vox * a.out_stride + a.out_coff + co] = v;
             }
         }
     }
@@ -427,27 +424,30 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 }
 
 // ---- first layers on the planar 2-channel grid (VALU: K = 16 / 54 is too thin for the matrix pipe) ------
-// thread = (output voxel, 4 consecutive couts); weights transposed into LDS as [ci*T+tap][cout]
+// thread = (output voxel, 16 consecutive couts): each of the 2*KS^3 input taps is loaded once per 16 outputs; weights
+// transposed into LDS as [ci*T+tap][cout]
 template <int KS, int S>
 __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restrict__ in, int64_t is_c, int64_t is_x, int64_t is_y,
                                                            int x0, int y0, int z0, int WX, int WY, int WZ, int OX, int OY, int OZ,
                                                            const float *__restrict__ w, int cout, int flags,
                                                            float *__restrict__ out, int out_stride)
 {
-    constexpr int T = KS * KS * KS, PAD = (KS == 3) ? 1 : 0, K = 2 * T;
+    constexpr int T = KS * KS * KS, PAD = (KS == 3) ? 1 : 0, K = 2 * T, CPT = 16;
     extern __shared__ __attribute__((aligned(16))) float wl[];     // [K][cout]
     for (int i = threadIdx.x; i < K * cout; i += blockDim.x) {
         const int co = i % cout, k = i / cout;                     // k = ci*T + tap
         wl[i] = w[(int64_t)co * K + k];
     }
     __syncthreads();
-    const int cq = cout / 4;
-    const int64_t total = (int64_t)OX * OY * OZ * cq;
+    const int cg = (cout + CPT - 1) / CPT;
+    const int64_t total = (int64_t)OX * OY * OZ * cg;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(t % cq) * 4;
-        const int64_t v = t / cq;
+        const int c0 = (int)(t % cg) * CPT;
+        const int64_t v = t / cg;
         const int oz = (int)(v % OZ), oy = (int)((v / OZ) % OY), ox = (int)(v / ((int64_t)OZ * OY));
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc[CPT / 4];
+#pragma unroll
+        for (int j = 0; j < CPT / 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -460,12 +460,22 @@ __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restri
                         float xv = 0.0f;
                         if (wx >= 0 && wx < WX && wy >= 0 && wy < WY && wz >= 0 && wz < WZ)
                             xv = in[ci * is_c + (int64_t)(x0 + wx) * is_x + (int64_t)(y0 + wy) * is_y + (z0 + wz)];
-                        const float4 wv = *reinterpret_cast<const float4 *>(wl + (ci * T + (dx * KS + dy) * KS + dz) * cout + c4);
-                        acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
-                        acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+                        const float *wr = wl + (ci * T + (dx * KS + dy) * KS + dz) * cout + c0;
+#pragma unroll
+                        for (int j = 0; j < CPT / 4; ++j) {
+                            if (c0 + 4 * j >= cout) break;
+                            const float4 wv = *reinterpret_cast<const float4 *>(wr + 4 * j);
+                            acc[j].x = fmaf(xv, wv.x, acc[j].x); acc[j].y = fmaf(xv, wv.y, acc[j].y);
+                            acc[j].z = fmaf(xv, wv.z, acc[j].z); acc[j].w = fmaf(xv, wv.w, acc[j].w);
+                        }
                     }
-        if (flags & SIS3D_EPI_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        *reinterpret_cast<float4 *>(out + v * out_stride + c4) = acc;
+#pragma unroll
+        for (int j = 0; j < CPT / 4; ++j) {
+            if (c0 + 4 * j >= cout) break;
+            float4 r = acc[j];
+            if (flags & SIS3D_EPI_RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            *reinterpret_cast<float4 *>(out + v * out_stride + c0 + 4 * j) = r;
+        }
     }
 }
 
@@ -855,7 +865,7 @@ extern "C" int sis3d_conv3d_planar2(const float *in, int64_t is_c, int64_t is_x,
     const int S = ksize == 2 ? 2 : 1;
     const int WX = OX * S, WY = OY * S, WZ = OZ * S;                 // window of the grid this call reads
     if (x0 < 0 || y0 < 0 || z0 < 0 || x0 + WX > X || y0 + WY > Y || z0 + WZ > Z) return SIS3D_EINVAL;
-    const int64_t total = (int64_t)OX * OY * OZ * (cout / 4);
+    const int64_t total = (int64_t)OX * OY * OZ * ((cout + 15) / 16);       // one thread per (voxel, 16 output channels)
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipStream_t st = as_stream(stream);
     if (ksize == 2) {

@@ -16,7 +16,7 @@ namespace {
 // (ZSEG = 8 on a 24x12x24x128 map left 3/4 of the CUs idle): ZSEG 2 on maps with >= 200k (voxel, float4) pairs, else 1.
 template <int ZSEG>
 __global__ __launch_bounds__(256) void maxpool3_kernel(const float4 *__restrict__ in, int X, int Y, int Z, int C4,
-                                                       float4 *__restrict__ out)
+                                                       float4 *__restrict__ out, int O4)
 {
     const int nseg = (Z + ZSEG - 1) / ZSEG;
     const int64_t total = (int64_t)X * Y * nseg * C4;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void maxpool3_kernel(const float4 *__restrict_
             m.y = fmaxf(fmaxf(col[j].y, col[j + 1].y), col[j + 2].y);
             m.z = fmaxf(fmaxf(col[j].z, col[j + 1].z), col[j + 2].z);
             m.w = fmaxf(fmaxf(col[j].w, col[j + 1].w), col[j + 2].w);
-            out[(((int64_t)x * Y + y) * Z + z) * C4 + c] = m;
+            out[(((int64_t)x * Y + y) * Z + z) * O4 + c] = m;          // O4: row stride of the (possibly wider) output
         }
     }
 }
@@ -124,14 +124,17 @@ extern "C" int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout
     return sis3d_check_launch();
 }
 
-extern "C" int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream)
+extern "C" int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, int out_stride, int out_coff,
+                                     sis3d_stream_t stream)
 {
     if (!in || !out || X <= 0 || Y <= 0 || Z <= 0 || C <= 0 || (C % 4)) return SIS3D_EINVAL;
+    if (out_stride < C || (out_stride % 4) || out_coff < 0 || (out_coff % 4) || out_coff + C > out_stride) return SIS3D_EINVAL;
     auto threads = [&](int zseg) { return (int64_t)X * Y * ((Z + zseg - 1) / zseg) * (C / 4); };
     auto go = [&](auto kern, int zseg) {
         const int64_t total = threads(zseg);
         const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4 *)in, X, Y, Z, C / 4, (float4 *)out);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4 *)in, X, Y, Z, C / 4,
+                           (float4 *)(out + out_coff), out_stride / 4);
         return sis3d_check_launch();
     };
     static const int force = [] { const char *e = getenv("SIS3D_POOL_ZSEG"); return e ? atoi(e) : 0; }();   // tuning hook

@@ -59,8 +59,8 @@ class FusedReLU(nn.Module):
 class HipMaxPool3d(nn.Module):
     """nn.MaxPool3d(3,1,1)"""
 
-    def forward(self, x):
-        return ops.maxpool3(ops.to_cl(x))
+    def forward(self, x, out=None, out_coff=0):
+        return ops.maxpool3(ops.to_cl(x), out, out_coff)
 
 
 class Bottleneck(nn.Module):
@@ -121,6 +121,8 @@ class FusedSequential(nn.Sequential):
                 x, y1 = m.forward_fused(x, y1, consumer(i), o, oc)
             elif isinstance(m, FusedReLU):
                 continue
+            elif isinstance(m, HipMaxPool3d) and last and last_out is not None:
+                x, y1 = m(x, last_out, last_coff), None
             elif isinstance(m, HipConv3d) and FUSE_BOTTLENECK and consumer(i) is not None and not (m.in_channels == 2 and not ops.is_cl(x)):
                 nb = consumer(i)
                 try:
@@ -164,13 +166,24 @@ class Base_Backbone(Network):
         if cfg.USE_IMAGES:
             # torch.cat([color, geometry], 1) (backbones.py:109): the last geometry Bottleneck writes its
             # channel range of the concatenated tensor directly (conv epilogue channel offset)
-            col = self.color(self._image_input)
-            cc, gc = col.shape[1], list(self.geometry1)[-1].conv3.out_channels
-            l1 = ops.new_act(cc + gc, col.shape[2:], col.device)
-            l1[:, :cc] = col
+            # torch.cat([color, geometry], 1): both branches write their channel range of l1 directly (the colour branch's
+            # last module -- max-pool or Bottleneck -- and the last geometry Bottleneck); no concat copy
+            cc, gc = self._branch_channels(self.color), self._branch_channels(self.geometry1)
+            od = tuple(int(v) // 4 for v in self._scene.shape[2:])
+            l1 = ops.new_act(cc + gc, od, self._scene.device)
+            self.color(self._image_input, last_out=l1, last_coff=0)
             self.geometry1(self._scene, last_out=l1, last_coff=cc)
             return l1
         return self.geometry1(self._scene)
+
+    @staticmethod
+    def _branch_channels(seq):
+        for m in reversed(list(seq)):
+            if isinstance(m, Bottleneck):
+                return m.conv3.out_channels
+            if isinstance(m, HipConv3d):
+                return m.out_channels
+        raise ValueError("empty branch")
 
     def _backbone_level2(self, l1):
         return self.geometry2(l1)

@@ -639,10 +639,14 @@ def mask_head_batched(scene, windows, w0, pcs, pc_last, sigmoid=True):
     return res
 
 
-def maxpool3(x):
+def maxpool3(x, out=None, out_coff=0):
+    """nn.MaxPool3d(3,1,1); `out` / `out_coff`: write into a channel range of a wider channels-last tensor"""
     if not is_cl(x):
         raise _lib.Sis3dError("maxpool3 expects a channels-last activation")
     _, C, X, Y, Z = x.shape
-    out = new_act(C, (X, Y, Z), x.device)
-    check(lib().sis3d_maxpool3d_3x3x3(_ptr(x), X, Y, Z, C, _ptr(out), _stream()), "sis3d_maxpool3d_3x3x3")
+    if out is None:
+        out, out_coff = new_act(C, (X, Y, Z), x.device), 0
+    elif not is_cl(out) or tuple(out.shape[2:]) != (X, Y, Z) or out_coff + C > out.shape[1]:
+        raise _lib.Sis3dError("maxpool3: bad `out`")
+    check(lib().sis3d_maxpool3d_3x3x3(_ptr(x), X, Y, Z, C, _ptr(out), out.shape[1], int(out_coff), _stream()), "sis3d_maxpool3d_3x3x3")
     return out

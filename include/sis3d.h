@@ -273,8 +273,11 @@ int sis3d_conv3d_planar2_ragged(const float *in, int64_t is_c, int64_t is_x, int
                                 int64_t total_items, const float *w, int cout, int flags, float *out, int out_stride,
                                 sis3d_stream_t stream);
 
-/* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding */
-int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, sis3d_stream_t stream);
+/* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding.  The C output channels land at
+ * [out_coff, out_coff + C) of rows of out_stride floats (out_stride = C, out_coff = 0: a plain tensor; otherwise a channel
+ * range of a wider tensor = the torch.cat of backbones.py:109 done in place). */
+int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *out, int out_stride, int out_coff,
+                          sis3d_stream_t stream);
 
 /* layout helpers: planar (C,X,Y,Z) <-> channels-last (X,Y,Z,C) */
 int sis3d_planar_to_cl(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
