@@ -88,6 +88,13 @@ struct ConvArgs {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// occupancy floor (waves per SIMD) of the fused-stage instantiations: two workgroups per CU for workgroups of <= 8 waves and of
+// 12 waves, one otherwise -- without it the stage code's extra registers would halve the residency of the 8-wave kernels
+constexpr int fused_min_waves(bool pw, int waves)
+{
+    return !pw ? 1 : waves <= 8 ? (2 * waves + 3) / 4 : waves == 12 ? 6 : (waves + 3) / 4;
+}
+
 // KS: kernel size (1,2,3); S: stride; brick BX*BY*BZ = 32*MW output voxels; NW waves along cout, each NTW
 // 32-wide cout tiles; KW waves split the reduction (taps for k=2/3, channel groups for k=1) of the SAME
 // output tile and are summed through LDS at the end (intra-workgroup split-K: no atomics, deterministic);
@@ -95,7 +102,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // PW: compile the fused pointwise stages in (separate instantiation so the plain kernels keep their register budget)
 // PROJ: the input is a back-projected image volume given as (voxel->pixel table, pixel-major features), see ConvArgs::ptab
 template <int KS, int S, int BX, int BY, int BZ, int MW, int NW, int KW, int NTW, int CK, bool PW = false, int PF = 4, bool PROJ = false>
-__global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64 * MW *NW *KW, fused_min_waves(PW, MW *NW *KW)) void conv3d_mfma_kernel(const ConvArgs a)
 {
     static_assert(BX * BY * BZ == 32 * MW, "brick must hold 32*MW voxels");
     constexpr int T = KS * KS * KS;
@@ -373,25 +380,47 @@ __global__ __launch_bounds__(64 * MW *NW *KW) void conv3d_mfma_kernel(const Conv
             for (int r = 0; r < 16; ++r) c2[r] = 0.0f;
             const float *ap2 = tin + (32 * mt + li) * ins + 4 * kh;
             const float4 *bp2 = reinterpret_cast<const float4 *>(st.wp) + (size_t)nt * kgs * 64 + lane;
-#pragma unroll 4
-            for (int g = 0; g < kgs; ++g) {
-                const float4 av = *reinterpret_cast<const float4 *>(ap2 + 8 * g);
-                const float4 bv = bp2[g * 64];
-                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c2, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c2, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c2, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c2, 0, 0, 0);
+            // k-groups in blocks of 4 (channel counts are multiples of 32): the four weight fragments and the four A
+            // fragments of a block are requested back to back, then consumed -- one exposed L2 latency per block instead of
+            // one per k-group (a plain `#pragma unroll` is refused here: "loop not unrolled")
+            for (int g0 = 0; g0 < kgs; g0 += 4) {
+                float4 bv[4], av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = bp2[(g0 + j) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const float4 *>(ap2 + 8 * (g0 + j));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv[j].x, c2, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv[j].y, c2, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bv[j].z, c2, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bv[j].w, c2, 0, 0, 0);
+                }
             }
             const int co = nt * 32 + li;
             const float bb = st.bias ? st.bias[co] : 0.0f;
+            auto row_of = [&](int r, int &mm, bool &inside, int64_t &vox) {
+                mm = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
+                inside = ox < gOX && oy < gOY && oz < gOZ;
+                vox = ((int64_t)ox * gOY + oy) * gOZ + oz;
+            };
+            // residual operands first, all 16 requests in flight together (they used to be loaded and awaited one by one)
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mm = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int ox = ox0 + mm / (BY * BZ), oy = oy0 + (mm / BZ) % BY, oz = oz0 + mm % BZ;
-                const bool inside = ox < gOX && oy < gOY && oz < gOZ;
-                const int64_t vox = ((int64_t)ox * gOY + oy) * gOZ + oz;
+                int mm; bool inside; int64_t vox;
+                row_of(r, mm, inside, vox);
+                rv[r] = ((st.flags & SIS3D_EPI_RESIDUAL) && inside) ? st.res[vox * st.res_stride + co] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int mm; bool inside; int64_t vox;
+                row_of(r, mm, inside, vox);
                 float v = c2[r] + bb;
-                if ((st.flags & SIS3D_EPI_RESIDUAL) && inside) v += st.res[vox * st.res_stride + co];
+                v += rv[r];
                 if (st.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.0f);
                 if (has_next) tout[mm * outs + co] = v;
                 if (inside && st.out) st.out[vox * st.out_stride + co] = v;

@@ -111,14 +111,24 @@ __device__ __forceinline__ void dense32(const float *tin, int cin, const float *
         for (int r = 0; r < 16; ++r) c[r] = 0.0f;
         const float *ap = tin + li * ins + 4 * kh;
         const float4 *bp = reinterpret_cast<const float4 *>(wp) + (size_t)nt * kgs * 64 + lane;
-#pragma unroll 16
-        for (int g = 0; g < kgs; ++g) {
-            const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * g);
-            const float4 bv = bp[g * 64];
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
+        // all weight fragments of (up to) 32 k-groups = 256 input channels are requested up front -- 128 VGPRs, which this
+        // 2-waves-per-SIMD kernel has to spare -- so a layer exposes ONE L2 latency instead of one per k-group (the former
+        // `#pragma unroll 16` loop was refused by the optimiser: a load, a wait and four MFMAs per iteration)
+        for (int gb = 0; gb < kgs; gb += 32) {
+            float4 bq[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (gb + j < kgs) bq[j] = bp[(gb + j) * 64];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (gb + j >= kgs) break;
+                const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * (gb + j));
+                const float4 bv = bq[j];
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
+            }
         }
         const int co = nt * 32 + li;
         const float bb = (co < cout_valid && bias) ? bias[co] : 0.0f;
