@@ -69,9 +69,10 @@ template averages three different layers: {', '.join('%s workgroups %.0f us' % (
 HBM traffic of that launch (PMC, corrected): 29.7 MB vs 14.2 MB algorithmic -> 0.25 TB/s: HBM is idle, the kernel is MFMA-pipe-bound
 (see DESIGN.md section 3 for why 100 % is out of reach at this problem size: 1728 output tiles over 1024 SIMDs).
 
-Progress inside round 1 (same box class): backbone+RPN 903 -> 932 (ragged mask head, fused softmax) -> 949 (max-pool) -> **998 M voxels/s**
-(third stream); detect 789 -> 874 -> 884 (one-kernel record packing); images 575 -> 667-674 (colour stem reads the views through the
-voxel->pixel table: no 226 MB volume); scene 21.9 -> 18.9 ms.
+Progress inside round 1 (same box class): backbone+RPN 903 -> 932 (ragged mask head, fused softmax) -> 949 (max-pool) -> **0.99-1.00 G voxels/s**
+(third stream; run-to-run 988-1003 M); detect 789 -> 874 -> 884 (one-kernel record packing) -> 907 (classifier tail loads batched); images
+575 -> 664-674 (colour stem reads the views through the voxel->pixel table: no 226 MB volume); scene 21.9 -> 18.7 ms; one chunk alone
+0.61 -> 0.585 ms.
 
 ### Per-kernel time, backbone+RPN, 3 chunks in flight (kernel durations OVERLAP across the three streams, so the per-chunk column sums to more than the step; the rpn conv row includes the 100 timing launches)
 
