@@ -90,8 +90,9 @@ Un-overlapped kernel times of the images path (1 chunk in flight, taken before t
 `r01_bench_images_inflight1_prefix_kernel_stats.csv`.
 
 Other kernels measured this round (tests/perf_frustum_vs_oracle.py, tools/pool_time.py): `sis3d_compute_projection`, 5 views: 26 us per 96x48x96 chunk
-(1.3 TB/s of list writes; torch-CPU oracle 0.80 s), 214 us for a 256x96x320 scene grid (2.9 TB/s; oracle 1.9 s).  max-pool 3x3x3: 9.8 us
-(24x12x24x128), 24.4 us (48x24x48x64, L1/L2-bound on its 18 taps per output: a separable LDS version is the next step there).
+(1.3 TB/s of list writes; torch-CPU oracle 0.80 s), 214 us for a 256x96x320 scene grid (2.9 TB/s; oracle 1.9 s).  max-pool 3x3x3: 6.8 us
+(24x12x24x128; 9.8 us before its tap loads were batched -- committed after the kernel_stats above were taken), 21.5 us (48x24x48x64,
+L1/L2-bound on its 18 taps per output: a separable LDS version is the next step there).
 
 """
 open(os.path.join(P, "README.md"), "w").write(head + tail)
