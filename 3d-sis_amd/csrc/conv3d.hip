@@ -241,6 +241,29 @@ __global__ __launch_bounds__(64 * MW *NW *KW, fused_min_waves(PW, MW *NW *KW)) v
     for (int q = 0; q < nchunks; ++q) {
         if (q) __syncthreads();
         // ---- stage the halo brick of chunk q: ROWS rows x CK floats, 16 B per thread, coalesced
+        constexpr int ITEMS = ROWS * (CK / 4), NIT = (ITEMS + NTHREADS - 1) / NTHREADS;
+        if constexpr (!PROJ && NIT <= 4 && (KS == 1 || PW)) {
+            // all of a thread's (<= 4) 16-byte pieces are requested before the first is written to LDS: the rolled loop
+            // compiles to load -> wait -> ds_write per piece, i.e. NIT exposed L2 latencies per chunk instead of one.  Used
+            // for the latency-bound kernels (1x1x1 convs, fused Bottleneck launches: 42.7 -> 37.5 us per 128/32 pair); the
+            // long plain k3 kernels hide that latency behind their six resident waves and measured 1-3 % slower with it
+            float4 sv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NTHREADS;
+                const int row = idx / (CK / 4), c4 = idx % (CK / 4);
+                const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
+                const int gx = ix0 + hx, gy = iy0 + hy, gz = iz0 + hz;
+                sv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < ITEMS && gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ)
+                    sv[it] = *reinterpret_cast<const float4 *>(p_in + ((size_t)(gx * gY + gy) * gZ + gz) * a.cin_stride + q * CK + c4 * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NTHREADS;
+                if (idx < ITEMS) *reinterpret_cast<float4 *>(lds + (idx / (CK / 4)) * RS + (idx % (CK / 4)) * 4) = sv[it];
+            }
+        } else
         for (int idx = tid; idx < ROWS * (CK / 4); idx += NTHREADS) {
             const int row = idx / (CK / 4), c4 = idx % (CK / 4);
             const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
