@@ -115,6 +115,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restr
     uint64_t *smask = remv + col_blocks;                                 // [n][col_blocks] if staged
     float *slev = (float *)(smask + (stage_mask ? (size_t)n * col_blocks : 0));   // [n] if staged
     float *sscr = slev + (stage_meta ? n : 0);
+    int *skeep = (int *)(sscr + (stage_meta ? n : 0));                   // [min(n, max_keep)] kept candidates (SELECT)
     __shared__ uint64_t s_kept;
     __shared__ int s_nk;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
@@ -152,14 +153,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restr
                 const int rank = nk0 + __popcll(kept & ((1ULL << lane) - 1ULL));
                 const int i = 64 * b + lane;
                 keep[rank] = i;
-                if (SELECT) {
-                    const int64_t src = order[i];
-                    float *r = rois + 6 * rank;
-                    const float *p = boxes_all + 6 * src;
-                    r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3]; r[4] = p[4]; r[5] = p[5];
-                    roi_scores[rank] = stage_meta ? sscr[i] : scores_sorted[i];
-                    roi_levels[rank] = stage_meta ? slev[i] : level_all[src];
-                }
+                if (SELECT) skeep[rank] = i;             // the gather itself runs after the sweep, on all threads
             }
             if (lane == 0) { s_kept = kept; s_nk = nk; }
         }
@@ -180,7 +174,22 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restr
     __syncthreads();
     const int nk = s_nk;
     if (tid == 0) num_keep[0] = nk;
-    if (SELECT) {                                      // zero-fill the padded rows
+    if (SELECT) {
+        // surviving rois / scores / levels: one thread per survivor, its dependent chain is order[i] -> three 8-byte box
+        // loads in flight together (this gather used to sit inside the serial sweep, seven awaited loads per kept row)
+        for (int r = tid; r < nk; r += blockDim.x) {
+            const int i = skeep[r];
+            const int64_t src = order[i];
+            const float2 *p = reinterpret_cast<const float2 *>(boxes_all + 6 * src);
+            const float2 b0 = p[0], b1 = p[1], b2 = p[2];
+            const float sc = stage_meta ? sscr[i] : scores_sorted[i];
+            const float lv = stage_meta ? slev[i] : level_all[src];
+            float2 *q = reinterpret_cast<float2 *>(rois + 6 * r);
+            q[0] = b0; q[1] = b1; q[2] = b2;
+            roi_scores[r] = sc;
+            roi_levels[r] = lv;
+        }
+        // zero-fill the padded rows
         for (int r = nk + tid; r < max_keep; r += blockDim.x) {
             for (int k = 0; k < 6; ++k) rois[6 * r + k] = 0.0f;
             roi_scores[r] = 0.0f;
@@ -208,7 +217,8 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     }
     const int stage_mask = mask_bytes <= SWEEP_LDS_MASK_MAX ? 1 : 0;
     const int stage_meta = (SELECT && n <= 4096) ? 1 : 0;
-    const size_t lds = (size_t)cb * 8 + (stage_mask ? mask_bytes : 0) + (stage_meta ? (size_t)n * 8 : 0) + 16;
+    const size_t lds = (size_t)cb * 8 + (stage_mask ? mask_bytes : 0) + (stage_meta ? (size_t)n * 8 : 0) +
+                       (SELECT ? (size_t)(n < max_keep ? n : max_keep) * 4 : 0) + 16;
     auto kern = nms_sweep_kernel<SELECT>;
     static bool attr_set = false;
     if (!attr_set) {

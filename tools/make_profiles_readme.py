@@ -69,10 +69,10 @@ template averages three different layers: {', '.join('%s workgroups %.0f us' % (
 HBM traffic of that launch (PMC, corrected): 29.7 MB vs 14.2 MB algorithmic -> 0.25 TB/s: HBM is idle, the kernel is MFMA-pipe-bound
 (see DESIGN.md section 3 for why 100 % is out of reach at this problem size: 1728 output tiles over 1024 SIMDs).
 
-Progress inside round 1 (same box class): backbone+RPN 903 -> 932 (ragged mask head, fused softmax) -> 949 (max-pool) -> **0.99-1.00 G voxels/s**
-(third stream; run-to-run 988-1003 M); detect 789 -> 874 -> 884 (one-kernel record packing) -> 907 (classifier tail loads batched); images
-575 -> 664-674 (colour stem reads the views through the voxel->pixel table: no 226 MB volume); scene 21.9 -> 18.7 ms; one chunk alone
-0.61 -> 0.585 ms.
+Progress inside round 1 (same box class): backbone+RPN 903 -> 932 (ragged mask head, fused softmax) -> 949 (max-pool) -> **1.0 G voxels/s**
+(third stream; run-to-run 988-1006 M); detect 789 -> 874 -> 884 (one-kernel record packing) -> 907-920 (serialised load chains removed from
+the classifier tail, fused stages, NMS select, RoI pooling); images 575 -> 664-684 (colour stem reads the views through the voxel->pixel
+table: no 226 MB volume); scene 21.9 -> 18.7-19.0 ms; one chunk alone 0.61 -> 0.58 ms.
 
 ### Per-kernel time, backbone+RPN, 3 chunks in flight (kernel durations OVERLAP across the three streams, so the per-chunk column sums to more than the step; the rpn conv row includes the 100 timing launches)
 
@@ -91,7 +91,7 @@ Un-overlapped kernel times of the images path (1 chunk in flight, taken before t
 
 Other kernels measured this round (tests/perf_frustum_vs_oracle.py, tools/pool_time.py): `sis3d_compute_projection`, 5 views: 26 us per 96x48x96 chunk
 (1.3 TB/s of list writes; torch-CPU oracle 0.80 s), 214 us for a 256x96x320 scene grid (2.9 TB/s; oracle 1.9 s).  max-pool 3x3x3: 6.8 us
-(24x12x24x128; 9.8 us before its tap loads were batched -- committed after the kernel_stats above were taken), 21.5 us (48x24x48x64,
+(24x12x24x128; 9.8 us before its tap loads were batched), 21.5 us (48x24x48x64,
 L1/L2-bound on its 18 taps per output: a separable LDS version is the next step there).
 
 """
