@@ -500,27 +500,36 @@ __global__ __launch_bounds__(256) void conv_planar2_kernel(const float *__restri
         float4 acc[CPT / 4];
 #pragma unroll
         for (int j = 0; j < CPT / 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // input taps in batches (all 16 for k2, one (channel, dx) slice of 9 for k3): clamped addresses, padding applied as
+        // a select, the batch's loads in flight together, then its FMAs.  Tap-by-tap the loads were awaited one at a time.
+        constexpr int NB = (KS == 2) ? 1 : 2 * KS, BT = K / NB;
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
+        for (int b = 0; b < NB; ++b) {
+            float xs[BT];
 #pragma unroll
-            for (int dx = 0; dx < KS; ++dx)
+            for (int u = 0; u < BT; ++u) {
+                const int k = b * BT + u, ci = k / T, tap = k % T;
+                const int dx = tap / (KS * KS), dy = (tap / KS) % KS, dz = tap % KS;
+                const int wx = ox * S + dx - PAD, wy = oy * S + dy - PAD, wz = oz * S + dz - PAD;   // window coords
+                const bool ok = wx >= 0 && wx < WX && wy >= 0 && wy < WY && wz >= 0 && wz < WZ;
+                const int cx = min(max(wx, 0), WX - 1), cy = min(max(wy, 0), WY - 1), cz = min(max(wz, 0), WZ - 1);
+                const float t = in[ci * is_c + (int64_t)(x0 + cx) * is_x + (int64_t)(y0 + cy) * is_y + (z0 + cz)];
+                xs[u] = ok ? t : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int dy = 0; dy < KS; ++dy)
+            for (int u = 0; u < BT; ++u) {
+                const float xv = xs[u];
+                const float *wr = wl + (b * BT + u) * cout + c0;
 #pragma unroll
-                    for (int dz = 0; dz < KS; ++dz) {
-                        const int wx = ox * S + dx - PAD, wy = oy * S + dy - PAD, wz = oz * S + dz - PAD;   // window coords
-                        float xv = 0.0f;
-                        if (wx >= 0 && wx < WX && wy >= 0 && wy < WY && wz >= 0 && wz < WZ)
-                            xv = in[ci * is_c + (int64_t)(x0 + wx) * is_x + (int64_t)(y0 + wy) * is_y + (z0 + wz)];
-                        const float *wr = wl + (ci * T + (dx * KS + dy) * KS + dz) * cout + c0;
-#pragma unroll
-                        for (int j = 0; j < CPT / 4; ++j) {
-                            if (c0 + 4 * j >= cout) break;
-                            const float4 wv = *reinterpret_cast<const float4 *>(wr + 4 * j);
-                            acc[j].x = fmaf(xv, wv.x, acc[j].x); acc[j].y = fmaf(xv, wv.y, acc[j].y);
-                            acc[j].z = fmaf(xv, wv.z, acc[j].z); acc[j].w = fmaf(xv, wv.w, acc[j].w);
-                        }
-                    }
+                for (int j = 0; j < CPT / 4; ++j) {
+                    if (c0 + 4 * j >= cout) break;
+                    const float4 wv = *reinterpret_cast<const float4 *>(wr + 4 * j);
+                    acc[j].x = fmaf(xv, wv.x, acc[j].x); acc[j].y = fmaf(xv, wv.y, acc[j].y);
+                    acc[j].z = fmaf(xv, wv.z, acc[j].z); acc[j].w = fmaf(xv, wv.w, acc[j].w);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < CPT / 4; ++j) {
             if (c0 + 4 * j >= cout) break;
@@ -832,27 +841,33 @@ __global__ __launch_bounds__(256) void conv_planar2_ragged_kernel(const float *_
         float4 acc[CPT / 4];
 #pragma unroll
         for (int j = 0; j < CPT / 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // one (channel, dx) slice of 9 taps per batch: loads in flight together (clamped addresses, padding as a select)
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
+        for (int b = 0; b < 2 * KS; ++b) {
+            float xs[KS * KS];
 #pragma unroll
-            for (int ddx = 0; ddx < KS; ++ddx)
+            for (int u = 0; u < KS * KS; ++u) {
+                const int ci = b / KS, ddx = b % KS, ddy = u / KS, ddz = u % KS;
+                const int wx = ox + ddx - 1, wy = oy + ddy - 1, wz = oz + ddz - 1;
+                const bool ok = wx >= 0 && wx < d.dx && wy >= 0 && wy < d.dy && wz >= 0 && wz < d.dz;
+                const int cx = min(max(wx, 0), d.dx - 1), cy = min(max(wy, 0), d.dy - 1), cz = min(max(wz, 0), d.dz - 1);
+                const float t = in[ci * is_c + (int64_t)(d.x0 + cx) * is_x + (int64_t)(d.y0 + cy) * is_y + (d.z0 + cz)];
+                xs[u] = ok ? t : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ddy = 0; ddy < KS; ++ddy)
+            for (int u = 0; u < KS * KS; ++u) {
+                const float xv = xs[u];
+                const float *wr = wl + (b * KS * KS + u) * cout + c0;
 #pragma unroll
-                    for (int ddz = 0; ddz < KS; ++ddz) {
-                        const int wx = ox + ddx - 1, wy = oy + ddy - 1, wz = oz + ddz - 1;
-                        float xv = 0.0f;
-                        if (wx >= 0 && wx < d.dx && wy >= 0 && wy < d.dy && wz >= 0 && wz < d.dz)
-                            xv = in[ci * is_c + (int64_t)(d.x0 + wx) * is_x + (int64_t)(d.y0 + wy) * is_y + (d.z0 + wz)];
-                        const float *wr = wl + (ci * T + (ddx * KS + ddy) * KS + ddz) * cout + c0;
-#pragma unroll
-                        for (int j = 0; j < CPT / 4; ++j) {
-                            if (c0 + 4 * j >= cout) break;
-                            const float4 wv = *reinterpret_cast<const float4 *>(wr + 4 * j);
-                            acc[j].x = fmaf(xv, wv.x, acc[j].x); acc[j].y = fmaf(xv, wv.y, acc[j].y);
-                            acc[j].z = fmaf(xv, wv.z, acc[j].z); acc[j].w = fmaf(xv, wv.w, acc[j].w);
-                        }
-                    }
+                for (int j = 0; j < CPT / 4; ++j) {
+                    if (c0 + 4 * j >= cout) break;
+                    const float4 wv = *reinterpret_cast<const float4 *>(wr + 4 * j);
+                    acc[j].x = fmaf(xv, wv.x, acc[j].x); acc[j].y = fmaf(xv, wv.y, acc[j].y);
+                    acc[j].z = fmaf(xv, wv.z, acc[j].z); acc[j].w = fmaf(xv, wv.w, acc[j].w);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < CPT / 4; ++j) {
             if (c0 + 4 * j >= cout) break;
