@@ -221,3 +221,58 @@ def test_oracle_vs_live_reference(oracle):
     # reference numpy cpu_nms == oracle C nms on the decoded proposals
     boxes = o["rois"][0]
     assert np.array_equal(ns.pth_nms.cpu_nms(boxes.numpy(), 0.3), oracle.nms(boxes, 0.3).numpy())
+
+
+def test_nms_fuzz_vs_live_reference(oracle):
+    """40 random box sets (ties, duplicates, zero-volume boxes, 1..700 boxes) through the reference's numpy cpu_nms"""
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("reference tree not present on this machine")
+    ns = rh.install()
+    g = torch.Generator().manual_seed(123)
+    for case in range(40):
+        n = int(torch.randint(1, 700, (1,), generator=g))
+        lo = torch.rand(n, 3, generator=g) * 60
+        size = torch.rand(n, 3, generator=g) * (30 if case % 2 else 6)
+        boxes = torch.cat([lo, lo + size], 1)
+        if case % 5 == 0:
+            boxes = boxes.round()                                   # integer coordinates -> exact IoU ties at the threshold
+        if case % 7 == 0:
+            boxes = torch.cat([boxes[:n // 2], boxes[:n - n // 2]], 0)   # exact duplicates
+        if case % 11 == 0:
+            boxes[::9, 3:] = boxes[::9, :3]                         # zero-volume boxes
+        for thresh in (0.1, 0.5):
+            want = ns.pth_nms.cpu_nms(boxes.numpy(), thresh)
+            got = oracle.nms(boxes, thresh).numpy()
+            assert np.array_equal(np.asarray(want, dtype=np.int64), got), (case, thresh)
+
+
+def test_collate_vs_live_reference(tmp_path):
+    """sis3d.datasets.dataset.collate_fn == lib/datasets/dataloader.py:collate_fn on the geometry side"""
+    import os
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("reference tree not present on this machine")
+    ns = rh.install(with_trainval=True)
+    from lib.datasets.dataloader import collate_fn as ref_collate
+    from sis3d.datasets.dataset import Dataset, collate_fn
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    lst = tmp_path / "l.txt"
+    lst.write_text(os.path.join(golden_dir, "synthetic.chunk") + "\n")
+    c = config.scannet_benchmark_cfg()
+    c.LABEL_MAP, c.USE_IMAGES, c.USE_MASK, c.KEEP_THRESH = os.path.join(golden_dir, "synthetic_labels.csv"), False, True, 0.5
+    item = Dataset(str(lst), "chunk", c)[0]
+    cfg = ns.cfg
+    saved = (cfg.USE_IMAGES,)
+    try:
+        cfg.USE_IMAGES = False
+        want = ref_collate([item])
+    finally:
+        cfg.USE_IMAGES = saved[0]
+    got = collate_fn([item])
+    assert got["id"] == want["id"] and torch.equal(got["data"], want["data"])
+    assert len(got["gt_box"]) == len(want["gt_box"]) and all(torch.equal(a, b) for a, b in zip(got["gt_box"], want["gt_box"]))
+    assert len(got["gt_mask"]) == len(want["gt_mask"])
+    for ma, mb in zip(got["gt_mask"], want["gt_mask"]):
+        assert len(ma) == len(mb) and all(torch.equal(a, b) for a, b in zip(ma, mb))
+    assert got["nearest_images"] == want["nearest_images"] == {}
