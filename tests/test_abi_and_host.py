@@ -101,3 +101,26 @@ def test_host_bbox_codec_matches_oracle(oracle):
     deltas = torch.randn(50, 6, generator=g) * 0.3
     assert torch.equal(clip_boxes(bbox_transform_inv(boxes, deltas), (96, 48, 96)),
                        oracle.clip_boxes(oracle.bbox_transform_inv(boxes, deltas), (96, 48, 96)))
+
+
+def test_projection_helper_host_geometry(oracle):
+    """host side of the device compute_projection: the 40 floats per view (two inverses + clamped frustum AABB) equal the
+    oracle's restatement of projection.py:27-61, and a CPU depth map without a GPU fails loudly (no CPU path)"""
+    import torch
+    from sis3d import config, ops, synthetic
+    from sis3d.layer_utils.projection import ProjectionHelper
+    c = config.scannet_benchmark_cfg()
+    dims = (40, 24, 32)
+    h = ProjectionHelper(c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX, c.DEPTH_SHAPE, list(dims), c.VOXEL_SIZE)
+    depth, c2w, w2g = synthetic.synth_cameras(3, 6, dims, c.VOXEL_SIZE)
+    for v in range(6):
+        row = h.view_params(c2w[v], w2g[v])
+        assert row.shape == (ops.VIEW_PARAM_FLOATS,) and row.dtype == torch.float32
+        assert torch.equal(row[0:16].view(4, 4), torch.inverse(w2g[v])) and torch.equal(row[16:32].view(4, 4), torch.inverse(c2w[v]))
+        bmin, bmax = oracle.frustum_bounds(c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX, c.DEPTH_SHAPE, c2w[v], w2g[v])
+        assert torch.equal(row[32:35], torch.maximum(bmin, torch.zeros(3)))
+        assert torch.equal(row[35:38], torch.minimum(bmax, torch.tensor([float(d) for d in dims])))
+        assert (row[32:35] >= 0).all() and (row[35:38] <= torch.tensor([40.0, 24.0, 32.0])).all() and not row[38:].any()
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            h.compute_projection(depth[0], c2w[0], w2g[0])
