@@ -45,7 +45,7 @@ All numbers: synthetic 96x48x96 chunks, seeded synthetic weights, fp32, inputs r
 Files: `r01_bench_*.json` = the bench.py JSON lines; `r01_*_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats
 --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline [--workload ...]` (kernel_stats only;
 the traces stay in gpurun_out/); `r01_dominant_kernel_from_trace.json` = the dominant kernel's launches of that same trace split by
-grid size (tools/dominant_from_trace.py); `r01_pmc_rpn_net.json` = HBM traffic counters of the dominant kernel (separate --pmc passes).
+grid size (tools/dominant_from_trace.py); `r01_pmc_rpn_net.json` / `r01_pmc_rpn_net_mfma.json` = HBM traffic and MFMA-busy counters of the dominant kernel (separate --pmc passes).
 Everything here is produced by `tools/round_profiles.sh` (one `gpurun` call) and this file's head by `tools/make_profiles_readme.py`.
 
 ## Headline (bench.py defaults: backbone + RPN, 3 chunks in flight per GPU)
@@ -66,6 +66,8 @@ Dominant kernel (rpn_net k3 128->256, 12.23 GFLOP/launch): {d0['roofline']['laun
 (bench.py: mean of 100 warm launches on the launch stream, HIP events).  rocprofv3 trace of the same command, the same 432-workgroup
 launches: {tr['avg_us']:.1f} us average ({tr['tflops']:.1f} TFLOP/s) -- agrees within {abs(tr['avg_us'] / d0['roofline']['launch_us'] - 1) * 100:.0f} %.  (The kernel_stats row of this
 template averages three different layers: {', '.join('%s workgroups %.0f us' % (k, v['avg_us']) for k, v in T['by_workgroups'].items())}.)
+MFMA-pipe utilisation from PMC counters (`r01_pmc_rpn_net_mfma.json`, tools/pmc_mfma.sh): SQ_VALU_MFMA_BUSY_CYCLES = 191,102,976 =
+2,985,984 MFMAs x 64 cycles (exactly the algorithmic count) over 300,062 active cycles x 1024 SIMDs = 62 % busy under the profiler.
 HBM traffic of that launch (PMC, corrected): 29.7 MB vs 14.2 MB algorithmic -> 0.25 TB/s: HBM is idle, the kernel is MFMA-pipe-bound
 (see DESIGN.md section 3 for why 100 % is out of reach at this problem size: 1728 output tiles over 1024 SIMDs).
 
