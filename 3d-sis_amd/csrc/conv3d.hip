@@ -27,6 +27,7 @@
 // This file may use FMA freely (fp32 tolerance 1e-4 applies, not bit-exactness).
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -563,8 +564,16 @@ int launch_cfg_(ConvArgs &a, hipStream_t st)
     a.ngroups = cdiv(a.ntiles, NW * NTW);
     auto kern = conv3d_mfma_kernel<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, PW, PF, PROJ>;
     if (lds > 64 * 1024) {
-        static size_t set_to = 0;
-        if (lds > set_to) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_to = lds; }
+        // per device and thread-safe: a relaxed atomic per (instantiation, device) remembers the largest size already granted
+        static std::atomic<size_t> set_to[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t> &slot = set_to[dev & 15];
+        if (lds > slot.load(std::memory_order_relaxed)) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            size_t cur = slot.load(std::memory_order_relaxed);
+            while (lds > cur && !slot.compare_exchange_weak(cur, lds, std::memory_order_relaxed)) {}
+        }
     }
     const int64_t blocks = a.nrag > 0 ? a.ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * a.ngroups * (a.nprob > 1 ? a.nprob : 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * MW * NW * KW), lds, st, a);

@@ -215,16 +215,20 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
         int rc = sis3d_check_launch();
         if (rc) return rc;
     }
-    const int stage_mask = mask_bytes <= SWEEP_LDS_MASK_MAX ? 1 : 0;
-    const int stage_meta = (SELECT && n <= 4096) ? 1 : 0;
-    const size_t lds = (size_t)cb * 8 + (stage_mask ? mask_bytes : 0) + (stage_meta ? (size_t)n * 8 : 0) +
-                       (SELECT ? (size_t)(n < max_keep ? n : max_keep) * 4 : 0) + 16;
+    constexpr size_t LDS_LIMIT = 160 * 1024 - 64;
+    int stage_mask = mask_bytes <= SWEEP_LDS_MASK_MAX ? 1 : 0;
+    int stage_meta = (SELECT && n <= 4096) ? 1 : 0;
+    const size_t keep_b = SELECT ? (size_t)(n < max_keep ? n : max_keep) * 4 : 0;     // the survivors' positions (select path)
+    auto need = [&] { return (size_t)cb * 8 + (stage_mask ? mask_bytes : 0) + (stage_meta ? (size_t)n * 8 : 0) + keep_b + 16; };
+    // the optional stagings are dropped first; what remains (one remove word per column block + the keep positions) is
+    // bounded by the caller's n / max_keep, not by this library: refuse instead of failing the launch
+    if (need() > LDS_LIMIT) stage_meta = 0;
+    if (need() > LDS_LIMIT) stage_mask = 0;
+    if (need() > LDS_LIMIT) return SIS3D_EUNSUPPORTED;
+    const size_t lds = need();
     auto kern = nms_sweep_kernel<SELECT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        attr_set = true;
-    }
+    // per call: the attribute is per device (and this may be another thread's first call); it costs < 1 us
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, mask, n, max_keep, keep, num_keep, boxes, level_all, scores_sorted, order,
                        rois, roi_scores, roi_levels, stage_mask, stage_meta);
     return sis3d_check_launch();

@@ -63,7 +63,8 @@ class Dataset(torch.utils.data.Dataset):
         if self.device_encode:
             from .. import ops
             raw = torch.from_numpy(np.array(sf.sdf)).cuda()        # blocking: the staging copy is pageable (ROCm hazards)
-            return ops.tsdf_encode(raw, sf.dims, cfg.TRUNCATED, mode, max_height)[0]
+            # planar (2,X,Y,Z), the layout the reference's blobs['data'] has and the first-layer kernels read
+            return ops.tsdf_encode(raw, sf.dims, cfg.TRUNCATED, mode, max_height, channels_last=False)[0]
         v = sf.sdf_grid()[None].astype(np.float32)
         a = np.abs(np.clip(v, -cfg.TRUNCATED, cfg.TRUNCATED))
         if mode == "flip":
@@ -115,7 +116,7 @@ def collate_fn(batch):
     def tens(x):
         return x if torch.is_tensor(x) else torch.from_numpy(x)
     if len(batch) == 1 and torch.is_tensor(batch[0]["data"]):
-        data = batch[0]["data"].unsqueeze(0)            # keeps the device tensor's channels-last layout
+        data = batch[0]["data"].unsqueeze(0)            # device-encoded sample: stays on the GPU, planar like the host path
     else:
         data = torch.stack([tens(x["data"]) for x in batch], 0)
     return {"id": [x["id"] for x in batch],

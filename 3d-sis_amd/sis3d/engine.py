@@ -15,15 +15,24 @@ RECORD_WIDTH = ops.RECORD_WIDTH     # proposal box (6), rpn score, level, class 
 
 
 class ChunkEngine:
-    def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1):
-        """stage: 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect' (+ proposals, RoI pooling, classifier).
+    def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1,
+                 mask_boxes=0):
+        """stage: 'backbone' (the two pyramid levels only), 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect'
+        (+ proposals, RoI pooling, classifier).
         from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
         blobs['nearest_images'], lib/datasets/dataloader.py:17-38) and the voxel->pixel lists are computed inside the
         captured graph (sis3d_compute_projection) instead of being loaded; `view_counts()` reports views that saw
         nothing -- the caller's cue to take the reference's killing_inds route (layer_utils.projection.prepare_projection).
         group (1 or 2): chunks per captured graph.  With 2, the four 12-GFLOP RPN convs of the pair go out as one batched
         launch (Network.backbone_rpn_group); slots are addressed by the `slot` argument of load / set_origin and `run()`
-        returns a list of per-chunk outputs."""
+        returns a list of per-chunk outputs.
+        mask_boxes (detect stage, USE_MASK nets): BASELINE config 3 in full -- the mask head runs inside the captured graph on
+        a FIXED detection set: with seeded weights no class probability passes CLASS_THRESH, so the first `mask_boxes`
+        post-NMS RoIs of the chunk loaded at prepare() time stand in as detections; their crop
+        windows (box rounded half-to-even, clipped, non-degenerate: trainval.py:702-712,742-745) are read back ONCE before
+        the capture.  `mask_stats()` reports the crop volumes and the mask-head FLOPs."""
+        self.mask_boxes = int(mask_boxes)
+        self.mask_plan = None
         self.net, self.dims, self.stage, self.use_graph = net, tuple(dims), stage, use_graph
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.group = int(group)
@@ -78,10 +87,17 @@ class ChunkEngine:
         net = self.net
         if self.group == 1:
             imageft = self._imageft(0)
+            if self.stage == "backbone":
+                # the backbone proper (geometry1 [+ color] + geometry2): what BASELINE.json's roofline target names
+                l1, l2 = net.backbone_only(self.scenes[0], imageft)
+                return {"level1": l1, "level2": l2}
             if self.stage == "rpn":
                 net.backbone_rpn(self.scenes[0], imageft)
                 return {k: v for k, v in net._predictions.items() if k.startswith("rpn_")}
-            return self._finish(net.detect(self.scenes[0], imageft), 0)
+            d = self._finish(net.detect(self.scenes[0], imageft), 0)
+            if self.mask_plan is not None:
+                d["mask_pred"] = net.mask_backbone.forward_planned(self.scenes[0], self.mask_plan)
+            return d
         fts = [self._imageft(g) for g in range(self.group)] if self.use_images else None
         if self.stage == "rpn":
             return [{k: v for k, v in pred.items() if k.startswith("rpn_")}
@@ -95,6 +111,10 @@ class ChunkEngine:
             for _ in range(max(1, warmup)):
                 self.out = self._step()
             torch.cuda.synchronize()
+            if self.mask_boxes > 0 and self.stage == "detect" and self.group == 1:
+                self.mask_plan = self._plan_masks()
+                self.out = self._step()
+                torch.cuda.synchronize()
             if self.use_graph:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -107,6 +127,28 @@ class ChunkEngine:
                     self.out = self._step()
                 torch.cuda.synchronize()
         return self
+
+    def _plan_masks(self):
+        """crop windows of the stand-in detections of the chunk currently loaded (one D2H read, before the capture)"""
+        n = int(self.out["num"].item())
+        rois = self.out["rois"][:min(n, self.mask_boxes)].detach().cpu()
+        wins = []
+        for r in rois.tolist():
+            w = [int(round(v)) for v in r]
+            w = [max(0, min(w[k], self.dims[k % 3])) for k in range(6)]
+            if w[0] < w[3] and w[1] < w[4] and w[2] < w[5]:
+                wins.append(tuple(w))
+        if not wins:
+            raise ops._lib.Sis3dError("mask_boxes: no non-degenerate RoI on this chunk")
+        return self.net.mask_backbone.plan(wins, self.device)
+
+    def mask_stats(self):
+        p = self.mask_plan
+        if p is None:
+            return {}
+        vols = sorted(dx * dy * dz for dx, dy, dz in p.dims)
+        return {"mask_boxes": p.n, "mask_voxels": p.voxels, "mask_head_gflop": p.flops / 1e9,
+                "mask_crop_voxels_min_median_max": [vols[0], vols[len(vols) // 2], vols[-1]]}
 
     @staticmethod
     def _copy(dst, src):

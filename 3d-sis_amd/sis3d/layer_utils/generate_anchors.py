@@ -18,6 +18,7 @@ def anchors_for_level(size, stride, sizes):
                                  np.arange(0, size[2]) * stride, indexing="ij")
         shifts = np.stack([gx.ravel(), gy.ravel(), gz.ravel()] * 2, axis=1)
         a = (base[None, :, :] + shifts[:, None, :]).reshape(-1, 6).astype(np.float32)
+        a.setflags(write=False)                            # shared by every caller of this shape
         _cache[key] = a
     return _cache[key]
 

@@ -6,6 +6,8 @@ the GPU, outputs padded to K rows + a device-side count).  `proposal_layer(...)`
 keeps the reference's signature and list-of-variable-length-tensors return
 (one 4-byte D2H read for the count).
 """
+import hashlib
+
 import numpy as np
 import torch
 
@@ -17,19 +19,28 @@ class ProposalEngine:
     def __init__(self, cfg=None):
         self.cfg = cfg or _default_cfg
         self._cache = {}
+        self._ident = {}
 
     def _level_tables(self, anchors, dims, device):
         """device anchors + int32 inside-index list (proposal_layer.py:36-43), cached per shape."""
-        key = (anchors.shape[0], hash(anchors[:64].tobytes()) if isinstance(anchors, np.ndarray) else id(anchors),
-               tuple(int(d) for d in dims), str(device))
+        # keyed on the CONTENT of the whole anchor table (a few hundred KB, hashed once per call: ~0.1 ms): neither
+        # id() (recycled after garbage collection) nor a prefix of the rows identifies an anchor set
+        a = anchors if isinstance(anchors, np.ndarray) else anchors.detach().cpu().numpy()
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        memo = self._ident.get(id(anchors))
+        if memo is not None and memo[0] is anchors and isinstance(anchors, np.ndarray) and not anchors.flags.writeable:
+            digest = memo[1]                                  # read-only array object seen before: content cannot have changed
+        else:
+            digest = hashlib.blake2b(a.tobytes(), digest_size=16).digest()
+            if isinstance(anchors, np.ndarray) and not anchors.flags.writeable:
+                self._ident[id(anchors)] = (anchors, digest)  # holds a reference, so the id cannot be recycled
+        key = (a.shape[0], digest, tuple(int(d) for d in dims), str(device), float(self.cfg["ALLOW_BORDER"]))
         if key not in self._cache:
-            a = anchors if isinstance(anchors, np.ndarray) else anchors.detach().cpu().numpy()
-            a = np.ascontiguousarray(a, dtype=np.float32)
             b = np.float32(self.cfg["ALLOW_BORDER"])
             inside = np.where((a[:, 0] >= -b) & (a[:, 1] >= -b) & (a[:, 2] >= -b) &
                               (a[:, 3] < np.float32(dims[0]) + b) & (a[:, 4] < np.float32(dims[1]) + b) &
                               (a[:, 5] < np.float32(dims[2]) + b))[0].astype(np.int32)
-            self._cache[key] = (torch.from_numpy(a).to(device), torch.from_numpy(inside).to(device))
+            self._cache[key] = (torch.tensor(a).to(device), torch.from_numpy(inside).to(device))
         return self._cache[key]
 
     def run(self, levels, dims, cfg_key="TEST"):

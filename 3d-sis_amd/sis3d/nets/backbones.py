@@ -267,7 +267,21 @@ def _mask_forward_batched(self, scene, windows):
     return ops.mask_head_batched(scene, windows, g[0].weight, pcs, g[10]._packed.get(g[10]), sigmoid=not self.training)
 
 
+def _mask_plan(self, windows, device):
+    """host-side part of forward_batched for a fixed window set (ops.MaskPlan): build once, run many times / capture"""
+    g = self.geometry
+    return ops.MaskPlan(windows, g[2].out_channels, g[10].out_channels, device)
+
+
+def _mask_forward_planned(self, scene, plan):
+    g = self.geometry
+    pcs = [g[i]._packed.get(g[i]) for i in (2, 4, 6, 8)]
+    return ops.mask_head_run(scene, plan, g[0].weight, pcs, g[10]._packed.get(g[10]), sigmoid=not self.training)
+
+
 MaskBackbone.forward_batched = _mask_forward_batched
+MaskBackbone.plan = _mask_plan
+MaskBackbone.forward_planned = _mask_forward_planned
 
 
 def state_dict_shapes(cfg=None):

@@ -95,6 +95,9 @@ class Network(nn.Module):
     def _classify_rois(self, l1, l2):
         cfg, p = self.cfg, self._prop
         ps = cfg.CLASS_POOLING_SIZE
+        if self._feat_stride[0] != self._feat_stride[1]:
+            # network.py:520,529 pool level 2 with 1/feat_stride[1]; the fused two-level launch takes one scale
+            raise NotImplementedError("pyramid levels with different strides (every shipped backbone uses 4, 4)")
         pool5 = ops.roi_pool_levels(l1, l2, p["rois"], p["levels"], ps, 1.0 / self._feat_stride[0], out_channels_last=True)
         self._pool5 = pool5
         x = pool5.permute(0, 2, 3, 4, 1).reshape(pool5.shape[0], -1)           # memory order (R, bins, C): a view
@@ -132,6 +135,17 @@ class Network(nn.Module):
         anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
         setattr(self, "_anchors_level%d" % lv, anchors)
         return (lv, prob, bbox, anchors)
+
+    def backbone_only(self, scene, imageft=None):
+        """Device-only: the backbone proper (backbones.py:98-113) -> (level1, level2)."""
+        self._scene = scene
+        self._scene_info = scene.shape[2:]
+        if imageft is not None:
+            self._imageft = imageft
+        l1 = self._backbone_level1()
+        l2 = self._backbone_level2(l1)
+        self._net_conv = (l1, l2)
+        return l1, l2
 
     def backbone_rpn(self, scene, imageft=None):
         """Device-only: backbone + RPN convs/heads/softmax (BASELINE config 1).  Fills the rpn_* predictions.

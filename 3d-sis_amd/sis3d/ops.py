@@ -571,72 +571,92 @@ def _rag_dtypes():
     return _RAG_DT
 
 
+class MaskPlan:
+    """Everything of a ragged mask-head batch that depends only on the crop windows: the three descriptor tables (one
+    upload), the packed activation buffers and the per-box output views.  Built on the host once; `mask_head_run` then
+    only enqueues kernels, so a plan made BEFORE a graph capture lets the whole mask head be captured (fixed windows)."""
+
+    def __init__(self, windows, C, NC, device):
+        import numpy as np
+        n = len(windows)
+        self.n, self.C, self.NC = n, C, NC
+        bx, by, bz, ng = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
+        check(lib().sis3d_ragged_tiling(C, C, 3, ctypes.byref(bx), ctypes.byref(by), ctypes.byref(bz), ctypes.byref(ng)), "sis3d_ragged_tiling")
+        bx, by, bz, ng = bx.value, by.value, bz.value, ng.value
+        rdt, pdt = _rag_dtypes()
+        w = np.asarray(windows, dtype=np.int64).reshape(n, 6)
+        ext = w[:, 3:] - w[:, :3]                                     # (n,3) crop sizes
+        nbk = -(-ext // np.array([bx, by, bz]))                       # bricks per axis
+        nvox = ext.prod(1)
+        voffs = np.concatenate([[0], np.cumsum(nvox)])                # voxel offset of every crop in the packed buffers
+        blks = np.concatenate([[0], np.cumsum(nbk.prod(1) * ng)])
+        d3 = np.zeros(n, dtype=rdt)
+        d1 = np.zeros(n, dtype=rdt)
+        dp = np.zeros(n, dtype=pdt)
+        for d, ostr in ((d3, C), (d1, NC)):
+            d["X"], d["Y"], d["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
+            d["nbx"], d["nby"], d["nbz"] = nbk[:, 0], nbk[:, 1], nbk[:, 2]
+            d["block0"] = blks[:-1]
+            d["in_off"] = voffs[:-1] * C
+            d["out_off"] = voffs[:-1] * ostr
+        dp["x0"], dp["y0"], dp["z0"] = w[:, 0], w[:, 1], w[:, 2]
+        dp["dx"], dp["dy"], dp["dz"] = ext[:, 0], ext[:, 1], ext[:, 2]
+        dp["t0"] = voffs[:-1] * (C // 4)
+        dp["out_off"] = voffs[:-1] * C
+        self.voxels, self.blocks, self.items = int(voffs[-1]), int(blks[-1]), int(voffs[-1]) * (C // 4)
+        self.dims = [tuple(int(v) for v in e) for e in ext]
+        # ONE upload for the three descriptor tables (each is a blocking pageable copy)
+        parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1)]
+        pad = [(-p.size) % 16 for p in parts]
+        host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
+        self.devbuf = torch.from_numpy(host).to(device)
+        o1 = parts[0].size + pad[0]
+        o2 = o1 + parts[1].size + pad[1]
+        self.g3, self.g1, self.gp = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:]
+        self.a = torch.empty(self.voxels, C, device=device)
+        self.b = torch.empty(self.voxels, C, device=device)
+        self.out = torch.empty(self.voxels, NC, device=device)
+        # 2 FLOP per MAC: conv0 (2 -> C, k3), four C -> C k3 convs, the C -> NC k1 head
+        self.flops = 2.0 * self.voxels * (54 * C + 4 * 27 * C * C + C * NC)
+
+    def views(self):
+        res, voff = [], 0
+        for dx, dy, dz in self.dims:
+            nv = dx * dy * dz
+            res.append(self.out[voff:voff + nv].view(dx, dy, dz, self.NC).permute(3, 0, 1, 2).unsqueeze(0))
+            voff += nv
+        return res
+
+
+def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
+    """enqueue the six ragged launches of a planned mask-head batch; no host work besides the launches"""
+    scene = _dev(scene, "scene")
+    if scene.dim() != 5 or scene.shape[0] != 1 or scene.shape[1] != 2 or scene.stride(4) != 1:
+        raise _lib.Sis3dError("mask_head_batched expects the planar (1,2,X,Y,Z) grid")
+    n, C, NC = plan.n, plan.C, plan.NC
+    st = scene.stride()
+    check(lib().sis3d_conv3d_planar2_ragged(_ptr(scene), st[1], st[2], st[3], _ptr(plan.gp), n, plan.items,
+                                            _ptr(_dev(w0.detach(), "w0").contiguous()), C, EPI_RELU, _ptr(plan.a), C, _stream()),
+          "sis3d_conv3d_planar2_ragged")
+    src, dst = plan.a, plan.b
+    for pc in pcs:
+        check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(plan.g3), n,
+                                        plan.blocks, _stream()), "sis3d_conv3d_ragged")
+        src, dst = dst, src
+    check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
+                                    _ptr(plan.out), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
+    return plan.views()
+
+
 def mask_head_batched(scene, windows, w0, pcs, pc_last, sigmoid=True):
     """The MaskBackbone (lib/nets/backbones.py:236-287) on ALL detected boxes at once: one launch per layer over a
     ragged batch of crops (sis3d_conv3d_planar2_ragged + 4 x sis3d_conv3d_ragged k3 + 1 x k1).
     scene (1,2,X,Y,Z) planar; windows [(x0,y0,z0,x1,y1,z1)]; w0 = conv0 weight (64,2,3,3,3); pcs = 4 PackedConv (64->64 k3);
     pc_last = PackedConv (64->NC, k1).  Returns a list of logical (1,NC,dx,dy,dz) tensors (views of one buffer)."""
-    import numpy as np
-    scene = _dev(scene, "scene")
-    if scene.dim() != 5 or scene.shape[0] != 1 or scene.shape[1] != 2 or scene.stride(4) != 1:
-        raise _lib.Sis3dError("mask_head_batched expects the planar (1,2,X,Y,Z) grid")
-    n = len(windows)
-    if n == 0:
+    if len(windows) == 0:
         return []
-    dev = scene.device
-    C, NC = pcs[0].cout, pc_last.cout
-    bx, by, bz, ng = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
-    check(lib().sis3d_ragged_tiling(C, C, 3, ctypes.byref(bx), ctypes.byref(by), ctypes.byref(bz), ctypes.byref(ng)), "sis3d_ragged_tiling")
-    bx, by, bz, ng = bx.value, by.value, bz.value, ng.value
-    rdt, pdt = _rag_dtypes()
-    w = np.asarray(windows, dtype=np.int64).reshape(n, 6)
-    ext = w[:, 3:] - w[:, :3]                                     # (n,3) crop sizes
-    nbk = -(-ext // np.array([bx, by, bz]))                       # bricks per axis
-    nvox = ext.prod(1)
-    voffs = np.concatenate([[0], np.cumsum(nvox)])                # voxel offset of every crop in the packed buffers
-    blks = np.concatenate([[0], np.cumsum(nbk.prod(1) * ng)])
-    d3 = np.zeros(n, dtype=rdt)
-    d1 = np.zeros(n, dtype=rdt)
-    dp = np.zeros(n, dtype=pdt)
-    for d, ostr in ((d3, C), (d1, NC)):
-        d["X"], d["Y"], d["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
-        d["nbx"], d["nby"], d["nbz"] = nbk[:, 0], nbk[:, 1], nbk[:, 2]
-        d["block0"] = blks[:-1]
-        d["in_off"] = voffs[:-1] * C
-        d["out_off"] = voffs[:-1] * ostr
-    dp["x0"], dp["y0"], dp["z0"] = w[:, 0], w[:, 1], w[:, 2]
-    dp["dx"], dp["dy"], dp["dz"] = ext[:, 0], ext[:, 1], ext[:, 2]
-    dp["t0"] = voffs[:-1] * (C // 4)
-    dp["out_off"] = voffs[:-1] * C
-    voff, blk, t0 = int(voffs[-1]), int(blks[-1]), int(voffs[-1]) * (C // 4)
-    dims = [tuple(int(v) for v in e) for e in ext]
-    # ONE upload for the three descriptor tables (each is a blocking pageable copy)
-    parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1)]
-    pad = [(-p.size) % 16 for p in parts]
-    host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
-    devbuf = torch.from_numpy(host).to(dev)
-    o1 = parts[0].size + pad[0]
-    o2 = o1 + parts[1].size + pad[1]
-    g3, g1, gp = devbuf[:o1], devbuf[o1:o2], devbuf[o2:]
-    a = torch.empty(voff, C, device=dev)
-    b = torch.empty(voff, C, device=dev)
-    out = torch.empty(voff, NC, device=dev)
-    st = scene.stride()
-    check(lib().sis3d_conv3d_planar2_ragged(_ptr(scene), st[1], st[2], st[3], _ptr(gp), n, t0, _ptr(_dev(w0.detach(), "w0").contiguous()), C,
-                                            EPI_RELU, _ptr(a), C, _stream()), "sis3d_conv3d_planar2_ragged")
-    src, dst = a, b
-    for pc in pcs:
-        check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(g3), n, blk,
-                                        _stream()), "sis3d_conv3d_ragged")
-        src, dst = dst, src
-    check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
-                                    _ptr(out), NC, _ptr(g1), n, blk, _stream()), "sis3d_conv3d_ragged")
-    res, voff = [], 0
-    for dx, dy, dz in dims:
-        nv = dx * dy * dz
-        res.append(out[voff:voff + nv].view(dx, dy, dz, NC).permute(3, 0, 1, 2).unsqueeze(0))
-        voff += nv
-    return res
+    plan = MaskPlan(windows, pcs[0].cout, pc_last.cout, _dev(scene, "scene").device)
+    return mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid)
 
 
 def maxpool3(x, out=None, out_coff=0):

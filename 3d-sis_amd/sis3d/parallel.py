@@ -39,11 +39,13 @@ def pack_block(records, num, origin):
     return torch.cat([n, rows.reshape(-1)])
 
 
-def gather_blocks(local_blocks, n_chunks, k_rows, group=None):
+def gather_blocks(local_blocks, n_chunks, k_rows, group=None, solo=False):
     """local_blocks: list of flat blocks for this rank's chunks (ascending chunk id).  Returns a
-    (n_chunks, block_floats) tensor ordered by chunk id, identical on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    (n_chunks, block_floats) tensor ordered by chunk id, identical on every rank.  solo: a world of one whatever
+    process group exists (no collective)."""
+    live = dist.is_initialized() and not solo
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
     per_rank = (n_chunks + world - 1) // world
     bf = block_floats(k_rows)
     ref = local_blocks[0] if local_blocks else None
@@ -108,13 +110,14 @@ def mask_windows_of(rows, origin, class_thresh):
     return out
 
 
-def scene_masks(recs, keep, chunk_ids, chunks, mask_fn, class_thresh, group=None):
+def scene_masks(recs, keep, chunk_ids, chunks, mask_fn, class_thresh, group=None, solo=False):
     """Instance masks of the detections that survived the whole-scene NMS, computed where the data lives: a detection
     belongs to the chunk that produced it (its box is clipped to that chunk), so the owner rank of the chunk crops its own
     grid -- no voxel data crosses ranks.  mask_fn(payload, windows, classes) -> list of binary masks.
     Returns {position in `keep`: (window in SCENE voxels, mask)} for this rank's chunks only."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    live = dist.is_initialized() and not solo
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
     kept = recs[keep].detach().cpu()
     kcid = chunk_ids[keep].detach().cpu()
     out = {}

@@ -11,8 +11,11 @@ from .engine import PipelinedEngines
 
 
 class SceneRunner:
-    def __init__(self, net, dims, use_graph=True, inflight=3):
+    def __init__(self, net, dims, use_graph=True, inflight=3, solo=False):
+        """solo: behave as a world of one even when a process group exists (the 1-GPU reference point bench.py takes on
+        rank 0 inside an N-rank run); no collective is issued"""
         self.net = net
+        self.solo = bool(solo)
         self.k_rows = int(net.cfg.TEST.RPN_POST_NMS_TOP_N)
         self.pipes = PipelinedEngines(net, inflight, dims=dims, stage="detect", use_graph=use_graph).prepare()
 
@@ -31,8 +34,9 @@ class SceneRunner:
         ranks' chunks may carry None).  -> (records (N,16) sorted by score, keep LongTensor) on the GPU, identical on
         every rank; with_masks adds this rank's {position in keep: (scene window, mask)} (parallel.scene_masks)."""
         thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
-        world = dist.get_world_size(group) if dist.is_initialized() else 1
-        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        live = dist.is_initialized() and not self.solo
+        world = dist.get_world_size(group) if live else 1
+        rank = dist.get_rank(group) if live else 0
         n_chunks = len(chunks)
         main = torch.cuda.current_stream()
         local = []
@@ -52,9 +56,10 @@ class SceneRunner:
                 blk.record_stream(main)
                 local.append(blk)
             self.pipes.join()
-            blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group)
+            blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group, solo=self.solo)
             if not with_masks:
                 return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep)
             recs, keep, cids = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, with_chunk_ids=True)
-            masks = parallel.scene_masks(recs, keep, cids, chunks, self.mask_fn, float(self.net.cfg.CLASS_THRESH), group)
+            masks = parallel.scene_masks(recs, keep, cids, chunks, self.mask_fn, float(self.net.cfg.CLASS_THRESH), group,
+                                         solo=self.solo)
             return recs, keep, masks

@@ -1,36 +1,49 @@
 #!/usr/bin/env python
 """bench.py -- voxels/sec of the 3D-SIS forward hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload backbone_rpn|detect|images] [--no-graph]
+    python bench.py --gpus N --steps K --warmup W [--workload auto|backbone_rpn|detect|images|scene] [--masks]
 
-One process per GPU (for N>1 the driver launches this under torch.distributed.run; RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* come from the env).  A step = one pass of the hot path over one batch of
-`--inflight` (default 3) independent synthetic 96x48x96 chunks per rank, each on its own HIP stream / captured
-graph, inputs already resident in HBM (static buffers of the ChunkEngine); weights
-are seeded synthetic (no checkpoints exist offline).  Chunks are independent, so ranks share nothing
-on the data path (scaling: weak); the per-scene proposal all-gather is exercised by `--workload scene`.
+One process per GPU.  Under `python -m torch.distributed.run` (how the driver starts N > 1) RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the env; started directly with `--gpus N`, N > 1, this script launches the N ranks
+itself (re-exec under torch.distributed.run, rendezvous on 127.0.0.1) and FAILS if the box has fewer than N GPUs --
+it never silently reports a smaller world.
+
+Workloads (`--workload auto` = backbone_rpn at N = 1, scene at N > 1):
+  backbone_rpn  BASELINE config[1]: one 96x48x96 geometry-only chunk per pipeline, HIP backbone + RPN; a step = one pass
+                over `--inflight` (default 3) independent chunks per GPU, each on its own HIP stream / captured graph, inputs
+                resident in HBM.  Ranks share nothing (scaling: weak).
+  detect        config[2]: + decode / top-k / NMS / RoI pooling / classifier (+ `--masks`: mask head on a fixed
+                deterministic detection set).
+  images        config[3]: 5-view back-projection + colour/geometry backbone + RPN.
+  scene         config[4]: a 32-chunk scene (4 x 1 x 8 grid of 96x48x96 tiles), chunk c -> rank c mod N, per-chunk detection,
+                ONE RCCL all_gather_into_tensor of the record blocks, whole-scene 3D NMS on every rank.  A step = one scene
+                (scaling: strong).  The line also carries `chunk_pipeline` (the config[1] workload run on all ranks at once
+                = the weak-scaling figure comparable with the N = 1 `value`) and `scene_single_gpu` (rank 0 alone on the
+                same scene in the same process), so 1 -> N scaling can be read off one line.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     -- dominant kernel (the k3 128->256 RPN conv, 12.2 GFLOP/launch): achieved = algorithmic FLOPs /
-                  mean launch duration measured live with HIP events on the launch stream; peak = 157.3 TF
-                  (fp32 MFMA == fp32 vector peak of gfx950).  The HBM-roof fraction of the whole step is given
-                  beside it (the metric's "% HBM roofline"): algorithmic bytes per chunk / step time / 8 TB/s.
-  cpu_baseline -- the CPU oracle (torch-CPU operators = what the reference's MAX_VOLUME=0 path runs) timed on
-                  this box's host cores on a bounded sample, rank 0 at N=1 only.
+  roofline     -- dominant kernel (the k3 128->256 RPN conv, 12.23 GFLOP/launch): achieved = algorithmic FLOPs / mean
+                  launch duration measured live with HIP events on the launch stream; peak = 157.3 TF (fp32 MFMA).
+  stages       -- N = 1: the backbone proper and backbone+RPN of ONE chunk alone on the GPU (captured graph, back-to-back
+                  replays on one stream, HIP events): ms, fraction of the fp32 roof and of the 8 TB/s HBM roof.
+  cpu_baseline -- the CPU oracle (torch-CPU operators = what the reference's MAX_VOLUME=0 path runs) timed on this box's
+                  host cores on a bounded sample, per stage, at the best thread count and at 1 thread; rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
 
-import torch  # noqa: E402
-
 VOXELS = 96 * 48 * 96
 # algorithmic work per chunk
+BACKBONE = dict(bytes=201.6e6, flops=17.72e9)
+RPN = dict(bytes=59.8e6, flops=24.86e9)
 ALGO = {
     "backbone_rpn": dict(bytes=261.4e6, flops=42.58e9),
     "detect": dict(bytes=261.4e6 + 2 * 3.54e6 + 200 * 32768 + 8.4e6, flops=42.58e9 + 0.9e9),
@@ -40,27 +53,113 @@ ALGO = {
 DOMINANT_FLOPS = 2.0 * 6912 * 256 * 128 * 27        # rpn_net_level{1,2}: 12.23 GFLOP per launch
 FP32_PEAK_TF = 157.3
 HBM_PEAK_GBS = 8000.0
+WORKLOAD_TEXT = {
+    "backbone_rpn": "config[1]: one 96x48x96 chunk per pipeline, geometry-only, HIP 3D-conv backbone + RPN (convs, heads, "
+                    "softmax), weights seeded synthetic",
+    "detect": "config[2]: backbone + RPN + decode/sort/NMS + RoI pooling + classifier",
+    "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN",
+    "scene": "config[4]: 32-chunk scene sharded chunk->rank, per-chunk detection, one RCCL all-gather of record blocks, "
+             "whole-scene 3D NMS on every rank",
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="backbone_rpn", choices=["backbone_rpn", "detect", "images", "scene"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
                     "measured best: 3")
-    ap.add_argument("--masks", action="store_true", help="scene workload: also run the mask head on the detections that survive "
-                    "the whole-scene NMS (each on the chunk / rank that produced it)")
+    ap.add_argument("--masks", action="store_true", help="detect: also run the mask head (config[2] in full) on a fixed "
+                    "deterministic detection set; scene: mask the detections that survive the whole-scene NMS, each on the "
+                    "chunk / rank that produced it")
+    ap.add_argument("--mask-boxes", type=int, default=16, help="detect --masks: number of post-NMS RoIs taken as detections")
+    ap.add_argument("--scene-chunks", type=int, default=32)
     ap.add_argument("--group", type=int, default=1, help="chunks per captured graph (2: the pair's four RPN convs in one launch)")
     ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
                     "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    return ap.parse_args()
+    ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # launch / rendezvous logic under gloo, no GPU
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ launching N ranks --
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(n, argv, port=None):
+    """the command that starts n ranks of this script on this node (one per GPU, rendezvous on the loopback address)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: check the box, then start the N ranks ourselves"""
+    if not args.selftest_cpu:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to run a smaller world\n"
+                             % (args.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16) // args.gpus))))
+    return subprocess.call(launch_command(args.gpus, argv), env=env)
+
+
+def emit(line):
+    """the JSON line must be the LAST thing on stdout: RCCL printf()s a version banner into C stdio's buffer, which would
+    otherwise be flushed at exit, after our line"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
+def selftest_cpu(args, rank, world):
+    """The launch / rendezvous / sharding / max-over-ranks logic of the N > 1 bench on CPU under gloo: the scene gather with
+    synthetic record blocks instead of GPU detections.  Used by tests/test_bench_launch.py; prints the same kind of line."""
+    import torch
+    import torch.distributed as dist
+    from sis3d import parallel
+    dist.init_process_group("gloo")
+    k_rows, n_chunks = 8, args.scene_chunks
+    local = []
+    for c in parallel.shard_chunks(n_chunks, rank, world):
+        g = torch.Generator().manual_seed(c)
+        rec = torch.rand(k_rows, parallel.RECORD_WIDTH, generator=g)
+        local.append(parallel.pack_block(rec, 3 + c % 5, (96.0 * (c % 4), 0.0, 96.0 * (c // 4))))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        blocks = parallel.gather_blocks(local, n_chunks, k_rows)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    recs, _ = parallel.merge_scene(blocks, k_rows, lambda b, th: torch.arange(b.shape[0]), 0.1)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        emit({"metric": "selftest (gloo, CPU): record all-gather only", "value": n_chunks * args.steps / float(t.item()),
+              "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "selftest": True,
+              "config": {"scene_chunks": n_chunks, "records": int(recs.shape[0])}})
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------- GPU workloads --
 def build_net(workload, masks=False):
     from sis3d import config, synthetic
     from sis3d.nets import backbones
@@ -79,6 +178,7 @@ def time_dominant_kernel(net, iters=50):
     """mean duration of the rpn_net k3 128->256 conv launch (12.23 GFLOP), HIP events on the launch (current) stream.
     Runs BEFORE any graph is captured, on its own input: on ROCm 7.2 eager launches of these kernels between replays
     of a captured graph were observed to fault the next replay, so the bench never interleaves them."""
+    import torch
     from sis3d import ops
     x = ops.new_act(128, (24, 12, 24), torch.device("cuda"))
     x.normal_().clamp_(min=0)                      # post-ReLU-like activations
@@ -95,18 +195,70 @@ def time_dominant_kernel(net, iters=50):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def time_stages(net, reps=60):
+    """ONE chunk alone on the GPU: captured graph of the backbone proper and of backbone+RPN, `reps` back-to-back replays
+    on one stream bracketed by HIP events -> ms per chunk.  The difference is the RPN (convs + heads + softmax)."""
+    import torch
+    from sis3d import synthetic
+    from sis3d.engine import ChunkEngine
+    out = {}
+    data = synthetic.synth_chunk(0)
+    for stage in ("backbone", "rpn"):
+        eng = ChunkEngine(net, stage=stage)
+        eng.load(data)
+        eng.prepare(warmup=2)
+        for _ in range(10):
+            eng.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            eng.run()
+        e1.record()
+        torch.cuda.synchronize()
+        out[stage] = e0.elapsed_time(e1) / reps
+        del eng
+    b, full = out["backbone"], out["rpn"]
+    r = max(full - b, 1e-6)
+
+    def frac(ms, algo):
+        return {"ms": ms, "fp32_frac": algo["flops"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                "hbm_frac": algo["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "voxels_per_s": VOXELS / (ms * 1e-3)}
+    return {"backbone": dict(frac(b, BACKBONE), algo_gflop=BACKBONE["flops"] / 1e9, algo_mb=BACKBONE["bytes"] / 1e6),
+            "rpn": dict(frac(r, RPN), algo_gflop=RPN["flops"] / 1e9, algo_mb=RPN["bytes"] / 1e6),
+            "backbone_rpn": frac(full, ALGO["backbone_rpn"]),
+            "how": "one chunk alone: captured graph, %d back-to-back replays on one stream, HIP events; rpn = backbone_rpn - backbone; "
+                   "binding roof is fp32 MFMA (157.3 TF), hbm_frac is against 8 TB/s with the algorithmic bytes" % reps}
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, KB -> B; profiles/r01_pmc_rpn_net.json).  Counters cannot be read from inside the bench."""
+    correction + WRITE_SIZE, KB -> B).  Counters cannot be read from inside the bench."""
+    for name in ("r02_pmc_rpn_net.json", "r01_pmc_rpn_net.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["traffic_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
+
+
+def cpu_model():
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_rpn_net.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
 
 
 def cpu_baseline(workload, sd, cfg, seconds):
-    """the oracle's backbone+RPN (torch CPU operators, as the reference's CPU path) on the host cores"""
+    """The oracle (torch-CPU operators, as the reference's MAX_VOLUME=0 path) on the host cores: the workload's forward at the
+    best thread count of a short sweep (the headline `value`) and at 1 thread, plus a per-stage table."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sis3d_oracle as orc
     from sis3d import config, synthetic
@@ -119,7 +271,7 @@ def cpu_baseline(workload, sd, cfg, seconds):
 
     def one():
         with torch.no_grad():
-            if workload == "detect":
+            if workload in ("detect", "scene"):
                 net.forward(data, feats, i3d, i2d)
             else:
                 imageft = orc.project_views_max(feats, i3d, i2d, data.shape[2:]) if workload == "images" else None
@@ -127,102 +279,86 @@ def cpu_baseline(workload, sd, cfg, seconds):
                 net.rpn(l1, 1)
                 net.rpn(l2, 2)
 
-    # oneDNN does not scale to hundreds of threads on a 0.02-GFLOP/voxel workload: pick the best of a short sweep
+    def timed(fn, budget, max_n=400):
+        fn()
+        n, t0 = 0, time.time()
+        while True:
+            fn()
+            n += 1
+            if time.time() - t0 >= budget or n >= max_n:
+                break
+        return (time.time() - t0) / n, n
+
+    # oneDNN does not scale to hundreds of threads on a 0.1-GFLOP/voxel workload: pick the best of a short sweep
     best_t, best = None, None
     for t in [c for c in (16, 32, 64, 128) if c <= cores] or [cores]:
         torch.set_num_threads(t)
-        one()
-        t0 = time.time()
-        one()
-        one()
-        d = (time.time() - t0) / 2
+        d, _ = timed(one, 0.0, 2)
         if best is None or d < best:
             best_t, best = t, d
         if d > 2.0 * best:
             break
     torch.set_num_threads(best_t)
-    n, t0 = 0, time.time()
-    while True:
-        one()
-        n += 1
-        if time.time() - t0 >= seconds or n >= 400:
-            break
-    dt = time.time() - t0
-    cores_used = best_t
-    return dict(value=VOXELS * n / dt, unit="voxels/s", cores=cores_used, kind="port", host_cores=cores,
+    per, n = timed(one, seconds * 0.5)
+    # per-stage table at the best thread count, then the whole forward at one thread
+    stages = {}
+    with torch.no_grad():
+        l1, l2 = net.backbone(data, None) if workload != "images" else net.backbone(data, orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
+        o = None
+        if not cfg["USE_IMAGES"]:
+            o = net.forward(data)
+        share = seconds * 0.3 / 6.0
+
+        def st(name, fn, unit_work=VOXELS):
+            d, k = timed(lambda: fn(), share, 50)
+            stages[name] = {"ms": d * 1e3, "threads": best_t, "runs": k}
+        if workload != "images":
+            st("backbone", lambda: net.backbone(data, None))
+        st("rpn_convs_heads", lambda: (net.rpn(l1, 1), net.rpn(l2, 2)))
+        if o is not None:
+            levels = []
+            for lid, feat in ((1, l1), (2, l2)):
+                anchors = torch.from_numpy(orc.generate_anchors(feat.shape[2:], net.stride, net.anchor_sizes[lid]))
+                levels.append((lid, o["rpn_cls_prob_level%d" % lid], o["rpn_bbox_pred_level%d" % lid], anchors))
+            tc = cfg["TEST"]
+            st("proposal_layer_cpu_nms", lambda: orc.proposal_layer(levels, tuple(data.shape[2:]), tc["RPN_PRE_NMS_TOP_N"],
+                                                                    tc["RPN_POST_NMS_TOP_N"], tc["RPN_NMS_THRESH"], cfg["ALLOW_BORDER"]))
+            rois, lv = o["rois"][0], o["level_inds"][0]
+            st("roi_pool_c", lambda: net.roi_pool_layer(l1, l2, rois, lv))
+            stages["roi_pool_c"]["rois"] = int(rois.shape[0])
+            if "pool5" in o:
+                st("classifier", lambda: net.classify(o["pool5"]))
+            if any(k.startswith("mask_backbone") for k in net.sd):
+                crop = data[:, :, 8:38, 6:36, 10:46].contiguous()
+                st("mask_head_30x30x36_crop", lambda: net.mask_backbone(crop))
+        if feats is not None:
+            st("projection_view_max", lambda: orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
+    torch.set_num_threads(1)
+    per1, n1 = timed(one, seconds * 0.2, 3)
+    torch.set_num_threads(best_t)
+    return dict(value=VOXELS / per, unit="voxels/s", cores=best_t, kind="port", host_cores=cores, cpu=cpu_model(),
+                single_thread={"value": VOXELS / per1, "unit": "voxels/s", "cores": 1, "runs": n1},
+                stages=stages,
                 sample="%d forward passes of one 96x48x96 chunk (%s; oracle = the reference's CPU operators via torch-CPU/oneDNN, "
-                       "%d threads, best of a 16/32/64/128 sweep) in %.1f s" % (n, workload, cores_used, dt))
+                       "%d threads, best of a 16/32/64/128 sweep) in %.1f s; stages: per-stage means at the same thread count; "
+                       "single_thread: %d passes" % (n, workload, best_t, per * n, n1))
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch.distributed as dist
-    use_dist = world > 1 or bool(os.environ.get("SIS3D_FORCE_DIST"))     # FORCE: exercise the RCCL path on one GPU
-    if world > 1:
-        # N ranks share one host: keep each rank's torch-CPU helpers (synthetic inputs, weight init) from spawning a thread
-        # per core each; the timed path is GPU-only
-        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    from sis3d import synthetic, ops
+def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):
+    """weak-scaling workloads: `inflight` independent chunks per GPU per step -> dict(dt, vox_per_step, single_ms, extra)"""
+    import torch
+    from sis3d import synthetic
     from sis3d.engine import PipelinedEngines
-    ops.lib()
-    net, cfg, sd = build_net(args.workload, masks=args.masks)
-    kt = time_dominant_kernel(net) if rank == 0 else 0.0
-    dbg = bool(os.environ.get("SIS3D_BENCH_DEBUG"))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    single_ms = None
-    if args.inflight <= 0:
-        args.inflight = 3
-    if args.workload == "scene":
-        # BASELINE config 5: 32 chunks of one scene (4 x 1 x 8 grid of 96x48x96 tiles), chunk c -> rank c mod W, per-chunk
-        # detection, ONE all-gather of the record blocks, whole-scene NMS on every rank.  A step = one whole scene.
-        from sis3d.scene import SceneRunner
-        n_chunks = 32
-        runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph, inflight=args.inflight)
-        chunks = []
-        for c in range(n_chunks):
-            payload = synthetic.synth_chunk(c).cuda() if c % world == rank else None     # resident in HBM, own shard only
-            chunks.append((c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), payload))
-        torch.cuda.synchronize()
-        for _ in range(max(1, args.warmup // 10)):
-            res = runner.infer(chunks, with_masks=args.masks)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = runner.infer(chunks, with_masks=args.masks)
-        barrier()
-        recs, keep = res[0], res[1]
-        dt = time.perf_counter() - t0
-        nfl, vox_per_step = 1, n_chunks * VOXELS
-        extra_cfg = {"scene_chunks": n_chunks, "records": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel())}
-        if args.masks:
-            extra_cfg["masks_on_this_rank"] = len(res[2])
-            extra_cfg["mask_voxels_on_this_rank"] = int(sum(m.numel() for _, m in res[2].values()))
-    else:
-        stage = "rpn" if args.workload in ("backbone_rpn", "images") else "detect"
-        nfl = max(1, args.inflight)
-        from_depth = args.workload == "images" and args.from_depth
-        grp = max(1, args.group)
-        eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph, group=grp, **({"from_depth": True} if from_depth else {}))
-        for i in range(nfl):
-          for g in range(grp):
+    stage = "rpn" if workload in ("backbone_rpn", "images") else "detect"
+    nfl = max(1, args.inflight)
+    from_depth = workload == "images" and args.from_depth
+    grp = max(1, args.group)
+    kw = {"from_depth": True} if from_depth else {}
+    if masks:
+        kw["mask_boxes"] = args.mask_boxes
+    eng = PipelinedEngines(net, nfl, stage=stage, use_graph=not args.no_graph, group=grp, **kw)
+    for i in range(nfl):
+        for g in range(grp):
             cid = (rank * nfl + i) * grp + g
             data = synthetic.synth_chunk(cid)
             if from_depth:
@@ -230,60 +366,176 @@ def main():
                 depth, c2w, w2g = synthetic.synth_cameras(cid, feats.shape[0], voxel_size=cfg.VOXEL_SIZE)
                 with torch.cuda.stream(eng.streams[i]):
                     eng.engines[i].load_views(data, feats, depth, c2w, w2g, slot=g)
-            elif args.workload == "images":
+            elif workload == "images":
                 feats, i3d, i2d = synthetic.synth_views(cid)
                 eng.load(i, data, feats, i3d, i2d, slot=g)
             else:
                 eng.load(i, data, slot=g)
-        eng.prepare(warmup=2)
-        if dbg:
-            print("[bench] prepared", file=sys.stderr, flush=True)
-        for _ in range(args.warmup):
-            eng.run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.run()
-        barrier()
-        dt = time.perf_counter() - t0
-        vox_per_step = world * nfl * grp * VOXELS
-        extra_cfg = {"chunks_per_graph": grp}
-        if from_depth:
+    eng.prepare(warmup=2)
+    for _ in range(args.warmup):
+        eng.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+    barrier()
+    dt = time.perf_counter() - t0
+    extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl}
+    if from_depth:
+        torch.cuda.synchronize()
+        extra.update({"views_from": "depth maps + poses (lists computed on device inside the step)",
+                      "visible_voxels_per_view": eng.engines[0].view_counts()})
+    if masks:
+        torch.cuda.synchronize()
+        extra.update(eng.engines[0].mask_stats())
+    single_ms = None
+    if rank == 0:
+        # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            eng.run(0)
             torch.cuda.synchronize()
-            extra_cfg = {"chunks_per_graph": grp, "views_from": "depth maps + poses (lists computed on device inside the step)",
-                         "visible_voxels_per_view": eng.engines[0].view_counts()}
-        if rank == 0:
-            # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                eng.run(0)
-                torch.cuda.synchronize()
-            single_ms = (time.perf_counter() - t1) / 50 * 1e3
+        single_ms = (time.perf_counter() - t1) / 50 * 1e3
+    return dict(dt=dt, vox_per_step=world * nfl * grp * VOXELS, single_ms=single_ms, extra=extra)
+
+
+def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None, inflight=None):
+    """BASELINE config 5: n_chunks chunks of one scene (4 x 1 x n/4 grid of 96x48x96 tiles), chunk c -> rank c mod W,
+    per-chunk detection, ONE all-gather of the record blocks, whole-scene NMS on every rank.  A step = one whole scene."""
+    import torch
+    from sis3d import synthetic
+    from sis3d.scene import SceneRunner
+    gw = 1 if group == "solo" else world
+    gr = 0 if group == "solo" else rank
+    n_local = len(range(gr, n_chunks, gw))
+    nfl = inflight or (args.inflight if args.inflight > 0 else (n_local if n_local <= 4 else 3))
+    runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph, inflight=max(1, nfl), solo=(group == "solo"))
+    chunks = []
+    for c in range(n_chunks):
+        payload = synthetic.synth_chunk(c).cuda() if c % gw == gr else None     # resident in HBM, own shard only
+        chunks.append((c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), payload))
+    torch.cuda.synchronize()
+    steps = steps or args.steps
+    for _ in range(max(1, min(args.warmup, steps) // 5)):
+        res = runner.infer(chunks, with_masks=args.masks)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = runner.infer(chunks, with_masks=args.masks)
+    barrier()
+    dt = time.perf_counter() - t0
+    recs, keep = res[0], res[1]
+    extra = {"scene_chunks": n_chunks, "chunks_on_this_rank": n_local, "streams_per_gpu": nfl,
+             "records_gathered": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel())}
+    if args.masks:
+        extra["masks_on_this_rank"] = len(res[2])
+        extra["mask_voxels_on_this_rank"] = int(sum(m.numel() for _, m in res[2].values()))
+    return dict(dt=dt, vox_per_step=n_chunks * VOXELS, single_ms=None, extra=extra, steps=steps)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args, argv)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a mismatched n_gpus\n"
+                         % (args.gpus, world))
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        sys.stderr.write("bench.py: rank %d needs GPU %d, this box exposes %d\n" % (rank, local, torch.cuda.device_count()
+                                                                                       if torch.cuda.is_available() else 0))
+        return 2
+    use_dist = world > 1 or bool(os.environ.get("SIS3D_FORCE_DIST"))     # FORCE: exercise the RCCL path on one GPU
+    if world > 1:
+        # N ranks share one host: keep each rank's torch-CPU helpers (synthetic inputs, weight init) from spawning a thread
+        # per core each; the timed path is GPU-only
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
+    torch.cuda.set_device(local)
     if use_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    workload = args.workload
+    if workload == "auto":
+        workload = "backbone_rpn" if world == 1 else "scene"
+    if args.inflight <= 0 and workload != "scene":
+        args.inflight = 3
+
+    from sis3d import ops
+    ops.lib()
+    net, cfg, sd = build_net(workload, masks=args.masks)
+    kt = time_dominant_kernel(net) if rank == 0 else 0.0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if not use_dist:
+            return dt
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms = dt / args.steps * 1e3
-    value = vox_per_step * args.steps / dt
+        return float(t.item())
 
+    stages = None
+    if rank == 0 and world == 1 and workload == "backbone_rpn" and not args.no_stages and not args.no_graph:
+        stages = time_stages(net)
+    side = {}
+    if workload == "scene":
+        if world > 1 and not args.masks:
+            # the N = 1 workload on every rank at once: the weak-scaling figure comparable with the N = 1 `value`
+            saved = args.inflight
+            args.inflight = 3
+            cp = run_chunk_pipeline(net, cfg, args, rank, world, "backbone_rpn", barrier)
+            args.inflight = saved
+            cdt = max_over_ranks(cp["dt"])
+            side["chunk_pipeline"] = {"workload": WORKLOAD_TEXT["backbone_rpn"], "value": cp["vox_per_step"] * args.steps / cdt,
+                                      "unit": "voxels/s", "scaling": "weak", "ms_per_step": cdt / args.steps * 1e3,
+                                      "chunks_per_step_per_gpu": 3, "single_chunk_latency_ms": cp["single_ms"]}
+        res = run_scene(net, args, rank, world, args.scene_chunks, barrier)
+        dt = max_over_ranks(res["dt"])
+        if world > 1 and rank == 0 and not args.masks:
+            # rank 0 alone on the same scene, same process: the 1-GPU reference point of the strong-scaling figure
+            solo = run_scene(net, args, 0, 1, args.scene_chunks, lambda: torch.cuda.synchronize(), group="solo",
+                             steps=max(3, min(20, args.steps // 10)))
+            sv = solo["vox_per_step"] * solo["steps"] / solo["dt"]
+            side["scene_single_gpu"] = {"value": sv, "unit": "voxels/s", "ms_per_scene": solo["dt"] / solo["steps"] * 1e3,
+                                        "steps": solo["steps"], "how": "rank 0 alone, same scene, same process, no collective"}
+    else:
+        res = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
+        dt = max_over_ranks(res["dt"])
+    ms = dt / args.steps * 1e3
+    value = res["vox_per_step"] * args.steps / dt
+
+    line = None
     if rank == 0:
-        nchunk_step = vox_per_step / VOXELS / world           # chunks per GPU per step
-        algo = {k: v * nchunk_step for k, v in ALGO[args.workload].items()}
+        nchunk_step = res["vox_per_step"] / VOXELS / world           # chunks per GPU per step
+        algo = {k: v * nchunk_step for k, v in ALGO[workload].items()}
+        if "scene_single_gpu" in side:
+            side["scene_speedup_vs_1gpu"] = value / side["scene_single_gpu"]["value"]
         line = {
             "metric": "voxels/sec forward on 96x48x96 chunks",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": ("strong" if args.workload == "scene" else "weak"), "vs_baseline": None,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": ("strong" if workload == "scene" else "weak"), "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"backbone_rpn": "config[1]: one 96x48x96 chunk per GPU, geometry-only, HIP 3D-conv backbone + RPN "
-                                                    "(convs, heads, softmax), weights seeded synthetic",
-                                    "detect": "config[2] minus mask head: backbone + RPN + decode/sort/NMS + RoI pooling + classifier",
-                                    "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN",
-                                    "scene": "config[4]: 32-chunk scene sharded chunk->rank, per-chunk detection, one RCCL all-gather of "
-                                             "record blocks, whole-scene 3D NMS on every rank"}[args.workload],
+            "config": {"workload": WORKLOAD_TEXT[workload] + (" + mask head" if args.masks else ""),
                        "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world,
-                       "chunks_per_step_per_gpu": nchunk_step, "streams_per_gpu": nfl, "single_chunk_latency_ms": single_ms, **extra_cfg},
-            "roofline": {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,1,...> rpn_net 128->256 (fp32 v_mfma_f32_32x32x2_f32)",
+                       "chunks_per_step_per_gpu": nchunk_step, "single_chunk_latency_ms": res["single_ms"], **res["extra"]},
+            "roofline": {"bound": "mfma", "kernel": "rpn_net k3 128->256 conv (exact fp32 MFMA)",
                          "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": DOMINANT_FLOPS / kt / 1e12 / FP32_PEAK_TF, "traffic": pmc_traffic(),
                          "launch_us": kt * 1e6},
@@ -292,23 +544,18 @@ def main():
                               "fp32_frac": algo["flops"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
                               "binding": "fp32 FLOPs (AI 163 FLOP/B >> 20 FLOP/B machine balance)"},
         }
+        line.update(side)
+        if stages is not None:
+            line["stages"] = stages
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, sd, cfg, args.cpu_seconds)
-        out_line = json.dumps(line)
+            line["cpu_baseline"] = cpu_baseline(workload, sd, cfg, args.cpu_seconds)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # the JSON line must be the LAST thing on stdout: RCCL printf()s a version banner into C stdio's buffer, which
-        # would otherwise be flushed at exit, after our line
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(out_line, flush=True)
+        emit(line)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

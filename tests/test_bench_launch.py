@@ -1,0 +1,58 @@
+"""bench.py's N > 1 entry: `python bench.py --gpus N` must itself start N ranks, and must never
+report a smaller world than it was asked for.  The launch / rendezvous / record all-gather / max-over-ranks logic runs
+here on CPU under gloo (`--selftest-cpu`, the GPU workloads replaced by synthetic record blocks)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_gpus_2_self_launches_two_ranks_gloo():
+    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--scene-chunks", "8", "--selftest-cpu"])
+    assert rc == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out                                  # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["selftest"] is True
+    assert d["config"]["records"] == sum(3 + c % 5 for c in range(8))     # every chunk of both ranks arrived
+    assert out.strip().splitlines()[-1] == lines[0]              # ... and it is the last thing on stdout
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has >= 2 GPUs")
+def test_gpus_2_without_two_gpus_fails_loudly():
+    rc, out, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert rc != 0
+    assert "refusing" in err and "--gpus 2" in err
+    assert not [ln for ln in out.splitlines() if ln.startswith("{")]       # no line claiming n_gpus: 1
+
+
+def test_world_size_mismatch_is_refused():
+    rc, out, err = _run(["--gpus", "2", "--selftest-cpu"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and "mismatched" in err and "{" not in out
+
+
+def test_launch_command_is_one_rank_per_gpu_on_loopback():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], port=29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    # defaults: N = 1, backbone+RPN; N > 1 resolves to the scene workload (BASELINE config 5)
+    a = bench.parse([])
+    assert a.gpus == 1 and a.workload == "auto" and a.scene_chunks == 32

@@ -121,7 +121,8 @@ def test_device_tsdf_encode_matches_reference_fixture(golden, tmp_path, mode):
     assert r["data"].is_cuda and tuple(r["data"].shape) == want.shape
     assert np.array_equal(r["data"].cpu().numpy(), want)                       # bit-exact, -inf voxels included
     blobs = collate_fn([r])
-    assert ops.is_cl(blobs["data"])                                           # goes into the conv stack without a re-layout
+    # planar (1,2,X,Y,Z) with contiguous z: what the first-layer kernels (geometry1.0, mask conv0) read
+    assert blobs["data"].is_contiguous() and not ops.is_cl(blobs["data"])
     sf = scene_file.SceneFile(CHUNK)
     raw = torch.from_numpy(np.ascontiguousarray(sf.sdf)).cuda()
     planar = ops.tsdf_encode(raw, sf.dims, 3.0, "abs", want.shape[2], channels_last=False)
@@ -145,3 +146,35 @@ def test_device_tsdf_encode_chunk_size():
         raw = torch.from_numpy(np.ascontiguousarray(sdf.reshape(-1, order="F"))).cuda()
         got = ops.tsdf_encode(raw, dims, 3.0, "abs", mh)
         assert np.array_equal(got[0].cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_device_encoded_sample_runs_through_the_network(tmp_path, oracle):
+    """.chunk file -> Dataset(device_encode=True) -> collate_fn -> Network.forward on the GPU, against the oracle fed with
+    the host-encoded sample of the same file (the device-encoded layout must be one the first layer accepts)"""
+    from sis3d import config, synthetic
+    from sis3d.nets import backbones
+    rng = np.random.default_rng(11)
+    sdf = (rng.standard_normal((32, 48, 24)) * 2).astype(np.float32)
+    p = str(tmp_path / "n.chunk")
+    scene_file.write_scene_file(p, sdf, np.zeros((0, 6), np.float32), [], [], [])
+    lst = tmp_path / "l.txt"
+    lst.write_text(p + "\n")
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_MASK = False
+    cfg.LABEL_MAP = ""
+    cfg.KEEP_THRESH = 0
+    host = collate_fn([Dataset(str(lst), "chunk", cfg)[0]])
+    dev = collate_fn([Dataset(str(lst), "chunk", cfg, device_encode=True)[0]])
+    assert dev["data"].is_cuda and torch.equal(dev["data"].cpu(), host["data"])
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    sd = synthetic.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    pred = net.forward(dev, "TEST", [])
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(host["data"])
+    l1, l2 = net._net_conv
+    assert float((l1.cpu() - o["level1"]).abs().max()) <= 1e-4 and float((l2.cpu() - o["level2"]).abs().max()) <= 1e-4
+    assert float((pred["rpn_bbox_pred_level2"].cpu() - o["rpn_bbox_pred_level2"]).abs().max()) <= 1e-4
+    assert abs(pred["rois"][0].shape[0] - o["rois"][0].shape[0]) <= 2
