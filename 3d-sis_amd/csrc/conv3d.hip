@@ -592,7 +592,7 @@ int launch_cfg(ConvArgs &a, hipStream_t st)
     } else {
         if (a.ptab) return SIS3D_EUNSUPPORTED;
     }
-    if constexpr (KS != 1 && CK == 32 && NW * NTW <= 4) {
+    if constexpr ((KS != 1 && CK == 32 && NW * NTW <= 4) || (KS == 1 && CK <= 64 && NW * NTW <= 4 && MW * NW * KW <= 8)) {
         if (a.npw > 0) {
             if (PF >= 12 && pf_override == 12) return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true, 12>(a, st);
             return launch_cfg_<KS, S, BX, BY, BZ, MW, NW, KW, NTW, CK, true, 4>(a, st);
@@ -765,6 +765,34 @@ extern "C" int sis3d_conv3d_chain(const float *in, int X, int Y, int Z, int cin,
     ConvArgs a;
     a.in = in;
     return chain_common(a, X, Y, Z, cin, cin_stride, packed_w, bias, cout, ksize, stride, flags, out, out_stride, nstages, stages, stream);
+}
+
+extern "C" int sis3d_conv3d_pw_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                                     int cout, int flags, const float *residual, int res_stride, float *out, int out_stride,
+                                     int out_coff, int nstages, const sis3d_pw_stage *stages, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || X <= 0 || Y <= 0 || Z <= 0 || nstages < 0 || nstages > 1) return SIS3D_EINVAL;
+    if ((cin != 32 && cin != 64) || (cin_stride % 4) || cin_stride < cin || (cout % 32) || cout > 128) return SIS3D_EUNSUPPORTED;
+    if ((flags & SIS3D_EPI_RESIDUAL) && !residual) return SIS3D_EINVAL;
+    if (flags & (SIS3D_EPI_RPN_HEAD | SIS3D_EPI_SIGMOID)) return SIS3D_EUNSUPPORTED;
+    if (nstages == 0)
+        return sis3d_conv3d(in, X, Y, Z, cin, cin_stride, packed_w, bias, cout, 1, 1, flags, residual, res_stride, out, out_stride,
+                            out_coff, nullptr, nullptr, 0, stream);
+    ConvArgs a;
+    a.nprob = 1;
+    a.rag = nullptr; a.nrag = 0; a.ragged_blocks = 0;
+    a.npw = 1;
+    const sis3d_pw_stage &s = stages[0];
+    if (!s.packed_w || !s.out || s.cout <= 0 || (s.cout % 32) || s.cout > 128 || s.cin != cout) return SIS3D_EINVAL;
+    if (s.flags & SIS3D_EPI_RESIDUAL) return SIS3D_EUNSUPPORTED;
+    a.pw[0].wp = s.packed_w; a.pw[0].bias = s.bias; a.pw[0].res = nullptr; a.pw[0].out = s.out;
+    a.pw[0].cout = s.cout; a.pw[0].res_stride = 0; a.pw[0].out_stride = s.out_stride; a.pw[0].flags = s.flags;
+    a.in = in; a.X = X; a.Y = Y; a.Z = Z; a.cin = cin; a.cin_stride = cin_stride;
+    a.wp = packed_w; a.bias = bias; a.cout = cout; a.ntiles = cout / 32;
+    a.flags = flags; a.res = residual; a.res_stride = res_stride;
+    a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.out2 = nullptr; a.out3 = nullptr; a.anchors = 0;
+    a.OX = X; a.OY = Y; a.OZ = Z;
+    return dispatch<1, 1>(a, as_stream(stream));
 }
 
 extern "C" int sis3d_conv3d_chain_projected(const int32_t *vox2pix, const float *feat_rows, int nslots, int64_t npix, int X, int Y, int Z,

@@ -1,0 +1,344 @@
+// k3 / pad-1 3D convolution, "one workgroup per CU, one wave per SIMD" formulation for gfx950 (CDNA4).
+//
+// Replaces the cuDNN calls behind nn.Conv3d(C, C', 3, padding=1) + bias + ReLU of lib/nets/backbones.py:20-22,188-231
+// (Bottleneck.conv2, geometry2[0]) and lib/nets/network.py:40 (rpn_net_level*), where conv3d.hip's workgroup-granular
+// decomposition leaves the chip quantised: its 32x32 tiles x tap-thirds give 5.06 wave tasks per SIMD (-> 6) on the
+// 24x12x24 grid, and with every load removed it still stops at 69 % of the fp32 MFMA roof (profiles/README.md).
+//
+// Here the layer is cut so that EVERY SIMD of the chip gets the same number of matrix instructions:
+//   * implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD like the 32x32x2 form, but 16-wide tiles:
+//     a 96x48x96 chunk's layers have 432 / 3456 voxel tiles of 16, i.e. 27 * 2^k -- they divide over 256 CUs);
+//   * a workgroup = 4 waves = one per SIMD, owns a BX x BY x BZ brick of output voxels (MT = ceil(vox/16) accumulator
+//     tiles PER WAVE) x ONE 16-wide cout tile; the four waves split the reduction by input channel (wave w takes
+//     channels 8w..8w+7 of every 32-channel chunk) and are summed through LDS at the end (deterministic);
+//     e.g. rpn_net 128->256 on 24x12x24: 16 bricks of 6x6x12 x 16 cout tiles = 256 workgroups, 27 tiles per wave,
+//     5832 MFMAs on every SIMD = exactly 1/1024 of the layer;
+//   * the halo brick of one 32-channel chunk is staged once in LDS (rows padded to 36 floats); a tap is a constant
+//     byte offset folded into the ds_read_b64 instruction; one read feeds two MFMAs (K order permuted: lane group k
+//     holds channels 2k, 2k+1 of the wave's eight);
+//   * weights are repacked once so that a wave's B operand for (chunk, tap) is one coalesced 8 B/lane load, fetched a
+//     few taps ahead through a small register ring;
+//   * with one wave per SIMD nothing else hides latency, so the NEXT chunk's halo brick is already in flight into
+//     registers (up to 28 x 16 B per lane) while the current chunk is being multiplied; the switch is barrier ->
+//     ds_write -> barrier;
+//   * MFMAs on one accumulator are 40 cycles apart in dependency but issue every 32: the two MFMAs of a read are
+//     interleaved over a group of G tiles.
+// Epilogue: + bias, ReLU, 16 B stores.  FMA contraction is irrelevant here (the MFMA is an fmaf chain; tolerance 1e-4).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int T16_MAXP = 4;    // independent same-shape problems per launch (the two RPN levels, chunk pairs)
+constexpr int CK = 32;         // channels per LDS chunk
+constexpr int RS = CK + 4;     // padded LDS row stride (floats): 144 B, 16 consecutive rows hit 16 distinct 8 B bank pairs
+constexpr int TAPS = 27;
+
+// compile-time loop: the body sees its index as a constant, so register arrays are never indexed dynamically (hipcc
+// declines `#pragma unroll` on the 100-250-step bodies below and would push the arrays to scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct T16Args {
+    const float *in[T16_MAXP];
+    const float *wp[T16_MAXP];
+    const float *bias[T16_MAXP];
+    float *out[T16_MAXP];
+    int X, Y, Z;
+    int cin_stride;
+    int cout, ntiles;          // ntiles = ceil(cout/16)
+    int nq;                    // cin / 32
+    int flags;
+    int out_stride, out_coff;
+    int nbx, nby, nbz;
+};
+
+template <int BX, int BY, int BZ, int G, int RB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
+{
+    constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
+    constexpr int IBY = BY + 2, IBZ = BZ + 2, IBX = BX + 2, ROWS = IBX * IBY * IBZ;
+    constexpr int ITEMS = ROWS * (CK / 4), NIT = (ITEMS + 255) / 256;
+    constexpr int NG = (MT + G - 1) / G;                   // tile groups per tap
+    constexpr int NSTEP = TAPS * NG;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [ROWS][RS]; reused as [4 waves][MT][16][16] for the reduction
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    // block -> (brick, cout tile): work list is brick-major / tile-minor and every XCD (block b runs on XCD b % 8, private
+    // 4 MiB L2) takes one contiguous range of it: the workgroups that share a halo brick share an L2
+    int wid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int prob = blockIdx.y;
+    const float *__restrict__ p_in = a.in[prob];
+    const float *__restrict__ p_wp = a.wp[prob];
+    const int nt = wid % a.ntiles;
+    int brick = wid / a.ntiles;
+    const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
+    const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
+    const int gX = a.X, gY = a.Y, gZ = a.Z;
+
+    // A operand addressing: lane (li, kq) of tile t reads voxel m = 16 t + li, channels 8 wave + 2 kq, +1
+    int abase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = 16 * t + li;
+        m = m < M ? m : M - 1;                             // surplus rows of the last tile recompute a valid voxel, never stored
+        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        abase[t] = (((lx * IBY + ly) * IBZ + lz) * RS + 8 * wave + 2 * kq) * 4;
+    }
+    // halo staging: item = (row, 16 B piece); global element offset (-1: outside the grid -> zero) and LDS byte offset
+    int goff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int row = idx >> 3, c4 = idx & 7;
+        const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
+        const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
+        const bool ok = idx < ITEMS && gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ;
+        goff[it] = ok ? ((gx * gY + gy) * gZ + gz) * a.cin_stride + c4 * 4 : -1;
+    }
+    float4 sv[NIT];
+    auto stage_load = [&](int q) {
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int o = goff[it];
+            const float4 v = *reinterpret_cast<const float4 *>(p_in + (size_t)(o < 0 ? 0 : o) + q * CK);
+            sv[it] = o < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : v;
+        });
+    };
+    auto stage_store = [&]() {
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int idx = tid + it * 256;
+            if (idx < ITEMS) *reinterpret_cast<float4 *>(lds + (idx >> 3) * RS + (idx & 7) * 4) = sv[it];
+        });
+    };
+    // B operand: packed [ntile][chunk][wave][tap][lane][2]
+    const float2 *bp = reinterpret_cast<const float2 *>(p_wp) + ((size_t)(nt * a.nq) * 4 + wave) * (TAPS * 64) + lane;
+    constexpr int QSTRIDE = 4 * TAPS * 64;                 // float2 elements per chunk
+    float2 bq[RB];
+    auto load_b = [&](int q, int tap) { return bp[(size_t)q * QSTRIDE + tap * 64]; };
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: first weight fragments, then chunk 0 straight into LDS
+#pragma unroll
+    for (int d = 0; d < RB - 1; ++d) bq[d] = load_b(0, d);
+    stage_load(0);
+    stage_store();
+    __syncthreads();
+
+    const int nq = a.nq;
+    for (int q = 0; q < nq; ++q) {
+        const bool more = q + 1 < nq;
+        if (more) stage_load(q + 1);                       // in flight while this chunk is multiplied
+        f32x2 ar[2][G];
+        auto read_group = [&](auto BUF, auto STEP) {
+            constexpr int buf = decltype(BUF)::value, step = decltype(STEP)::value;
+            constexpr int tap = step / NG, g = step % NG;
+            constexpr int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+            constexpr int toff = ((dx * IBY + dy) * IBZ + dz) * RS * 4;
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value, t = g * G + j;
+                if constexpr (t < MT)
+                    ar[buf][j] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(lds) + abase[t] + toff);
+            });
+        };
+        read_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, NSTEP>([&](auto STEP) {
+            constexpr int step = decltype(STEP)::value;
+            constexpr int tap = step / NG, g = step % NG;
+            if constexpr (g == 0) {
+                // fetch the fragment RB-1 taps ahead (wraps into the next chunk's first taps)
+                constexpr int tn = tap + RB - 1;
+                if constexpr (tn < TAPS) bq[tn % RB] = load_b(q, tn);
+                else if (more) bq[tn % RB] = load_b(q + 1, tn - TAPS);
+            }
+            if constexpr (step + 1 < NSTEP) read_group(std::integral_constant<int, (step + 1) & 1>{}, std::integral_constant<int, step + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const float2 b = bq[tap % RB];
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value, t = g * G + j;
+                if constexpr (t < MT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].x, b.x, acc[t], 0, 0, 0);
+            });
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value, t = g * G + j;
+                if constexpr (t < MT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].y, b.y, acc[t], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();                                   // every wave is done with chunk q's image
+        if (more) {
+            stage_store();
+            __syncthreads();
+        }
+    }
+
+    // ---- cross-wave reduction: every wave publishes its MT partial tiles as [16 voxels][16 couts] (D layout: column =
+    // lane & 15, rows 4 (lane >> 4) + r), then wave w finishes tiles w, w+4, ...: 16 B per lane = 4 couts of one voxel
+    float *red = lds + (size_t)wave * (MT * 256);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[t * 256 + (4 * kq + r) * 16 + li] = acc[t][r];
+    __syncthreads();
+    const int row = lane >> 2, c4 = lane & 3;
+    const int co = 16 * nt + 4 * c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias[prob] && co < a.cout) bv = *reinterpret_cast<const float4 *>(a.bias[prob] + co);
+    float *__restrict__ p_out = a.out[prob];
+    for (int t = wave; t < MT; t += 4) {
+        const float4 *src = reinterpret_cast<const float4 *>(lds + t * 256 + row * 16 + c4 * 4);
+        const float4 s0 = src[0], s1 = src[MT * 64], s2 = src[2 * MT * 64], s3 = src[3 * MT * 64];
+        float4 v;
+        v.x = (s0.x + s1.x) + (s2.x + s3.x) + bv.x;
+        v.y = (s0.y + s1.y) + (s2.y + s3.y) + bv.y;
+        v.z = (s0.z + s1.z) + (s2.z + s3.z) + bv.z;
+        v.w = (s0.w + s1.w) + (s2.w + s3.w) + bv.w;
+        if (a.flags & SIS3D_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const int m = 16 * t + row;
+        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        const int ox = ox0 + lx, oy = oy0 + ly, oz = oz0 + lz;
+        if (m < M && ox < gX && oy < gY && oz < gZ && co < a.cout)
+            *reinterpret_cast<float4 *>(p_out + ((size_t)(ox * gY + oy) * gZ + oz) * a.out_stride + a.out_coff + co) = v;
+    }
+}
+
+// (Cout,Cin,3,3,3) -> [cout/16][cin/32][wave 4][tap 27][lane 64][2]: lane (j = lane & 15, k = lane >> 4) holds
+// W[16 tile + j][32 q + 8 wave + 2 k + e][tap], e = 0, 1
+__global__ __launch_bounds__(256) void pack_weight_t16_kernel(const float *__restrict__ w, int cout, int cin, int ntiles, int nq,
+                                                              float *__restrict__ packed)
+{
+    const int64_t total = (int64_t)ntiles * nq * 4 * TAPS * 128;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 1), lane = (int)((idx >> 1) & 63);
+        int64_t rest = idx >> 7;
+        const int tap = (int)(rest % TAPS);
+        rest /= TAPS;
+        const int wv = (int)(rest & 3);
+        rest >>= 2;
+        const int q = (int)(rest % nq), tile = (int)(rest / nq);
+        const int co = tile * 16 + (lane & 15);
+        const int ci = q * CK + 8 * wv + 2 * (lane >> 4) + e;
+        packed[idx] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * TAPS + tap] : 0.0f;
+    }
+}
+
+template <int BX, int BY, int BZ>
+int launch_t16(T16Args &a, int nprob, hipStream_t st)
+{
+    constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
+    constexpr int G = (MT % 3 == 0) ? 3 : (MT >= 4 ? 4 : MT);
+    constexpr int RB = (MT >= 14) ? 3 : 9;                 // weight-fragment ring (taps); must divide 27 so the ring index carries across chunks
+    constexpr int ROWS = (BX + 2) * (BY + 2) * (BZ + 2);
+    constexpr size_t img = (size_t)ROWS * RS * sizeof(float), red = (size_t)4 * MT * 256 * sizeof(float);
+    constexpr size_t lds = img > red ? img : red;
+    static_assert(lds <= 160 * 1024, "LDS brick too large");
+    a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
+    auto kern = conv3d_k3t16_kernel<BX, BY, BZ, G, RB>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * a.ntiles;
+    if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(256), lds, st, a);
+    return sis3d_check_launch();
+}
+
+struct Brick { int bx, by, bz; };
+constexpr Brick BRICKS[] = {{6, 6, 12}, {6, 6, 6}, {3, 6, 6}, {3, 3, 6}, {4, 4, 4}, {4, 4, 8}, {4, 8, 8}};
+constexpr int NBRICKS = sizeof(BRICKS) / sizeof(BRICKS[0]);
+
+// estimated SIMD-cycles of the slowest CU: rounds of 256 workgroups x (MFMA issue + chunk switches + fixed cost)
+int64_t t16_cost(const Brick &b, int X, int Y, int Z, int cin, int ntiles, int nprob)
+{
+    const int64_t nb = (int64_t)cdiv(X, b.bx) * cdiv(Y, b.by) * cdiv(Z, b.bz);
+    const int64_t nwg = nb * ntiles * nprob;
+    const int64_t rounds = (nwg + 255) / 256;
+    const int mt = (b.bx * b.by * b.bz + 15) / 16;
+    const int rows = (b.bx + 2) * (b.by + 2) * (b.bz + 2);
+    const int64_t per_wg = (int64_t)mt * TAPS * (cin / 16) * 32 + (int64_t)(cin / CK) * (rows * 8 / 256 * 30 + 1200) + 3000;
+    return rounds * per_wg;
+}
+
+} // namespace
+
+extern "C" size_t sis3d_conv_k3t16_packed_floats(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0 || cin % CK) return 0;
+    return (size_t)((cout + 15) / 16) * (cin / CK) * 4 * TAPS * 128;
+}
+
+extern "C" int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream)
+{
+    if (!w || !packed || cout <= 0 || cin <= 0 || cin % CK) return SIS3D_EINVAL;
+    const int ntiles = (cout + 15) / 16, nq = cin / CK;
+    const int64_t total = (int64_t)ntiles * nq * 4 * TAPS * 128;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_weight_t16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), w, cout, cin,
+                       ntiles, nq, packed);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob)
+{
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nprob < 1) return SIS3D_EINVAL;
+    // tuning hook: SIS3D_K3_MAXVOX caps the brick volume (smaller bricks = less LDS / fewer registers per workgroup, so
+    // workgroups of other streams' kernels can share the CU)
+    static const int maxvox = [] { const char *e = getenv("SIS3D_K3_MAXVOX"); return e ? atoi(e) : 0; }();
+    int best = -1;
+    int64_t bc = -1;
+    for (int i = 0; i < NBRICKS; ++i) {
+        if (maxvox > 0 && BRICKS[i].bx * BRICKS[i].by * BRICKS[i].bz > maxvox) continue;
+        const int64_t c = t16_cost(BRICKS[i], X, Y, Z, cin, (cout + 15) / 16, nprob);
+        if (bc < 0 || c < bc) { bc = c; best = i; }
+    }
+    return best < 0 ? 3 : best;
+}
+
+extern "C" int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                  const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                                  int out_stride, int out_coff, int brick, sis3d_stream_t stream)
+{
+    if (nprob < 1 || nprob > T16_MAXP || !ins || !packed_ws || !outs) return SIS3D_EINVAL;
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || cin_stride < cin || (cin_stride % 4)) return SIS3D_EINVAL;
+    if ((cin % CK) || (cout % 4) || (out_stride % 4) || (out_coff % 4) || out_stride < out_coff + cout) return SIS3D_EUNSUPPORTED;
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    if ((int64_t)X * Y * Z * cin_stride > 0x7fffffffLL) return SIS3D_EUNSUPPORTED;      // 32-bit element offsets in the staging table
+    T16Args a;
+    for (int p = 0; p < T16_MAXP; ++p) {
+        const int s = p < nprob ? p : 0;
+        if (!ins[s] || !packed_ws[s] || !outs[s]) return SIS3D_EINVAL;
+        a.in[p] = ins[s]; a.wp[p] = packed_ws[s]; a.bias[p] = biases ? biases[s] : nullptr; a.out[p] = outs[s];
+    }
+    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
+    if (brick < 0) brick = sis3d_conv3d_k3t16_brick(X, Y, Z, cin, cout, nprob);
+    hipStream_t st = as_stream(stream);
+    switch (brick) {
+    case 0: return launch_t16<6, 6, 12>(a, nprob, st);
+    case 1: return launch_t16<6, 6, 6>(a, nprob, st);
+    case 2: return launch_t16<3, 6, 6>(a, nprob, st);
+    case 3: return launch_t16<3, 3, 6>(a, nprob, st);
+    case 4: return launch_t16<4, 4, 4>(a, nprob, st);
+    case 5: return launch_t16<4, 4, 8>(a, nprob, st);
+    case 6: return launch_t16<4, 8, 8>(a, nprob, st);
+    default: return SIS3D_EINVAL;
+    }
+}

@@ -43,6 +43,13 @@ SIGNATURES = {
                                    c_vp, c_vp]),
     "sis3d_conv3d_chain_projected": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp,
                                              c_int, c_int, c_vp, c_vp]),
+    "sis3d_conv3d_pw_chain": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_int,
+                                      c_int, c_vp, c_vp]),
+    "sis3d_conv_k3t16_packed_floats": (c_sz, [c_int, c_int]),
+    "sis3d_conv_k3t16_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "sis3d_conv3d_k3t16_brick": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sis3d_conv3d_k3t16": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int,
+                                   c_vp]),
     "sis3d_project_views_prepare": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_conv3d_batched": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int,
                                      c_vp, c_int, c_int, c_vp]),

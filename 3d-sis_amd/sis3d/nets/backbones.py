@@ -84,6 +84,17 @@ class Bottleneck(nn.Module):
         x = ops.to_cl(x)
         if y1 is None:
             y1 = self.conv1(x)
+        pc2 = self.conv2._packed.get(self.conv2)
+        if SPLIT_BOTTLENECK and pc2.packed_t16 is not None:
+            # conv2 on the balanced k3 kernel (every SIMD of the chip gets the same MFMA count), then ONE pointwise launch
+            # for conv3 + residual + ReLU (+ the next block's conv1 on the tile while it is on chip)
+            y2 = ops.conv3d_k3t16([y1], [pc2], relu=True)[0]
+            pc3 = self.conv3._packed.get(self.conv3)
+            stage = dict(pc=nxt.conv1._packed.get(nxt.conv1), relu=True) if nxt is not None else None
+            try:
+                return ops.conv3d_pw_chain(y2, pc3, residual=x, relu=True, out=out, out_coff=out_coff, stage=stage)
+            except ops.Sis3dUnsupported:
+                return self.conv3(y2, residual=x, out=out, out_coff=out_coff), None
         if FUSE_BOTTLENECK:
             stages = [dict(pc=self.conv3._packed.get(self.conv3), relu=True, residual=x, out=out, out_coff=out_coff)]
             if nxt is not None:
@@ -98,6 +109,7 @@ class Bottleneck(nn.Module):
 
 
 FUSE_BOTTLENECK = True
+SPLIT_BOTTLENECK = not ops.K3_LEGACY     # conv2 through csrc/conv3d_t16.hip + one pointwise launch (default)
 
 
 class FusedSequential(nn.Sequential):
@@ -123,7 +135,8 @@ class FusedSequential(nn.Sequential):
                 continue
             elif isinstance(m, HipMaxPool3d) and last and last_out is not None:
                 x, y1 = m(x, last_out, last_coff), None
-            elif isinstance(m, HipConv3d) and FUSE_BOTTLENECK and consumer(i) is not None and not (m.in_channels == 2 and not ops.is_cl(x)):
+            elif isinstance(m, HipConv3d) and FUSE_BOTTLENECK and consumer(i) is not None and not (m.in_channels == 2 and not ops.is_cl(x)) \
+                    and not (SPLIT_BOTTLENECK and m.kernel_size[0] == 3 and m._packed.get(m).packed_t16 is not None):
                 nb = consumer(i)
                 try:
                     x, outs = ops.conv3d_chain(ops.to_cl(x), m._packed.get(m), m.stride[0],

@@ -347,6 +347,80 @@ def to_planar(t):
     return t.contiguous()
 
 
+import os as _os
+
+K3_LEGACY = bool(_os.environ.get("SIS3D_K3_LEGACY"))       # A/B switch: every k3 conv through conv3d.hip's 32x32 tiles
+K3_BRICK = int(_os.environ.get("SIS3D_K3_BRICK", "-1"))    # tuning hook: force a brick of sis3d_conv3d_k3t16
+
+
+def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
+    """Conv3d(k3, p1) + bias (+ ReLU) of 1..4 same-shape problems in one launch of the balanced kernel
+    (sis3d_conv3d_k3t16).  xs: channels-last activations; pcs: PackedConv with .packed_t16.  -> list of outputs."""
+    n = len(xs)
+    x0, p0 = xs[0], pcs[0]
+    for x, pc in zip(xs, pcs):
+        if not is_cl(x) or x.shape != x0.shape or (pc.cin, pc.cout, pc.k) != (p0.cin, p0.cout, 3) or pc.packed_t16 is None \
+                or (pc.bias is None) != (p0.bias is None):
+            raise _lib.Sis3dError("conv3d_k3t16: problems must share shape and geometry (k3, cin % 32 == 0)")
+    _, cin_t, X, Y, Z = x0.shape
+    if cin_t != p0.cin:
+        raise _lib.Sis3dError("conv3d_k3t16: activation has %d channels, packed weight expects %d" % (cin_t, p0.cin))
+    if outs is None:
+        outs, out_coff = [new_act(p0.cout, (X, Y, Z), x0.device) for _ in range(n)], 0
+    for o in outs:
+        if not is_cl(o) or tuple(o.shape[2:]) != (X, Y, Z) or out_coff + p0.cout > o.shape[1]:
+            raise _lib.Sis3dError("conv3d_k3t16: bad `out`")
+    arr = ctypes.c_void_p * n
+    ins = arr(*[x.data_ptr() for x in xs])
+    wps = arr(*[pc.packed_t16.data_ptr() for pc in pcs])
+    bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
+    os_ = arr(*[o.data_ptr() for o in outs])
+    rc = lib().sis3d_conv3d_k3t16(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, EPI_RELU if relu else 0, os_, outs[0].shape[1],
+                                  int(out_coff), K3_BRICK if brick is None else int(brick), _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("conv3d_k3t16: unsupported shape")
+    check(rc, "sis3d_conv3d_k3t16")
+    return outs
+
+
+def conv3d_pw_chain(x, pc, residual=None, relu=True, out=None, out_coff=0, stage=None):
+    """1x1x1 conv + bias + residual + ReLU written to `out` (channel offset out_coff), optionally followed by ONE fused
+    1x1x1 stage on the on-chip tile (the next Bottleneck's conv1): sis3d_conv3d_pw_chain.
+    stage: dict(pc=PackedConv(k=1), relu=bool).  -> (main, stage_out | None); raises Sis3dUnsupported."""
+    if not is_cl(x) or pc.k != 1 or x.shape[1] != pc.cin:
+        raise _lib.Sis3dError("conv3d_pw_chain expects a channels-last activation and a k=1 PackedConv")
+    _, cin_t, X, Y, Z = x.shape
+    od = (X, Y, Z)
+    if out is None:
+        out, out_coff = new_act(pc.cout, od, x.device), 0
+    elif not is_cl(out) or tuple(out.shape[2:]) != od or out_coff + pc.cout > out.shape[1]:
+        raise _lib.Sis3dError("conv3d_pw_chain: bad `out`")
+    if residual is not None and (not is_cl(residual) or tuple(residual.shape[2:]) != od or residual.shape[1] != pc.cout):
+        raise _lib.Sis3dError("conv3d_pw_chain: residual shape mismatch")
+    flags = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    arr, so = None, None
+    if stage is not None:
+        spc = stage["pc"]
+        if spc.k != 1 or spc.cin != pc.cout:
+            raise _lib.Sis3dError("conv3d_pw_chain: stage expects %d input channels, k=1" % pc.cout)
+        so = new_act(spc.cout, od, x.device)
+        arr = (_lib.PwStage * 1)()
+        arr[0].packed_w = spc.packed.data_ptr()
+        arr[0].bias = spc.bias.data_ptr() if spc.bias is not None else None
+        arr[0].residual = None
+        arr[0].out = so.data_ptr()
+        arr[0].cin, arr[0].cout = pc.cout, spc.cout
+        arr[0].res_stride, arr[0].out_stride = 0, spc.cout
+        arr[0].flags = EPI_RELU if stage.get("relu", True) else 0
+    rc = lib().sis3d_conv3d_pw_chain(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed), _ptr(pc.bias), pc.cout, flags, _ptr(residual),
+                                     residual.shape[1] if residual is not None else 0, _ptr(out), out.shape[1], int(out_coff),
+                                     1 if stage is not None else 0, arr, _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no fused pointwise tiling for this shape")
+    check(rc, "sis3d_conv3d_pw_chain")
+    return out, so
+
+
 class PackedConv:
     """Weights of one nn.Conv3d repacked into MFMA fragment order (sis3d_conv_pack_weight)."""
 
@@ -366,6 +440,13 @@ class PackedConv:
         check(lib().sis3d_conv_pack_weight(_ptr(w), self.cout, self.cin, k, _ptr(self.packed), _stream()), "sis3d_conv_pack_weight")
         self.bias = _dev(bias.detach(), "bias").contiguous().clone() if bias is not None else None
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+        # second pack for the balanced k3 kernel (csrc/conv3d_t16.hip): [cout/16][cin/32][4][27][64][2]
+        self.packed_t16 = None
+        if k == 3 and self.cin % 32 == 0 and self.cout % 4 == 0 and not K3_LEGACY:
+            nt = lib().sis3d_conv_k3t16_packed_floats(self.cout, self.cin)
+            self.packed_t16 = torch.empty(nt, device=w.device)
+            check(lib().sis3d_conv_k3t16_pack_weight(_ptr(w), self.cout, self.cin, _ptr(self.packed_t16), _stream()),
+                  "sis3d_conv_k3t16_pack_weight")
 
 
 def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, out_coff=0, rpn_anchors=0):
@@ -384,6 +465,11 @@ def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, 
         if stride != 1:
             raise _lib.Sis3dError("k=1/3 convs are stride 1")
         od = (X, Y, Z)
+    if pc.k == 3 and pc.packed_t16 is not None and residual is None and not sigmoid and not rpn_anchors:
+        try:
+            return conv3d_k3t16([x], [pc], relu=relu, outs=None if out is None else [out], out_coff=out_coff)[0]
+        except Sis3dUnsupported:
+            pass
     flags = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_SIGMOID if sigmoid else 0)
     out2 = None
     o3_ptr = None
@@ -477,6 +563,11 @@ def conv3d_batched(xs, pcs, stride=1, relu=False, residuals=None):
     of identical shape; pcs: PackedConv objects of identical geometry.  -> list of outputs."""
     n = len(xs)
     x0, p0 = xs[0], pcs[0]
+    if p0.k == 3 and stride == 1 and residuals is None and all(pc.packed_t16 is not None for pc in pcs):
+        try:
+            return conv3d_k3t16(xs, pcs, relu=relu)
+        except Sis3dUnsupported:
+            pass
     for x, pc in zip(xs, pcs):
         if not is_cl(x) or x.shape != x0.shape or (pc.cin, pc.cout, pc.k) != (p0.cin, p0.cout, p0.k) or (pc.bias is None) != (p0.bias is None):
             raise _lib.Sis3dError("conv3d_batched: problems must share shape and geometry")

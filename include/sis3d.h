@@ -241,6 +241,32 @@ int sis3d_conv3d_chain_projected(const int32_t *vox2pix, const float *feat_rows,
                                  int cin, const float *packed_w, const float *bias, int cout, int flags, float *out,
                                  int out_stride, int nstages, const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
 
+/* The pointwise half of the Bottleneck (lib/nets/backbones.py:33-40) as ONE launch when conv2 ran on its own
+ * (sis3d_conv3d_k3t16):   main  = relu(conv3(y2) + b3 + x)      1x1x1 + residual; the block output, written to `out` at
+ *                                                               channel offset out_coff of rows of out_stride floats
+ *                         stage0= relu(conv1_next(main) + b1)   optional (nstages 0 or 1): the NEXT block's conv1
+ * Same tile-on-chip mechanism and argument meaning as sis3d_conv3d_chain; cin in {32,64}, packed_w from
+ * sis3d_conv_pack_weight(ksize 1). */
+int sis3d_conv3d_pw_chain(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                          int cout, int flags, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
+                          int nstages, const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
+
+/* Conv3d(cin, cout, 3, padding=1) + bias + ReLU in the balanced "one workgroup per CU, one wave per SIMD" form
+ * (csrc/conv3d_t16.hip): v_mfma_f32_16x16x4_f32, workgroup = brick of voxels x one 16-wide cout tile, the four waves
+ * split the input channels.  Replaces the same cuDNN calls as sis3d_conv3d(ksize 3) for cin % 32 == 0, cout % 4 == 0;
+ * nprob (<= 4) independent same-shape problems per launch (host arrays of device pointers, as sis3d_conv3d_batched).
+ * Weights: sis3d_conv_k3t16_pack_weight from the checkpoint layout (Cout,Cin,3,3,3) into
+ * [cout/16][cin/32][4][27][64][2] (sis3d_conv_k3t16_packed_floats floats).  flags: 0 or SIS3D_EPI_RELU.
+ * brick: index of the voxel brick (0: 6x6x12, 1: 6x6x6, 2: 3x6x6, 3: 3x3x6, 4: 4x4x4, 5: 4x4x8, 6: 4x8x8) or -1 =
+ * sis3d_conv3d_k3t16_brick's choice (fewest SIMD-cycles on the busiest CU for this grid).  Any grid size; partial
+ * bricks are masked. */
+size_t sis3d_conv_k3t16_packed_floats(int cout, int cin);
+int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
+int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob);
+int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                       const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                       int out_stride, int out_coff, int brick, sis3d_stream_t stream);
+
 /* nprob (<= 4) INDEPENDENT convolutions of identical shape in ONE launch (different input / weights / bias /
  * residual / output pointers; host arrays of device pointers, read at call time).  Used for the two RPN levels
  * (lib/nets/network.py:539,552): their 432 workgroups each leave 80 of the 256 CUs a workgroup short, a single

@@ -1,0 +1,130 @@
+"""fp32 parity of the balanced k3 kernel (csrc/conv3d_t16.hip: 16x16x4 MFMA tiles, one workgroup per CU, the four waves
+split the input channels) and of the pointwise Bottleneck half (sis3d_conv3d_pw_chain) against torch-CPU operators --
+the arithmetic the reference's nn.Conv3d calls run (lib/nets/backbones.py:17-40).  Tolerance 1e-4 (north_star)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+BRICKS = {0: (6, 6, 12), 1: (6, 6, 6), 2: (3, 6, 6), 3: (3, 3, 6), 4: (4, 4, 4), 5: (4, 4, 8), 6: (4, 8, 8)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sis3d import ops as o
+    o.lib()
+    return o
+
+
+def cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last_3d)
+
+
+def _w(cout, cin, k, g):
+    fan = cin * k ** 3
+    return (torch.rand(cout, cin, k, k, k, generator=g) * 2 - 1) / fan ** 0.5
+
+
+# every brick instantiation on a grid it tiles exactly, on a grid it does not, and on one smaller than the brick
+@pytest.mark.parametrize("brick", sorted(BRICKS))
+@pytest.mark.parametrize("dims", [(24, 12, 24), (13, 9, 11), (5, 3, 2)])
+def test_every_brick_vs_torch_cpu(ops, brick, dims):
+    g = torch.Generator().manual_seed(100 * brick + dims[0])
+    cin, cout = 64, 48
+    x = torch.randn(1, cin, *dims, generator=g)
+    w, b = _w(cout, cin, 3, g), torch.randn(cout, generator=g) * 0.1
+    want = F.relu(F.conv3d(x, w, b, padding=1))
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    assert pc.packed_t16 is not None
+    got = ops.conv3d_k3t16([cl(x)], [pc], relu=True, brick=brick)[0]
+    assert got.shape == want.shape and ops.is_cl(got)
+    assert (got.cpu() - want).abs().max().item() <= TOL
+
+
+# the network's own layer shapes through the automatic brick choice (what ops.conv3d now runs for k3)
+@pytest.mark.parametrize("cin,cout,dims", [(128, 256, (24, 12, 24)), (128, 128, (24, 12, 24)), (64, 64, (24, 12, 24)),
+                                           (32, 32, (24, 12, 24)), (32, 32, (48, 24, 48)), (64, 64, (30, 30, 36)),
+                                           (32, 20, (7, 5, 9)), (96, 64, (12, 12, 12))])
+def test_layer_shapes_auto_brick(ops, cin, cout, dims):
+    g = torch.Generator().manual_seed(cin + cout + dims[2])
+    x = torch.randn(1, cin, *dims, generator=g)
+    w, b = _w(cout, cin, 3, g), torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    got = ops.conv3d(cl(x), pc)                                   # no ReLU
+    assert (got.cpu() - F.conv3d(x, w, b, padding=1)).abs().max().item() <= TOL
+    pc0 = ops.PackedConv(w.cuda(), None)                          # no bias, ReLU
+    got0 = ops.conv3d(cl(x), pc0, relu=True)
+    assert (got0.cpu() - F.relu(F.conv3d(x, w, None, padding=1))).abs().max().item() <= TOL
+
+
+def test_batched_problems_and_channel_offset(ops):
+    g = torch.Generator().manual_seed(5)
+    dims = (12, 6, 12)
+    xs = [torch.randn(1, 32, *dims, generator=g) for _ in range(3)]
+    ws = [_w(64, 32, 3, g) for _ in range(3)]
+    bs = [torch.randn(64, generator=g) * 0.1 for _ in range(3)]
+    pcs = [ops.PackedConv(w.cuda(), b.cuda()) for w, b in zip(ws, bs)]
+    outs = ops.conv3d_batched([cl(x) for x in xs], pcs, relu=True)
+    for x, w, b, o in zip(xs, ws, bs, outs):
+        assert (o.cpu() - F.relu(F.conv3d(x, w, b, padding=1))).abs().max().item() <= TOL
+    # write into a channel range of a wider tensor (torch.cat fusion), neighbours untouched
+    wide = ops.new_act(128, dims, torch.device("cuda")).fill_(-3.0)
+    ops.conv3d(cl(xs[0]), pcs[0], relu=True, out=wide, out_coff=32)
+    assert (wide[:, 32:96].cpu() - F.relu(F.conv3d(xs[0], ws[0], bs[0], padding=1))).abs().max().item() <= TOL
+    assert bool((wide[:, :32] == -3.0).all()) and bool((wide[:, 96:] == -3.0).all())
+
+
+def test_matches_the_32x32_tile_kernel(ops, monkeypatch):
+    """the two k3 kernels (conv3d.hip 32x32x2 tiles / conv3d_t16.hip 16x16x4 tiles) differ only in summation order"""
+    g = torch.Generator().manual_seed(9)
+    x = cl(torch.randn(1, 128, 24, 12, 24, generator=g))
+    w, b = _w(128, 128, 3, g).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+    pc = ops.PackedConv(w, b)
+    new = ops.conv3d(x, pc, relu=True)
+    t16, pc.packed_t16 = pc.packed_t16, None
+    old = ops.conv3d(x, pc, relu=True)
+    pc.packed_t16 = t16
+    assert (new - old).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,cnext,dims", [(32, 32, 32, (48, 24, 48)), (32, 128, 32, (24, 12, 24)), (64, 128, 64, (24, 12, 24)),
+                                                 (32, 128, None, (24, 12, 24)), (64, 128, 64, (11, 7, 5)), (32, 64, 32, (9, 9, 9))])
+def test_pointwise_chain_vs_torch_cpu(ops, cin, cout, cnext, dims):
+    """relu(conv3(y2) + b3 + x) and relu(conv1_next(.) + b1) in one launch (backbones.py:33-40 + the next block's :29-31)"""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    y2 = torch.randn(1, cin, *dims, generator=g)
+    res = torch.randn(1, cout, *dims, generator=g)
+    w3, b3 = _w(cout, cin, 1, g), torch.randn(cout, generator=g) * 0.1
+    want = F.relu(F.conv3d(y2, w3, b3) + res)
+    pc3 = ops.PackedConv(w3.cuda(), b3.cuda())
+    stage = None
+    if cnext is not None:
+        w1, b1 = _w(cnext, cout, 1, g), torch.randn(cnext, generator=g) * 0.1
+        stage = dict(pc=ops.PackedConv(w1.cuda(), b1.cuda()), relu=True)
+    try:
+        main, so = ops.conv3d_pw_chain(cl(y2), pc3, residual=cl(res), relu=True, stage=stage)
+    except ops.Sis3dUnsupported:
+        pytest.skip("no fused pointwise tiling for %d->%d (callers fall back to separate launches)" % (cin, cout))
+    assert (main.cpu() - want).abs().max().item() <= TOL
+    if cnext is not None:
+        assert (so.cpu() - F.relu(F.conv3d(want, w1, b1))).abs().max().item() <= TOL
+    else:
+        assert so is None
+
+
+def test_bottleneck_sequence_split_equals_fused(ops):
+    """FusedSequential of two Bottlenecks: the split path (k3t16 + pointwise chain) against the reference arithmetic"""
+    from sis3d.nets import backbones as bb
+    torch.manual_seed(3)
+    seq = bb.FusedSequential(bb.Bottleneck(128, 64), bb.Bottleneck(128, 64)).eval()
+    x = torch.randn(1, 128, 24, 12, 24)
+    with torch.no_grad():
+        y = x
+        for blk in seq:
+            z = F.relu(F.conv3d(y, blk.conv1.weight, blk.conv1.bias))
+            z = F.relu(F.conv3d(z, blk.conv2.weight, blk.conv2.bias, padding=1))
+            y = F.relu(F.conv3d(z, blk.conv3.weight, blk.conv3.bias) + y)
+        got = seq.cuda()(cl(x))
+    assert (got.cpu() - y).abs().max().item() <= TOL
