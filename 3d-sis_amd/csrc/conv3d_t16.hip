@@ -93,25 +93,27 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
     const int gX = a.X, gY = a.Y, gZ = a.Z;
 
-    // A operand addressing: lane (li, kq) of tile t reads voxel m = 16 t + li, channels 8 wave + 2 kq, +1
-    int abase[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        int m = 16 * t + li;
-        m = m < M ? m : M - 1;                             // surplus rows of the last tile recompute a valid voxel, never stored
-        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
-        abase[t] = (((lx * IBY + ly) * IBZ + lz) * RS + 8 * wave + 2 * kq) * 4;
-    }
-    // halo staging: item = (row, 16 B piece); global element offset (-1: outside the grid -> zero) and LDS byte offset
+    // halo staging: item = (row, 16 B piece); global element offset (-1: outside the grid -> zero).  Rows advance by 32 per
+    // item: (hx, hy, hz) is carried incrementally instead of re-dividing (this address math sits in front of the very first
+    // load of a workgroup that has nothing else to overlap it with)
     int goff[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        const int row = idx >> 3, c4 = idx & 7;
-        const int hz = row % IBZ, hy = (row / IBZ) % IBY, hx = row / (IBZ * IBY);
-        const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
-        const bool ok = idx < ITEMS && gx >= 0 && gx < gX && gy >= 0 && gy < gY && gz >= 0 && gz < gZ;
-        goff[it] = ok ? ((gx * gY + gy) * gZ + gz) * a.cin_stride + c4 * 4 : -1;
+    {
+        const int row0 = tid >> 3, c4 = tid & 7;
+        int hz = row0 % IBZ, hy = (row0 / IBZ) % IBY, hx = row0 / (IBZ * IBY);
+        constexpr int DZ = 32 % IBZ, DY = (32 / IBZ) % IBY, DX = 32 / (IBZ * IBY);
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
+            const bool ok = (tid + it * 256 < ITEMS) && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
+            goff[it] = ok ? ((gx * gY + gy) * gZ + gz) * a.cin_stride + c4 * 4 : -1;
+            hz += DZ;
+            const int cz = hz >= IBZ;
+            hz -= cz * IBZ;
+            hy += DY + cz;
+            const int cy = hy >= IBY;
+            hy -= cy * IBY;
+            hx += DX + cy;
+        });
     }
     float4 sv[NIT];
     auto stage_load = [&](int q) {
@@ -143,6 +145,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
 #pragma unroll
     for (int d = 0; d < RB - 1; ++d) bq[d] = load_b(0, d);
     stage_load(0);
+    __builtin_amdgcn_sched_barrier(0);                     // the A-operand address math below runs under the loads' latency
+    // A operand addressing: lane (li, kq) of tile t reads voxel m = 16 t + li, channels 8 wave + 2 kq, +1
+    int abase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = 16 * t + li;
+        m = m < M ? m : M - 1;                             // surplus rows of the last tile recompute a valid voxel, never stored
+        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        abase[t] = (((lx * IBY + ly) * IBZ + lz) * RS + 8 * wave + 2 * kq) * 4;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     stage_store();
     __syncthreads();
 

@@ -1,0 +1,282 @@
+// 1x1x1 convolutions of the Bottleneck (lib/nets/backbones.py:27-40) as register-chained MFMA GEMMs on gfx950.
+//
+// Replaces the cuDNN / elementwise kernels behind
+//     out  = relu(conv3(y2) + b3 + x)          Bottleneck.conv3 + residual + ReLU        (backbones.py:33-40)
+//     out2 = relu(conv1_next(out) + b1)        the NEXT block's conv1 + ReLU              (backbones.py:29-31)
+// and the stand-alone conv1 of the first block of a stage.  These layers move 10-28 MB for 0.1-0.2 GFLOP: they are
+// HBM / L2-latency bound, and the generic implicit-GEMM kernel (conv3d.hip: LDS halo staging, barriers, split-K through
+// LDS) spends 10-19 us on them.  Here a wave owns a tile of 16 voxels and NOTHING is staged:
+//   * both GEMMs are computed transposed, D^T[cout][voxel] = W[cout][cin] * Y^T[cin][voxel], on v_mfma_f32_16x16x4_f32:
+//     the B operand is the activation tile, lane (voxel = lane & 15, k = lane >> 4) loads 16 B = channels 16 g + 4 k .. +3
+//     straight from global memory (K order permuted so the four MFMAs of a group consume the four floats of one load);
+//   * the result comes out as lane (voxel = lane & 15; couts 16 n + 4 (lane >> 4) + r) -- exactly the B-operand layout of
+//     the NEXT GEMM, so conv3 -> (+bias, +residual, ReLU) -> conv1_next chains through registers: no LDS, no shuffle;
+//     residual loads and all stores are 16 B per lane;
+//   * weights are repacked once into fragment order [cout/16][cin/16][lane][4] and live in registers;
+//   * wide layers (cout >= 64) split the output channels over the 4 waves of a workgroup (the 24x12x24 grid has only
+//     432 voxel tiles); the second GEMM is then split over its reduction (each wave holds its quarter of the
+//     channels) and summed through 4-16 KB of LDS.
+// FMA contraction irrelevant (MFMA = fmaf chain); tolerance 1e-4.
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct PwArgs {
+    const float *in;
+    int in_stride;
+    const float *w1p, *b1;       // stage 1 (conv3 / a plain conv1): pw16-packed weights, bias (may be NULL)
+    const float *res;            // residual rows (may be NULL)
+    int res_stride;
+    float *out;
+    int out_stride, out_coff, flags1;
+    const float *w2p, *b2;       // stage 2 (the next block's conv1); unused when C2 == 0
+    float *out2;
+    int out2_stride, flags2;
+    int nvox;
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(const float4 &w, const float4 &x, f32x4 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ float4 relu4(float4 v, bool on)
+{
+    if (on) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+}
+
+// D^T tiles of one GEMM: NT output tiles (16 couts each) x KG groups of 16 input channels; two output tiles are
+// accumulated in lockstep so that consecutive MFMAs never wait on the 40-cycle accumulator dependency
+template <int NT, int KG>
+__device__ __forceinline__ void gemm_t(const float4 (&w)[NT][KG], const float4 (&x)[KG], f32x4 (&acc)[NT])
+{
+    static_for<0, NT>([&](auto N) { acc[decltype(N)::value] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
+    static_for<0, (NT + 1) / 2>([&](auto P) {
+        constexpr int n0 = 2 * decltype(P)::value, n1 = n0 + 1;
+        static_for<0, KG>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            if constexpr (n1 < NT) {
+                acc[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n0][g].x, x[g].x, acc[n0], 0, 0, 0);
+                acc[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n1][g].x, x[g].x, acc[n1], 0, 0, 0);
+                acc[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n0][g].y, x[g].y, acc[n0], 0, 0, 0);
+                acc[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n1][g].y, x[g].y, acc[n1], 0, 0, 0);
+                acc[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n0][g].z, x[g].z, acc[n0], 0, 0, 0);
+                acc[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n1][g].z, x[g].z, acc[n1], 0, 0, 0);
+                acc[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n0][g].w, x[g].w, acc[n0], 0, 0, 0);
+                acc[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n1][g].w, x[g].w, acc[n1], 0, 0, 0);
+            } else {
+                acc[n0] = mfma4(w[n0][g], x[g], acc[n0]);
+            }
+        });
+    });
+}
+
+// WS = 1: a wave owns whole voxel tiles (all C1 and C2 output channels); grid-stride loop with the weights in registers.
+// WS = 4: the 4 waves of a workgroup share one voxel tile: wave w computes output channels [w C1/4, (w+1) C1/4) of stage
+//         1, then its K-quarter of stage 2; the partial stage-2 tiles are summed through LDS.
+template <int C0, int C1, int C2, int WS>
+__global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
+{
+    static_assert(C0 % 16 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "channel counts are multiples of 16");
+    static_assert(WS == 1 || (WS == 4 && C1 % 64 == 0), "the 4-wave split needs cout % 64 == 0");
+    constexpr int KG1 = C0 / 16;              // input channel groups of stage 1
+    constexpr int NT1 = C1 / 16 / WS;         // stage-1 output tiles of this wave
+    constexpr int NT2 = C2 / 16;              // stage-2 output tiles (all of them, partial sums when WS == 4)
+    constexpr int NT2A = NT2 > 0 ? NT2 : 1;
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t1_0 = WS == 1 ? 0 : wave * NT1;                       // first stage-1 tile of this wave
+    __shared__ __attribute__((aligned(16))) float red[(WS == 4 && NT2 > 0) ? 4 * NT2 * 256 : 4];
+
+    // ---- weights and biases of this wave, once
+    float4 w1[NT1][KG1], bb1[NT1];
+    static_for<0, NT1>([&](auto N) {
+        constexpr int n = decltype(N)::value;
+        static_for<0, KG1>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            w1[n][g] = reinterpret_cast<const float4 *>(a.w1p)[((size_t)(t1_0 + n) * KG1 + g) * 64 + lane];
+        });
+        bb1[n] = a.b1 ? *reinterpret_cast<const float4 *>(a.b1 + 16 * (t1_0 + n) + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    float4 w2[NT2A][NT1], bb2[NT2A];
+    if constexpr (NT2 > 0) {
+        static_for<0, NT2>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            static_for<0, NT1>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                w2[n][g] = reinterpret_cast<const float4 *>(a.w2p)[((size_t)n * (C1 / 16) + t1_0 + g) * 64 + lane];
+            });
+            bb2[n] = a.b2 ? *reinterpret_cast<const float4 *>(a.b2 + 16 * n + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        });
+    }
+    const bool relu1 = a.flags1 & SIS3D_EPI_RELU, relu2 = a.flags2 & SIS3D_EPI_RELU;
+    const int nmt = (a.nvox + 15) / 16;
+    const int first = WS == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    const int step = WS == 1 ? gridDim.x * 4 : gridDim.x;
+
+    auto load_tile = [&](int mt, float4 (&y)[KG1], float4 (&r)[NT1]) {
+        int v = 16 * mt + li;
+        v = v < a.nvox ? v : a.nvox - 1;
+        const float *yp = a.in + (size_t)v * a.in_stride + 4 * q;
+        static_for<0, KG1>([&](auto G) { y[decltype(G)::value] = *reinterpret_cast<const float4 *>(yp + 16 * decltype(G)::value); });
+        if (a.res) {
+            const float *rp = a.res + (size_t)v * a.res_stride + 16 * t1_0 + 4 * q;
+            static_for<0, NT1>([&](auto N) { r[decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
+        } else {
+            static_for<0, NT1>([&](auto N) { r[decltype(N)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
+        }
+    };
+
+    float4 y[KG1], r[NT1];
+    if (first < nmt) load_tile(first, y, r);
+    for (int mt = first; mt < nmt; mt += step) {
+        // the next tile's operands are requested before this tile's MFMAs
+        float4 yn[KG1], rn[NT1];
+        const bool more = mt + step < nmt;
+        if (more) load_tile(mt + step, yn, rn);
+        const int v = 16 * mt + li;
+        const bool ok = v < a.nvox;
+        f32x4 acc[NT1];
+        gemm_t<NT1, KG1>(w1, y, acc);
+        float4 z[NT1];
+        static_for<0, NT1>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            float4 t;
+            t.x = acc[n][0] + bb1[n].x + r[n].x; t.y = acc[n][1] + bb1[n].y + r[n].y;
+            t.z = acc[n][2] + bb1[n].z + r[n].z; t.w = acc[n][3] + bb1[n].w + r[n].w;
+            z[n] = relu4(t, relu1);
+            if (ok && a.out) *reinterpret_cast<float4 *>(a.out + (size_t)v * a.out_stride + a.out_coff + 16 * (t1_0 + n) + 4 * q) = z[n];
+        });
+        if constexpr (NT2 > 0) {
+            f32x4 acc2[NT2];
+            gemm_t<NT2, NT1>(w2, z, acc2);
+            if constexpr (WS == 1) {
+                static_for<0, NT2>([&](auto N) {
+                    constexpr int n = decltype(N)::value;
+                    float4 t;
+                    t.x = acc2[n][0] + bb2[n].x; t.y = acc2[n][1] + bb2[n].y; t.z = acc2[n][2] + bb2[n].z; t.w = acc2[n][3] + bb2[n].w;
+                    if (ok) *reinterpret_cast<float4 *>(a.out2 + (size_t)v * a.out2_stride + 16 * n + 4 * q) = relu4(t, relu2);
+                });
+            } else {
+                static_for<0, NT2>([&](auto N) {
+                    constexpr int n = decltype(N)::value;
+                    *reinterpret_cast<f32x4 *>(red + ((wave * NT2 + n) * 64 + lane) * 4) = acc2[n];
+                });
+                __syncthreads();
+                for (int n = wave; n < NT2; n += 4) {
+                    const float4 *src = reinterpret_cast<const float4 *>(red) + n * 64 + lane;
+                    const float4 s0 = src[0], s1 = src[NT2 * 64], s2 = src[2 * NT2 * 64], s3 = src[3 * NT2 * 64];
+                    const float4 bn = a.b2 ? *reinterpret_cast<const float4 *>(a.b2 + 16 * n + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 t;
+                    t.x = (s0.x + s1.x) + (s2.x + s3.x) + bn.x; t.y = (s0.y + s1.y) + (s2.y + s3.y) + bn.y;
+                    t.z = (s0.z + s1.z) + (s2.z + s3.z) + bn.z; t.w = (s0.w + s1.w) + (s2.w + s3.w) + bn.w;
+                    if (ok) *reinterpret_cast<float4 *>(a.out2 + (size_t)v * a.out2_stride + 16 * n + 4 * q) = relu4(t, relu2);
+                }
+                if (more) __syncthreads();
+            }
+        }
+        if (more) {
+            static_for<0, KG1>([&](auto G) { y[decltype(G)::value] = yn[decltype(G)::value]; });
+            static_for<0, NT1>([&](auto N) { r[decltype(N)::value] = rn[decltype(N)::value]; });
+        }
+    }
+}
+
+// (Cout,Cin[,1,1,1]) -> [cout/16][cin/16][lane 64][4]: lane (i = lane & 15, k = lane >> 4) holds W[16 n + i][16 g + 4 k + e]
+__global__ __launch_bounds__(256) void pack_weight_pw16_kernel(const float *__restrict__ w, int cout, int cin, int nt, int kg,
+                                                               float *__restrict__ packed)
+{
+    const int64_t total = (int64_t)nt * kg * 256;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        const int64_t rest = idx >> 8;
+        const int g = (int)(rest % kg), n = (int)(rest / kg);
+        const int co = 16 * n + (lane & 15), ci = 16 * g + 4 * (lane >> 4) + e;
+        packed[idx] = (co < cout && ci < cin) ? w[(int64_t)co * cin + ci] : 0.0f;
+    }
+}
+
+template <int C0, int C1, int C2, int WS>
+int launch_pw(const PwArgs &a, hipStream_t st)
+{
+    const int nmt = (a.nvox + 15) / 16;
+    // WS == 1: ~2 waves per SIMD, every wave loops over its tiles with the weights in registers; WS == 4: one tile per
+    // workgroup pass
+    int blocks = WS == 1 ? (nmt + 3) / 4 : nmt;
+    const int cap = WS == 1 ? 512 : 2048;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((pw16_kernel<C0, C1, C2, WS>), dim3(blocks), dim3(256), 0, st, a);
+    return sis3d_check_launch();
+}
+
+} // namespace
+
+extern "C" size_t sis3d_conv_pw16_packed_floats(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0) return 0;
+    return (size_t)((cout + 15) / 16) * ((cin + 15) / 16) * 256;
+}
+
+extern "C" int sis3d_conv_pw16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream)
+{
+    if (!w || !packed || cout <= 0 || cin <= 0) return SIS3D_EINVAL;
+    const int nt = (cout + 15) / 16, kg = (cin + 15) / 16;
+    const int64_t blocks = ((int64_t)nt * kg * 256 + 255) / 256;
+    hipLaunchKernelGGL(pack_weight_pw16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, as_stream(stream), w, cout, cin,
+                       nt, kg, packed);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_conv3d_pw16(const float *in, int64_t nvox, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                                 int flags, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
+                                 const float *packed_w2, const float *bias2, int cout2, int flags2, float *out2, int out2_stride,
+                                 sis3d_stream_t stream)
+{
+    if (!in || !packed_w || nvox <= 0 || nvox > 0x7fffffff || cin <= 0 || cout <= 0 || cout2 < 0) return SIS3D_EINVAL;
+    if ((cin_stride % 4) || cin_stride < cin || (out_stride % 4) || (out_coff % 4) || (res_stride % 4)) return SIS3D_EINVAL;
+    if (!out && cout2 == 0) return SIS3D_EINVAL;
+    if (cout2 > 0 && (!packed_w2 || !out2 || (out2_stride % 4) || out2_stride < cout2)) return SIS3D_EINVAL;
+    if ((flags & ~(SIS3D_EPI_RELU | SIS3D_EPI_RESIDUAL)) || (flags2 & ~SIS3D_EPI_RELU)) return SIS3D_EUNSUPPORTED;
+    if ((flags & SIS3D_EPI_RESIDUAL) && !residual) return SIS3D_EINVAL;
+    PwArgs a;
+    a.in = in; a.in_stride = cin_stride; a.w1p = packed_w; a.b1 = bias;
+    a.res = (flags & SIS3D_EPI_RESIDUAL) ? residual : nullptr; a.res_stride = res_stride;
+    a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.flags1 = flags;
+    a.w2p = packed_w2; a.b2 = bias2; a.out2 = out2; a.out2_stride = out2_stride; a.flags2 = flags2;
+    a.nvox = (int)nvox;
+    hipStream_t st = as_stream(stream);
+    const int key = cin * 1000000 + cout * 1000 + cout2;
+    switch (key) {
+    case 32 * 1000000 + 32 * 1000 + 32: return launch_pw<32, 32, 32, 1>(a, st);
+    case 32 * 1000000 + 32 * 1000 + 0: return launch_pw<32, 32, 0, 1>(a, st);
+    case 32 * 1000000 + 64 * 1000 + 32: return launch_pw<32, 64, 32, 4>(a, st);
+    case 32 * 1000000 + 64 * 1000 + 0: return launch_pw<32, 64, 0, 4>(a, st);
+    case 32 * 1000000 + 128 * 1000 + 32: return launch_pw<32, 128, 32, 4>(a, st);
+    case 32 * 1000000 + 128 * 1000 + 0: return launch_pw<32, 128, 0, 4>(a, st);
+    case 64 * 1000000 + 128 * 1000 + 64: return launch_pw<64, 128, 64, 4>(a, st);
+    case 64 * 1000000 + 128 * 1000 + 0: return launch_pw<64, 128, 0, 4>(a, st);
+    case 64 * 1000000 + 64 * 1000 + 0: return launch_pw<64, 64, 0, 4>(a, st);
+    case 64 * 1000000 + 32 * 1000 + 0: return launch_pw<64, 32, 0, 1>(a, st);
+    case 128 * 1000000 + 64 * 1000 + 0: return launch_pw<128, 64, 0, 4>(a, st);
+    case 128 * 1000000 + 32 * 1000 + 0: return launch_pw<128, 32, 0, 1>(a, st);
+    case 128 * 1000000 + 128 * 1000 + 0: return launch_pw<128, 128, 0, 4>(a, st);
+    default: return SIS3D_EUNSUPPORTED;
+    }
+}

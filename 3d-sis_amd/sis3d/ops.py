@@ -351,6 +351,43 @@ import os as _os
 
 K3_LEGACY = bool(_os.environ.get("SIS3D_K3_LEGACY"))       # A/B switch: every k3 conv through conv3d.hip's 32x32 tiles
 K3_BRICK = int(_os.environ.get("SIS3D_K3_BRICK", "-1"))    # tuning hook: force a brick of sis3d_conv3d_k3t16
+PW_LEGACY = bool(_os.environ.get("SIS3D_PW_LEGACY"))       # A/B switch: 1x1x1 convs through conv3d.hip only
+
+
+def conv3d_pw16(x, pc, residual=None, relu=True, out=None, out_coff=0, stage=None, want_main=True):
+    """1x1x1 conv (+ bias, + residual, ReLU) and optionally the next 1x1x1 conv on its result, chained through registers
+    (sis3d_conv3d_pw16).  -> (main | None, stage_out | None); raises Sis3dUnsupported for shapes without an instantiation."""
+    if pc.packed_pw16 is None or (stage is not None and stage["pc"].packed_pw16 is None):
+        raise Sis3dUnsupported("no pw16 pack for this layer")
+    _, cin_t, X, Y, Z = x.shape
+    od = (X, Y, Z)
+    if cin_t != pc.cin:
+        raise _lib.Sis3dError("conv3d_pw16: activation has %d channels, packed weight expects %d" % (cin_t, pc.cin))
+    if want_main:
+        if out is None:
+            out, out_coff = new_act(pc.cout, od, x.device), 0
+        elif not is_cl(out) or tuple(out.shape[2:]) != od or out_coff + pc.cout > out.shape[1]:
+            raise _lib.Sis3dError("conv3d_pw16: bad `out`")
+    else:
+        out = None
+    if residual is not None and (not is_cl(residual) or tuple(residual.shape[2:]) != od or residual.shape[1] != pc.cout):
+        raise _lib.Sis3dError("conv3d_pw16: residual shape mismatch")
+    flags = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    so, spc = None, None
+    if stage is not None:
+        spc = stage["pc"]
+        if spc.k != 1 or spc.cin != pc.cout:
+            raise _lib.Sis3dError("conv3d_pw16: stage expects %d input channels, k=1" % pc.cout)
+        so = new_act(spc.cout, od, x.device)
+    rc = lib().sis3d_conv3d_pw16(_ptr(x), X * Y * Z, pc.cin, cin_t, _ptr(pc.packed_pw16), _ptr(pc.bias), pc.cout, flags, _ptr(residual),
+                                 residual.shape[1] if residual is not None else 0, _ptr(out), out.shape[1] if out is not None else 0,
+                                 int(out_coff), _ptr(spc.packed_pw16) if spc else None, _ptr(spc.bias) if spc else None,
+                                 spc.cout if spc else 0, (EPI_RELU if stage.get("relu", True) else 0) if spc else 0, _ptr(so),
+                                 spc.cout if spc else 0, _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no pw16 instantiation for %d -> %d -> %s" % (pc.cin, pc.cout, spc.cout if spc else None))
+    check(rc, "sis3d_conv3d_pw16")
+    return out, so
 
 
 def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
@@ -389,6 +426,10 @@ def conv3d_pw_chain(x, pc, residual=None, relu=True, out=None, out_coff=0, stage
     stage: dict(pc=PackedConv(k=1), relu=bool).  -> (main, stage_out | None); raises Sis3dUnsupported."""
     if not is_cl(x) or pc.k != 1 or x.shape[1] != pc.cin:
         raise _lib.Sis3dError("conv3d_pw_chain expects a channels-last activation and a k=1 PackedConv")
+    try:
+        return conv3d_pw16(x, pc, residual=residual, relu=relu, out=out, out_coff=out_coff, stage=stage)
+    except Sis3dUnsupported:
+        pass
     _, cin_t, X, Y, Z = x.shape
     od = (X, Y, Z)
     if out is None:
@@ -440,6 +481,13 @@ class PackedConv:
         check(lib().sis3d_conv_pack_weight(_ptr(w), self.cout, self.cin, k, _ptr(self.packed), _stream()), "sis3d_conv_pack_weight")
         self.bias = _dev(bias.detach(), "bias").contiguous().clone() if bias is not None else None
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+        # 1x1x1: second pack for the register-chained pointwise kernels (csrc/pointwise.hip): [cout/16][cin/16][64][4]
+        self.packed_pw16 = None
+        if k == 1 and self.cin % 16 == 0 and self.cout % 16 == 0 and not PW_LEGACY:
+            npw = lib().sis3d_conv_pw16_packed_floats(self.cout, self.cin)
+            self.packed_pw16 = torch.empty(npw, device=w.device)
+            check(lib().sis3d_conv_pw16_pack_weight(_ptr(w), self.cout, self.cin, _ptr(self.packed_pw16), _stream()),
+                  "sis3d_conv_pw16_pack_weight")
         # second pack for the balanced k3 kernel (csrc/conv3d_t16.hip): [cout/16][cin/32][4][27][64][2]
         self.packed_t16 = None
         if k == 3 and self.cin % 32 == 0 and self.cout % 4 == 0 and not K3_LEGACY:
@@ -465,6 +513,11 @@ def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, 
         if stride != 1:
             raise _lib.Sis3dError("k=1/3 convs are stride 1")
         od = (X, Y, Z)
+    if pc.k == 1 and pc.packed_pw16 is not None and not sigmoid and not rpn_anchors:
+        try:
+            return conv3d_pw16(x, pc, residual=residual, relu=relu, out=out, out_coff=out_coff)[0]
+        except Sis3dUnsupported:
+            pass
     if pc.k == 3 and pc.packed_t16 is not None and residual is None and not sigmoid and not rpn_anchors:
         try:
             return conv3d_k3t16([x], [pc], relu=relu, outs=None if out is None else [out], out_coff=out_coff)[0]

@@ -251,6 +251,23 @@ int sis3d_conv3d_pw_chain(const float *in, int X, int Y, int Z, int cin, int cin
                           int cout, int flags, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
                           int nstages, const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
 
+/* The same pointwise pair as register-chained 16x16x4 MFMA GEMMs (csrc/pointwise.hip): a wave owns 16 voxels, the
+ * activation rows are read 16 B per lane straight from global memory, conv3's result tile is already in the operand
+ * layout of conv1_next -- no LDS staging, no barrier (wide layers: 4 waves share a voxel tile, one LDS reduction).
+ *     out  = epi(W1 in + b1 [+ residual])            cout channels at out_coff of rows of out_stride floats (out may be
+ *                                                    NULL when only the second stage is wanted)
+ *     out2 = epi2(W2 out + b2)                       optional (cout2 > 0)
+ * in: nvox rows of cin_stride floats (channels-last activations of ANY grid, flattened).  packed_w / packed_w2 from
+ * sis3d_conv_pw16_pack_weight (checkpoint layout (Cout,Cin[,1,1,1]) -> [cout/16][cin/16][64][4]).  flags: SIS3D_EPI_RELU |
+ * SIS3D_EPI_RESIDUAL; flags2: SIS3D_EPI_RELU.  SIS3D_EUNSUPPORTED for (cin, cout, cout2) combinations that are not
+ * instantiated (callers fall back to sis3d_conv3d_pw_chain / sis3d_conv3d). */
+size_t sis3d_conv_pw16_packed_floats(int cout, int cin);
+int sis3d_conv_pw16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
+int sis3d_conv3d_pw16(const float *in, int64_t nvox, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                      int flags, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
+                      const float *packed_w2, const float *bias2, int cout2, int flags2, float *out2, int out2_stride,
+                      sis3d_stream_t stream);
+
 /* Conv3d(cin, cout, 3, padding=1) + bias + ReLU in the balanced "one workgroup per CU, one wave per SIMD" form
  * (csrc/conv3d_t16.hip): v_mfma_f32_16x16x4_f32, workgroup = brick of voxels x one 16-wide cout tile, the four waves
  * split the input channels.  Replaces the same cuDNN calls as sis3d_conv3d(ksize 3) for cin % 32 == 0, cout % 4 == 0;

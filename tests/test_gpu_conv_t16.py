@@ -128,3 +128,47 @@ def test_bottleneck_sequence_split_equals_fused(ops):
             y = F.relu(F.conv3d(z, blk.conv3.weight, blk.conv3.bias) + y)
         got = seq.cuda()(cl(x))
     assert (got.cpu() - y).abs().max().item() <= TOL
+
+
+PW16 = [(32, 32, 32), (32, 32, None), (32, 64, 32), (32, 64, None), (32, 128, 32), (32, 128, None), (64, 128, 64), (64, 128, None),
+        (64, 64, None), (64, 32, None), (128, 64, None), (128, 32, None), (128, 128, None)]
+
+
+@pytest.mark.parametrize("cin,cout,cnext", PW16)
+@pytest.mark.parametrize("dims", [(24, 12, 24), (7, 5, 3)])
+def test_register_chained_pointwise_vs_torch_cpu(ops, cin, cout, cnext, dims):
+    """every instantiation of sis3d_conv3d_pw16 (csrc/pointwise.hip), with and without residual, ragged last voxel tile"""
+    g = torch.Generator().manual_seed(cin * 13 + cout + (cnext or 0))
+    y2 = torch.randn(1, cin, *dims, generator=g)
+    res = torch.randn(1, cout, *dims, generator=g)
+    w3, b3 = _w(cout, cin, 1, g), torch.randn(cout, generator=g) * 0.1
+    pc3 = ops.PackedConv(w3.cuda(), b3.cuda())
+    assert pc3.packed_pw16 is not None
+    stage = None
+    if cnext is not None:
+        w1, b1 = _w(cnext, cout, 1, g), torch.randn(cnext, generator=g) * 0.1
+        stage = dict(pc=ops.PackedConv(w1.cuda(), b1.cuda()), relu=True)
+    want = F.relu(F.conv3d(y2, w3, b3) + res)
+    main, so = ops.conv3d_pw16(cl(y2), pc3, residual=cl(res), relu=True, stage=stage)
+    assert ops.is_cl(main) and (main.cpu() - want).abs().max().item() <= TOL
+    if cnext is not None:
+        assert (so.cpu() - F.relu(F.conv3d(want, w1, b1))).abs().max().item() <= TOL
+    # no residual, no ReLU, no bias, written into a channel range of a wider tensor
+    pc0 = ops.PackedConv(w3.cuda(), None)
+    wide = ops.new_act(cout + 32, dims, torch.device("cuda")).fill_(5.0)
+    ops.conv3d_pw16(cl(y2), pc0, relu=False, out=wide, out_coff=16)
+    assert (wide[:, 16:16 + cout].cpu() - F.conv3d(y2, w3)).abs().max().item() <= TOL
+    assert bool((wide[:, :16] == 5.0).all()) and bool((wide[:, 16 + cout:] == 5.0).all())
+
+
+def test_plain_k1_conv_routes_through_pw16_and_matches_legacy(ops):
+    g = torch.Generator().manual_seed(77)
+    x = cl(torch.randn(1, 128, 24, 12, 24, generator=g))
+    w, b = _w(64, 128, 1, g).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    pc = ops.PackedConv(w, b)
+    new = ops.conv3d(x, pc, relu=True)
+    saved, pc.packed_pw16 = pc.packed_pw16, None
+    old = ops.conv3d(x, pc, relu=True)                              # conv3d.hip's generic 1x1x1 path
+    pc.packed_pw16 = saved
+    assert (new - old).abs().max().item() <= 2e-5
+    assert (new.cpu() - F.relu(F.conv3d(x.cpu(), w.cpu(), b.cpu()))).abs().max().item() <= TOL

@@ -76,6 +76,23 @@ def main():
                 us = timeit(lambda: seq(x))
                 print("bneck x2 %-22s %-6s %8.1f us per pair" % (tag, "split" if split else "fused", us))
         bb.SPLIT_BOTTLENECK = True
+    # the pointwise half alone: register-chained (pointwise.hip) vs the generic 1x1x1 path with fused stage (conv3d.hip)
+    import torch.nn.functional as F  # noqa: F401
+    for tag, c0, c1, c2, dims in (("pw 32->32(+res)->32 @48", 32, 32, 32, (48, 24, 48)), ("pw 32->128(+res)->32 @24", 32, 128, 32, (24, 12, 24)),
+                                  ("pw 64->128(+res)->64 @24", 64, 128, 64, (24, 12, 24)), ("pw 32->32 plain @48", 32, 32, None, (48, 24, 48)),
+                                  ("pw 128->64 plain @24", 128, 64, None, (24, 12, 24))):
+        y2 = ops.new_act(c0, dims, dev).normal_()
+        res = ops.new_act(c1, dims, dev).normal_() if c2 is not None else None
+        pc3 = ops.PackedConv(torch.randn(c1, c0, 1, 1, 1, device=dev) * 0.1, torch.zeros(c1, device=dev))
+        stage = dict(pc=ops.PackedConv(torch.randn(c2, c1, 1, 1, 1, device=dev) * 0.1, torch.zeros(c2, device=dev)), relu=True) if c2 else None
+        nv = dims[0] * dims[1] * dims[2]
+        mb = 4e-6 * nv * (c0 + c1 * (2 if res is not None else 1) + (c2 or 0))
+        us = timeit(lambda: ops.conv3d_pw16(y2, pc3, residual=res, relu=True, stage=stage))
+        saved, pc3.packed_pw16 = pc3.packed_pw16, None
+        us_old = timeit(lambda: ops.conv3d_pw_chain(y2, pc3, residual=res, relu=True, stage=stage) if c2 is not None
+                        else ops.conv3d(y2, pc3, relu=True))
+        pc3.packed_pw16 = saved
+        print("%-28s pw16 %6.1f us (%4.0f GB/s of %.1f MB)   conv3d.hip %6.1f us" % (tag, us, mb / us * 1e3, mb, us_old))
 
 
 if __name__ == "__main__":
