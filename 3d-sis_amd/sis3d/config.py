@@ -55,6 +55,8 @@ def scannet_benchmark_cfg():
     c.USE_IMAGES = False          # geometry-only by default here (BASELINE configs 1-3)
     c.ONLY_IMAGES = False
     c.USE_IMAGES_GT = True        # feature maps handed in directly (network.py:199-201)
+    c.NUM_2D_CLASSES = 41         # lib/utils/config.py:188
+    c.PRETRAINED_ENET_PATH = ""   # benchmark.yml:114 points at scannetv2_enet.pth (not available offline: default init then)
     c.MASK_USE_IMAGES = False
     c.MASK_ONLY_IMAGES = False
     c.NUM_IMAGE_CHANNELS = 128

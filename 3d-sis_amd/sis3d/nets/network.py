@@ -69,8 +69,11 @@ class Network(nn.Module):
         if cfg.USE_MASK:
             self.mask_backbone = getattr(backbones, cfg.MASK_BACKBONE)(cfg=cfg)
         if cfg.USE_IMAGES and not cfg.USE_IMAGES_GT:
-            raise NotImplementedError("ENet (lib/nets/enet.py) stays on PyTorch-ROCm/MIOpen and needs its checkpoint; "
-                                      "feed feature maps with USE_IMAGES_GT=True (SURVEY.md 8c)")
+            # network.py:63-64: the 2D encoder, split into its frozen and trainable halves + classifier (same attribute
+            # names = same state_dict keys).  PyTorch-ROCm operators: outside the hand-written 3D path.
+            from . import enet
+            self.image_enet_fixed, self.image_enet_trainable, self.image_enet_classification = enet.create_enet_for_3d(
+                cfg.NUM_2D_CLASSES, cfg.get("PRETRAINED_ENET_PATH", ""), cfg.NUM_CLASSES)
 
     def delete_intermediate_states(self):
         for d in (self._losses, self._predictions, self._anchor_targets, self._proposal_targets, self._mask_targets):
@@ -135,6 +138,13 @@ class Network(nn.Module):
         anchors = anchors_for_level(feat.shape[2:], self._feat_stride[lv - 1], anchor_sizes(cfg, lv))
         setattr(self, "_anchors_level%d" % lv, anchors)
         return (lv, prob, bbox, anchors)
+
+    def image_features(self, images):
+        """network.py:203-205: `image_enet_trainable(image_enet_fixed(images))`, eval mode, no grad"""
+        with torch.no_grad():
+            self.image_enet_fixed.eval()
+            self.image_enet_trainable.eval()
+            return self.image_enet_trainable(self.image_enet_fixed(images.float())).contiguous()
 
     def backbone_only(self, scene, imageft=None):
         """Device-only: the backbone proper (backbones.py:98-113) -> (level1, level2)."""
@@ -245,9 +255,10 @@ class Network(nn.Module):
             self._gt_mask = blobs.get("gt_mask") if cfg.USE_MASK else None
             imageft = None
             if cfg.USE_IMAGES:
-                if not cfg.USE_IMAGES_GT:
-                    raise NotImplementedError("ENet encoder not part of this build; pass feature maps (USE_IMAGES_GT)")
                 feats = blobs["nearest_images"]["images"][0].to(dev, non_blocking=True)
+                if not cfg.USE_IMAGES_GT:
+                    # network.py:203-205: RGB views (V,3,256,328) -> ENet features (V,128,32,41)
+                    feats = self.image_features(feats)
                 p3 = blobs["proj_ind_3d"][0].to(dev, non_blocking=True)
                 p2 = blobs["proj_ind_2d"][0].to(dev, non_blocking=True)
                 project = ops.project_views_prepare if self.fuse_projection else ops.project_views_max

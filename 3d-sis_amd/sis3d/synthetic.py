@@ -54,6 +54,62 @@ def synth_state_dict(shapes, seed=0, gains=None):
     return out
 
 
+DEFAULT_GAINS_LATER = object()      # placeholder default: DEFAULT_GAINS is defined further down
+
+
+def synth_enet_state_dict(shapes, seed=0, prefix=""):
+    """Seeded weights for the ENet tree (sis3d.nets.enet / lib/nets/enet.py): conv weights / biases as synth_state_dict,
+    BatchNorm statistics in a sane range (running_var > 0), BN scale near 1, PReLU slopes in (0.1, 0.4).  Keys are drawn
+    from generators seeded by the key WITHOUT `prefix`, so the stand-alone encoder and the `image_enet_*` copies inside a
+    Network get the same tensors."""
+    out = {}
+    names = set(shapes)
+    for name in shapes:
+        shape = tuple(shapes[name])
+        key = name[len(prefix):] if prefix and name.startswith(prefix) else name
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * int(seed) + 17) & 0x7FFFFFFF)
+        stem = name.rsplit(".", 1)[0]
+        is_bn = (stem + ".running_mean") in names
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            t = torch.zeros(shape, dtype=torch.int64)
+        elif leaf == "running_var":
+            t = torch.rand(*shape, generator=g) + 0.5
+        elif leaf == "running_mean":
+            t = torch.rand(*shape, generator=g) - 0.5
+        elif is_bn and leaf == "weight":
+            t = torch.rand(*shape, generator=g) + 0.5
+        elif is_bn and leaf == "bias":
+            t = (torch.rand(*shape, generator=g) - 0.5) * 0.2
+        elif leaf == "weight" and len(shape) == 1:             # PReLU slopes
+            t = torch.rand(*shape, generator=g) * 0.3 + 0.1
+        elif leaf == "weight":
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = (torch.rand(*shape, generator=g) * 2.0 - 1.0) / fan_in ** 0.5
+        else:                                                   # conv bias
+            t = (torch.rand(*shape, generator=g) - 0.5) * 0.2
+        out[name] = t
+    return out
+
+
+def synth_checkpoint(shapes, seed=0, gains=DEFAULT_GAINS_LATER):
+    """seeded weights for a whole 3D-SIS checkpoint: the `image_enet_*` entries (2D encoder: BatchNorm statistics, PReLU
+    slopes) from synth_enet_state_dict, everything else from synth_state_dict"""
+    e = {k: v for k, v in shapes.items() if k.startswith("image_enet_")}
+    r = {k: v for k, v in shapes.items() if not k.startswith("image_enet_")}
+    sd = synth_state_dict(r, seed=seed, gains=DEFAULT_GAINS if gains is DEFAULT_GAINS_LATER else gains)
+    sd.update(synth_enet_state_dict(e, seed=seed))
+    return sd
+
+
+def synth_images(chunk_id=0, n_views=5, image_hw=(256, 328)):
+    """seeded colour views (V,3,H,W), roughly mean/std normalised like the dataloader's output (dataloader.py:26-31)"""
+    g = torch.Generator().manual_seed(2468 + int(chunk_id))
+    return torch.randn(n_views, 3, *image_hw, generator=g)
+
+
 # spreads RPN scores away from 0.5 and lets a few class scores pass CLASS_THRESH
 DEFAULT_GAINS = {"rpn_cls_score_net": 8.0, "classifier_cls_score_net.weight": 150.0}
 

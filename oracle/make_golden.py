@@ -11,6 +11,8 @@ roi_pooling.c built into oracle/_ref/).  The fixtures are what pins the oracle
 """
 import hashlib
 import os
+import subprocess
+import tempfile
 import sys
 
 import numpy as np
@@ -102,19 +104,59 @@ def anchors_case(ns):
     print("anchors", f1.shape, f2.shape)
 
 
-def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3, only_images=False):
+def split_state_dict(shapes, seed=0):
+    return synthetic.synth_checkpoint(shapes, seed=seed)
+
+
+def enet_case(ns):
+    """the reference's ENet (lib/nets/enet.py create_enet, split as create_enet_for_3d :701-705) with seeded weights:
+    fixed -> trainable features on a small view (full output) and on two full-size views (every 4th pixel), plus the key /
+    shape list of its checkpoint (the state_dict contract)"""
+    from lib.nets import enet as renet
+    ref = renet.create_enet(41)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    ref.load_state_dict(synthetic.synth_enet_state_dict(shapes, seed=0))
+    ref.eval()
+    n = len(ref)
+    fixed = torch.nn.Sequential(*[ref[i] for i in range(n - 9)])
+    train = torch.nn.Sequential(*[ref[i] for i in range(n - 9, n - 1)])
+    small = synthetic.synth_images(7, 1, (64, 80))
+    full = synthetic.synth_images(3, 2)
+    with torch.no_grad():
+        f_small = train(fixed(small))
+        mid_full = fixed(full)
+        f_full = train(mid_full)
+        cls_full = ref[n - 1](f_full)
+    keys = sorted(shapes)
+    np.savez_compressed(os.path.join(OUT, "enet_cases.npz"), keys=np.array(keys),
+                        shapes=np.array([",".join(str(d) for d in shapes[k]) for k in keys]),
+                        small_out=f_small.numpy(), full_fixed_sub=mid_full[:, :, ::4, ::4].numpy(), full_out_sub=f_full[:, :, ::4, ::4].numpy(),
+                        full_out_sha=np.array(sha(f_full.numpy())), full_cls_sub=cls_full[:, :, ::4, ::4].numpy())
+    print("enet", tuple(f_full.shape), "max %.3f" % float(f_full.abs().max()),
+          "%.1f KB" % (os.path.getsize(os.path.join(OUT, "enet_cases.npz")) / 1024))
+
+
+def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3, only_images=False, rgb=False):
+    """rgb: the views are RGB images and the reference runs its own ENet on them (USE_IMAGES_GT=False, network.py:203-205)"""
     ns.cfg.ONLY_IMAGES = bool(only_images)
+    ckpt = None
+    if rgb:
+        from lib.nets import enet as renet
+        ckpt = os.path.join(tempfile.mkdtemp(), "enet_init.pth")
+        torch.save(renet.create_enet(int(ns.cfg.NUM_2D_CLASSES)).state_dict(), ckpt)     # overwritten by the seeded weights below
     try:
-        net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=True)
+        net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=True, enet_ckpt=ckpt)
     finally:
         pass
     shapes = {k: v.shape for k, v in net.state_dict().items()}
-    sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
+    sd = split_state_dict(shapes, seed=0)
     net.load_state_dict(sd)
     data = synthetic.synth_chunk(chunk_id, dims)
     feats = i3d = i2d = None
     if use_images:
         feats, i3d, i2d = synthetic.synth_views(chunk_id, n_views=n_views, n_per_view=n_per_view, dims=dims)
+        if rgb:
+            feats = synthetic.synth_images(chunk_id, n_views)
     grabbed = {}
     bb = net._backbone
 
@@ -149,6 +191,7 @@ def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3,
         out["imageft_nz_val"] = ift[0][:, nz[:, 0], nz[:, 1], nz[:, 2]].numpy()
         out["imageft_stride"] = np.array(ift.stride())
     ns.cfg.ONLY_IMAGES = False
+    ns.cfg.USE_IMAGES_GT = True
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "R=%d" % out["rois"].shape[0], "masks=%d" % len(masks),
           "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
@@ -291,6 +334,10 @@ def suncg_case():
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
+    if "--enet" in sys.argv:                     # only the round-2 additions (2D encoder + RGB end-to-end)
+        enet_case(ns)
+        e2e(ns, "e2e_rgb_small", True, (64, 32, 48), 6, n_views=3, n_per_view=400, sub=2, rgb=True)
+        return
     nms_cases(ns)
     roi_cases(ns)
     projection_cases(ns)
@@ -298,6 +345,8 @@ def main():
     compute_projection_cases(ns)
     benchmark_case(ns)
     dataset_case(ns)
+    enet_case(ns)
+    e2e(ns, "e2e_rgb_small", True, (64, 32, 48), 6, n_views=3, n_per_view=400, sub=2, rgb=True)
     if "--only-new" in sys.argv:
         return
     e2e(ns, "e2e_geometry_full", False, (96, 48, 96), 0, sub=4)

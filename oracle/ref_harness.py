@@ -216,11 +216,15 @@ def make_blobs(data, images=None, proj3d=None, proj2d=None, scene_id="syn0"):
     return blobs
 
 
-def build_net(ns, seed=0, use_images=False, use_mask=True):
-    """`getattr(backbones, cfg.NET)(); init_modules()` as lib/model/trainval.py:68-70 does."""
+def build_net(ns, seed=0, use_images=False, use_mask=True, enet_ckpt=None):
+    """`getattr(backbones, cfg.NET)(); init_modules()` as lib/model/trainval.py:68-70 does.
+    enet_ckpt: path of an ENet state_dict file -> USE_IMAGES_GT=False, the reference builds its 2D encoder from it
+    (create_enet_for_3d always torch.load()s cfg.PRETRAINED_ENET_PATH, enet.py:699) and RGB views are the image input."""
     cfg = ns.cfg
     cfg.USE_IMAGES = bool(use_images)
-    cfg.USE_IMAGES_GT = bool(use_images)   # feature maps supplied directly (network.py:199-201)
+    cfg.USE_IMAGES_GT = bool(use_images) and enet_ckpt is None   # True: feature maps supplied directly (network.py:199-201)
+    if enet_ckpt is not None:
+        cfg.PRETRAINED_ENET_PATH = enet_ckpt
     cfg.USE_MASK = bool(use_mask)
     torch.manual_seed(seed)
     with in_reference_dir():
