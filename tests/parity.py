@@ -1,0 +1,53 @@
+"""End-to-end proposal parity, the protocol of SURVEY.md 8(c)(3): the device and oracle proposal lists are compared as
+SETS with exact (IoU = 1, coordinates within `tol`) one-to-one matching; a box left unmatched on either side FAILS unless
+its RPN score sits within `gap` of another candidate's score (a near-tie: the two fp32 pipelines differ by ~1e-6 in the
+logits, so the stable sort may order such a pair differently and NMS then keeps the other one) -- those are REPORTED."""
+import torch
+
+
+def match_sets(got, want, tol=1e-3):
+    """greedy one-to-one matching of box rows by max-abs coordinate difference <= tol -> (pairs [(i_want, j_got)],
+    unmatched_want, unmatched_got)"""
+    pairs, used = [], set()
+    if len(want) and len(got):
+        d = (got[None, :, :] - want[:, None, :]).abs().amax(-1)           # (W, G)
+        for i in range(d.shape[0]):
+            row = d[i].clone()
+            if used:
+                row[list(used)] = float("inf")
+            j = int(row.argmin())
+            if float(row[j]) <= tol:
+                pairs.append((i, j))
+                used.add(j)
+    mw = {i for i, _ in pairs}
+    return pairs, [i for i in range(len(want)) if i not in mw], [j for j in range(len(got)) if j not in used]
+
+
+def nearest_score_gap(score, all_scores_sorted):
+    """distance from `score` to the closest OTHER candidate score (all_scores_sorted: every candidate, descending)"""
+    a = all_scores_sorted
+    d = (a - score).abs()
+    k = int(d.argmin())                                     # the candidate itself (or its fp32 twin on the other side)
+    d[k] = float("inf")
+    return float(d.min()) if d.numel() > 1 else float("inf")
+
+
+def assert_proposals_match(got_rois, got_scores, want_rois, want_scores, all_scores_sorted, tol=1e-3, gap=1e-5, score_tol=1e-4,
+                           label=""):
+    """-> number of near-ties reported.  got_* device outputs (CPU tensors), want_* the oracle's, all_scores_sorted the
+    oracle's full candidate score list (OracleNet.forward()['_scores_sorted_all'])."""
+    got_rois, want_rois = got_rois.float().cpu(), want_rois.float().cpu()
+    gs, ws = got_scores.float().cpu().view(-1), want_scores.float().cpu().view(-1)
+    pairs, un_w, un_g = match_sets(got_rois, want_rois, tol)
+    for i, j in pairs:
+        assert abs(float(ws[i]) - float(gs[j])) <= score_tol, (label, "score of a matched box", i, j, float(ws[i]), float(gs[j]))
+    near = 0
+    for side, idx, sc in (("oracle-only", un_w, ws), ("device-only", un_g, gs)):
+        for k in idx:
+            g_ = nearest_score_gap(float(sc[k]), all_scores_sorted.float().cpu().clone())
+            assert g_ <= gap + 2e-6, "%s %s box %d (score %.7f) has no near-tied rival: nearest other candidate score is %.3g away" % (
+                label, side, k, float(sc[k]), g_)
+            near += 1
+    print("[parity] %s: %d oracle / %d device proposals, %d matched exactly, %d near-ties reported" % (
+        label, len(want_rois), len(got_rois), len(pairs), near))
+    return near

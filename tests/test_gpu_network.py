@@ -7,8 +7,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from sis3d import config, synthetic  # noqa: E402
+from parity import assert_proposals_match  # noqa: E402
 
 TOL = 1e-4
+
+
+def check_proposals(p, o, label):
+    """set match at IoU = 1, unmatched boxes only where the score is a near-tie (reported)"""
+    return assert_proposals_match(p["rois"][0].cpu(), p["roi_scores"][0].cpu(), o["rois"][0], o["roi_scores"][0],
+                                  o["_scores_sorted_all"], label=label)
 
 
 def build(cfg, seed=0):
@@ -28,14 +35,6 @@ def blobs_for(data, feats=None, i3d=None, i2d=None):
         b["proj_ind_3d"] = [i3d]
         b["proj_ind_2d"] = [i2d]
     return b
-
-
-def match_boxes(got, want, tol=1e-3):
-    """proposal SETS: every oracle box has a device box within tol (order may differ on near-ties)"""
-    if len(want) == 0:
-        return 1.0
-    d = (got[None, :, :] - want[:, None, :]).abs().amax(-1)
-    return float((d.min(1).values <= tol).float().mean())
 
 
 @pytest.mark.parametrize("name,use_images", [("e2e_geometry_small", False), ("e2e_images_small", True),
@@ -66,11 +65,16 @@ def test_forward_vs_oracle_and_golden(oracle, golden, name, use_images):
     if use_images:
         assert torch.equal(net._imageft.cpu(), o["imageft"])                                  # bit-exact gather
     # ---- proposals: same set up to near-tie reordering
-    rois, want = p["rois"][0].cpu(), o["rois"][0]
-    frac = match_boxes(rois, want)
-    assert frac >= 0.9, frac
-    assert abs(rois.shape[0] - want.shape[0]) <= max(3, want.shape[0] // 10)
-    assert np.abs(np.sort(p["roi_scores"][0].cpu().numpy()[:, 0])[-20:] - np.sort(g["roi_scores"][:, 0])[-20:]).max() <= TOL
+    near = check_proposals(p, o, name)
+    if near == 0:
+        # no near-tie anywhere: the device list is the reference's own list (fixture), row for row
+        assert p["rois"][0].shape[0] == g["rois"].shape[0]
+        assert np.abs(p["rois"][0].cpu().numpy() - g["rois"]).max() <= 1e-3
+        assert np.abs(p["roi_scores"][0].cpu().numpy() - g["roi_scores"]).max() <= TOL
+        assert np.array_equal(p["level_inds"][0].cpu().numpy(), g["level_inds"])
+        assert np.array_equal(p["cls_pred"].cpu().numpy(), g["cls_pred"])
+        assert np.abs(p["cls_score"].cpu().numpy() - g["cls_score"]).max() <= TOL
+        assert np.abs(p["bbox_pred"].cpu().numpy() - g["bbox_pred"]).max() <= TOL
 
 
 def test_stage_isolated_heads_exact_inputs(oracle):
@@ -120,15 +124,65 @@ def test_mask_head_vs_oracle(oracle):
 
 
 def test_full_forward_masks(oracle, golden):
+    """BASELINE config 3 at full size, mask VALUES: every device mask against the oracle's mask of the same detection
+    (same crop window and class), and the reference's own first four masks (fixture) against their device twins"""
+    from sis3d.model.trainval import final_detections, mask_windows
     g = golden("e2e_geometry_full")
     cfg = config.scannet_benchmark_cfg()
     net, sd = build(cfg)
     data = synthetic.synth_chunk(0)
     p = net.forward(blobs_for(data), "TEST", [])
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data)
+    near = check_proposals(p, o, "config 3 full size")
     masks = p["mask_pred"][0]
-    assert abs(len(masks) - int(g["n_masks"])) <= 3
-    for m in masks:
-        assert m.shape[1] == cfg.NUM_CLASSES and float(m.min()) >= 0 and float(m.max()) <= 1
+    _, _, pred_box, keep = final_detections(p, data.shape[2:], cfg)
+    wins = mask_windows(pred_box, keep)
+    assert len(wins) == len(masks) and len(masks) > 0
+    owins = [tuple(c) for c in o["_mask_aux"]["crops"]]
+    omasks = o["mask_pred"][0]
+    assert len(omasks) == int(g["n_masks"])
+    if near == 0:
+        assert wins == owins                                   # same detections, same integer crop windows, same order
+    by_win = {w: m for w, m in zip(owins, omasks)}
+    flips = checked = 0
+    for w, m in zip(wins, masks):
+        assert m.shape[1] == cfg.NUM_CLASSES and tuple(m.shape[2:]) == (w[3] - w[0], w[4] - w[1], w[5] - w[2])
+        if w in by_win:
+            want = by_win[w]
+            assert float((m.cpu() - want).abs().max()) <= TOL, w            # sigmoid outputs of all 19 class channels
+            flips += int(((m.cpu() >= cfg.MASK_THRESH) != (want >= cfg.MASK_THRESH)).sum())
+            checked += 1
+    assert checked >= len(owins) - near and checked > 0
+    print("[parity] masks: %d of %d compared at 1e-4, %d voxels flip at MASK_THRESH (|p - 0.5| < 1e-4)" % (checked, len(masks), flips))
+    # the reference's own masks (fixture): its first four detections
+    for i in range(min(4, int(g["n_masks"]))):
+        ref_m = torch.from_numpy(g["mask_%d" % i])
+        # the oracle is pinned to them bit for bit on the machine that generated the fixture (tests/test_oracle_pinning.py);
+        # another host's oneDNN may pick a different summation order for the same convs
+        assert float((omasks[i] - ref_m).abs().max()) <= 1e-5
+        if owins[i] in dict(zip(wins, masks)):
+            assert float((dict(zip(wins, masks))[owins[i]].cpu() - ref_m).abs().max()) <= TOL
+
+
+def test_config4_full_size_vs_oracle(oracle):
+    """BASELINE config 4 at 96x48x96 (feature maps handed in, USE_IMAGES_GT): RPN maps, logits, proposals vs the oracle"""
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES, cfg.USE_MASK = True, False
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(13)
+    feats, i3d, i2d = synthetic.synth_views(13)                # 5 views, 3000 visible voxels each
+    p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data, feats, i3d, i2d)
+    l1, l2 = net._net_conv
+    assert (l1.cpu() - o["level1"]).abs().max() <= TOL and (l2.cpu() - o["level2"]).abs().max() <= TOL
+    assert torch.equal(net._imageft.cpu(), o["imageft"])
+    for lv in (1, 2):
+        for k in ("rpn_cls_score_level%d", "rpn_cls_prob_level%d", "rpn_bbox_pred_level%d"):
+            assert (p[k % lv].cpu() - o[k % lv]).abs().max() <= TOL, k % lv
+    if check_proposals(p, o, "config 4 full size") == 0:
+        assert (p["cls_score"].cpu() - o["cls_score"]).abs().max() <= TOL
+        assert (p["bbox_pred"].cpu() - o["bbox_pred"]).abs().max() <= TOL
+        assert torch.equal(p["cls_pred"].cpu(), o["cls_pred"])
 
 
 def test_mask_head_batched_equals_per_box(oracle):
@@ -167,8 +221,8 @@ def test_whole_scene_odd_grid_vs_oracle(oracle, dims):
     for lv in (1, 2):
         assert (p["rpn_cls_prob_level%d" % lv].cpu() - o["rpn_cls_prob_level%d" % lv]).abs().max() <= TOL
         assert (p["rpn_bbox_pred_level%d" % lv].cpu() - o["rpn_bbox_pred_level%d" % lv]).abs().max() <= TOL
-    assert match_boxes(p["rois"][0].cpu(), o["rois"][0]) >= 0.9
-    assert abs(p["cls_score"].shape[0] - o["cls_score"].shape[0]) <= max(3, o["cls_score"].shape[0] // 10)
+    if check_proposals(p, o, "odd grid %s" % (dims,)) == 0:
+        assert (p["cls_score"].cpu() - o["cls_score"]).abs().max() <= TOL
 
 
 @pytest.mark.parametrize("kill_view", [None, 1])
@@ -204,7 +258,7 @@ def test_forward_from_depth_maps_vs_oracle(oracle, kill_view):
     for lv in (1, 2):
         k = "rpn_cls_prob_level%d" % lv
         assert (p[k].cpu() - o[k]).abs().max() <= TOL
-    assert match_boxes(p["rois"][0].cpu(), o["rois"][0]) >= 0.9
+    check_proposals(p, o, "from depth maps, kill=%s" % kill_view)
 
 
 @pytest.mark.parametrize("n_per_view,kill", [(400, ()), (3000, (1,)), (0, ())])
@@ -260,8 +314,8 @@ def test_forward_config_switches(oracle, switch):
         if k in o:
             assert (p[k].cpu() - o[k]).abs().max() <= TOL
     rois, want = p["rois"][0].cpu(), o["rois"][0]
-    assert want.shape[0] > 0 and abs(rois.shape[0] - want.shape[0]) <= max(3, want.shape[0] // 10)
-    assert match_boxes(rois, want) >= 0.9
+    assert want.shape[0] > 0
+    check_proposals(p, o, switch)
     lv_got = set(p["level_inds"][0].cpu().tolist())
     assert lv_got <= set(o["level_inds"][0].tolist()) | {1.0, 2.0}
     if switch == "level1_only":

@@ -49,11 +49,14 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
         rec[:n, 10:16] = torch.from_numpy(oracle.class_boxes(o, data.shape[2:]))
         return rec, n
     orecs, okeep = parallel.infer_scene(chunks, odetect, oracle.nms, cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH)
-    # proposal sets agree up to near-tie reordering (fp32 logits differ by ~1e-6 between oneDNN and the MFMA kernel)
-    assert abs(recs.shape[0] - orecs.shape[0]) <= max(3, orecs.shape[0] // 10)
+    # the gathered record sets match one to one; an unmatched record must be a near-tie of the RPN scores
+    from parity import assert_proposals_match
+    allsc = torch.cat([on.forward(c[2])["_scores_sorted_all"] for c in chunks]).sort(descending=True).values
+    near = assert_proposals_match(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6], allsc, label="4-chunk scene records")
+    if near == 0:
+        assert recs.shape[0] == orecs.shape[0] and torch.equal(keep.cpu(), okeep)
     got, want = recs[keep][:, :6].cpu(), orecs[okeep][:, :6]
     d = (got[None] - want[:, None]).abs().amax(-1)
-    assert float((d.min(1).values <= 1e-3).float().mean()) >= 0.9
     # boxes were shifted to scene coordinates
     assert float(recs[:, 3].max()) > dims[0] and float(recs[:, 5].max()) > dims[2]
     # class-regressed final boxes of the matched detections agree with the oracle's host-side decode
@@ -146,3 +149,59 @@ def test_grouped_engine_equals_single_chunk_engines(stage):
         assert keys and ("block" in keys or stage == "rpn")
         for k in keys:
             assert torch.equal(got[g][k], want[k]), (g, k)
+
+
+def test_config5_scene_32_chunks_vs_oracle(oracle):
+    """BASELINE config 5 at its real size: 32 chunks of 96x48x96 laid out 4 x 1 x 8 (what `bench.py --workload scene`
+    times), per-chunk captured graph -> record blocks -> gather -> whole-scene NMS, against the oracle running the same
+    chunks on the CPU + cpu_nms over the concatenation."""
+    from parity import assert_proposals_match
+    from sis3d import parallel
+    from sis3d.engine import RECORD_WIDTH
+    from sis3d.nets import backbones
+    from sis3d.scene import SceneRunner
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_MASK = False
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    sd = synthetic.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    dims = synthetic.CHUNK_DIMS
+    chunks = [(c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), synthetic.synth_chunk(c)) for c in range(32)]
+    runner = SceneRunner(net, dims)
+    recs, keep = runner.infer([(c, o, d.cuda()) for c, o, d in chunks])
+    on = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
+    k = cfg.TEST.RPN_POST_NMS_TOP_N
+    allsc = []
+
+    def odetect(data):
+        o = on.forward(data)
+        allsc.append(o["_scores_sorted_all"])
+        n = o["rois"][0].shape[0]
+        rec = torch.zeros(k, RECORD_WIDTH)
+        rec[:n, :6], rec[:n, 6], rec[:n, 7] = o["rois"][0], o["roi_scores"][0][:, 0], o["level_inds"][0]
+        rec[:n, 8] = o["cls_pred"].float()
+        rec[:n, 9] = o["cls_prob"].gather(1, o["cls_pred"].view(-1, 1))[:, 0]
+        rec[:n, 10:16] = torch.from_numpy(oracle.class_boxes(o, data.shape[2:]))
+        return rec, n
+    orecs, okeep = parallel.infer_scene(chunks, odetect, oracle.nms, k, cfg.TEST.RPN_NMS_THRESH)
+    assert float(recs[:, 3].max()) > 3 * 96 and float(recs[:, 5].max()) > 7 * 96          # scene coordinates of the 4 x 1 x 8 grid
+    near = assert_proposals_match(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6],
+                                  torch.cat(allsc).sort(descending=True).values, label="config 5: 32-chunk scene records")
+    # the whole-scene NMS itself is integer-exact on the device's own records
+    assert torch.equal(keep.cpu(), oracle.nms(recs[:, :6].cpu().contiguous(), cfg.TEST.RPN_NMS_THRESH))
+    if near == 0:
+        # same records (the score-sorted ORDER may swap rows whose scores differ by ~1e-7 between the two fp32 pipelines):
+        # level, class, class probability and the class-regressed final box of every matched record
+        from parity import match_sets
+        assert recs.shape[0] == orecs.shape[0] and keep.numel() == okeep.numel()
+        pairs, uw, ug = match_sets(recs[:, :6].cpu(), orecs[:, :6])
+        assert not uw and not ug
+        iw = torch.tensor([i for i, _ in pairs])
+        jg = torch.tensor([j for _, j in pairs])
+        r, w = recs.cpu()[jg], orecs[iw]
+        assert torch.equal(r[:, 7], w[:, 7]) and torch.equal(r[:, 8], w[:, 8])
+        assert float((r[:, 9] - w[:, 9]).abs().max()) <= 1e-4 and float((r[:, 10:16] - w[:, 10:16]).abs().max()) <= 5e-3
+        s_ = recs[:, 6]
+        assert bool((s_[:-1] >= s_[1:]).all())
