@@ -35,7 +35,8 @@ struct PwArgs {
     const float *w2p, *b2;       // stage 2 (the next block's conv1); unused when C2 == 0
     float *out2;
     int out2_stride, flags2;
-    int nvox;
+    int nvox;                    // OUTPUT voxels
+    int iY, iZ, oY, oZ;          // TAPS == 8 (k2 s2): input grid (Y, Z) and output grid (OY, OZ) extents
 };
 
 template <int I, int N, typename F>
@@ -91,12 +92,18 @@ __device__ __forceinline__ void gemm_t(const float4 (&w)[NT][KG], const float4 (
 // WS = 1: a wave owns whole voxel tiles (all C1 and C2 output channels); grid-stride loop with the weights in registers.
 // WS = 4: the 4 waves of a workgroup share one voxel tile: wave w computes output channels [w C1/4, (w+1) C1/4) of stage
 //         1, then its K-quarter of stage 2; the partial stage-2 tiles are summed through LDS.
-template <int C0, int C1, int C2, int WS>
+// TAPS = 8: stage 1 is a Conv3d(C0, C1, k=2, s=2) (the stems geometry1[4] / color[4], backbones.py:193,207): its reduction runs
+//           over the 2x2x2 input voxels of an output voxel, i.e. 8 gathered rows per lane instead of one -- the same GEMM with
+//           K = 8 C0 (weights packed with K index = tap * C0 + ci, tap = 4 dx + 2 dy + dz)
+template <int C0, int C1, int C2, int WS, int TAPS = 1>
 __global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
 {
     static_assert(C0 % 16 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "channel counts are multiples of 16");
     static_assert(WS == 1 || (WS == 4 && C1 % 64 == 0), "the 4-wave split needs cout % 64 == 0");
-    constexpr int KG1 = C0 / 16;              // input channel groups of stage 1
+    static_assert(TAPS == 1 || TAPS == 8, "pointwise or k2/s2");
+    constexpr int KGC = C0 / 16;              // channel groups per input row
+    constexpr int KG1 = TAPS * KGC;           // reduction groups of stage 1
+    constexpr bool PREFETCH = TAPS == 1;      // the gathered variant holds 8 rows per lane: no second operand set
     constexpr int NT1 = C1 / 16 / WS;         // stage-1 output tiles of this wave
     constexpr int NT2 = C2 / 16;              // stage-2 output tiles (all of them, partial sums when WS == 4)
     constexpr int NT2A = NT2 > 0 ? NT2 : 1;
@@ -134,8 +141,21 @@ __global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
     auto load_tile = [&](int mt, float4 (&y)[KG1], float4 (&r)[NT1]) {
         int v = 16 * mt + li;
         v = v < a.nvox ? v : a.nvox - 1;
-        const float *yp = a.in + (size_t)v * a.in_stride + 4 * q;
-        static_for<0, KG1>([&](auto G) { y[decltype(G)::value] = *reinterpret_cast<const float4 *>(yp + 16 * decltype(G)::value); });
+        if constexpr (TAPS == 1) {
+            const float *yp = a.in + (size_t)v * a.in_stride + 4 * q;
+            static_for<0, KG1>([&](auto G) { y[decltype(G)::value] = *reinterpret_cast<const float4 *>(yp + 16 * decltype(G)::value); });
+        } else {
+            const int oz = v % a.oZ, oy = (v / a.oZ) % a.oY, ox = v / (a.oZ * a.oY);
+            const float *yp = a.in + ((size_t)(2 * ox * a.iY + 2 * oy) * a.iZ + 2 * oz) * a.in_stride + 4 * q;
+            static_for<0, TAPS>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                const float *tp = yp + (size_t)(((t >> 2) * a.iY + ((t >> 1) & 1)) * a.iZ + (t & 1)) * a.in_stride;
+                static_for<0, KGC>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    y[t * KGC + g] = *reinterpret_cast<const float4 *>(tp + 16 * g);
+                });
+            });
+        }
         if (a.res) {
             const float *rp = a.res + (size_t)v * a.res_stride + 16 * t1_0 + 4 * q;
             static_for<0, NT1>([&](auto N) { r[decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
@@ -148,9 +168,11 @@ __global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
     if (first < nmt) load_tile(first, y, r);
     for (int mt = first; mt < nmt; mt += step) {
         // the next tile's operands are requested before this tile's MFMAs
-        float4 yn[KG1], rn[NT1];
+        float4 yn[PREFETCH ? KG1 : 1], rn[PREFETCH ? NT1 : 1];
         const bool more = mt + step < nmt;
-        if (more) load_tile(mt + step, yn, rn);
+        if constexpr (PREFETCH) {
+            if (more) load_tile(mt + step, yn, rn);
+        }
         const int v = 16 * mt + li;
         const bool ok = v < a.nvox;
         f32x4 acc[NT1];
@@ -193,11 +215,155 @@ __global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
             }
         }
         if (more) {
-            static_for<0, KG1>([&](auto G) { y[decltype(G)::value] = yn[decltype(G)::value]; });
-            static_for<0, NT1>([&](auto N) { r[decltype(N)::value] = rn[decltype(N)::value]; });
+            if constexpr (PREFETCH) {
+                static_for<0, KG1>([&](auto G) { y[decltype(G)::value] = yn[decltype(G)::value]; });
+                static_for<0, NT1>([&](auto N) { r[decltype(N)::value] = rn[decltype(N)::value]; });
+            } else {
+                load_tile(mt + step, y, r);
+            }
         }
     }
 }
+
+// geometry1[0] = Conv3d(2, C1, k=2, s=2, bias=False) + ReLU on the PLANAR 2-channel grid (backbones.py:188), chained into the
+// first Bottleneck's conv1 (C1 -> C2, + bias, ReLU; backbones.py:29-31).  K = 2 channels x 8 taps = 16 = ONE reduction
+// group: lane (voxel, k) gathers (ci = k >> 1, dx = k & 1) x (dy, dz) -- four scalar loads from the planar grid -- and the
+// result tile feeds the second GEMM from registers.  Both outputs are channels-last.
+template <int C1, int C2>
+__global__ __launch_bounds__(256) void stem_planar_kernel(const float *__restrict__ in, int64_t is_c, int64_t is_x, int64_t is_y, int oX,
+                                                          int oY, int oZ, const float *__restrict__ w1p, int flags1,
+                                                          float *__restrict__ out, int out_stride, const float *__restrict__ w2p,
+                                                          const float *__restrict__ b2, int flags2, float *__restrict__ out2,
+                                                          int out2_stride)
+{
+    constexpr int NT1 = C1 / 16, NT2 = C2 / 16, NT2A = NT2 > 0 ? NT2 : 1;
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int wave = threadIdx.x >> 6;
+    float4 w1[NT1][1];
+    static_for<0, NT1>([&](auto N) { w1[decltype(N)::value][0] = reinterpret_cast<const float4 *>(w1p)[decltype(N)::value * 64 + lane]; });
+    float4 w2[NT2A][NT1], bb2[NT2A];
+    if constexpr (NT2 > 0) {
+        static_for<0, NT2>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            static_for<0, NT1>([&](auto G) { w2[n][decltype(G)::value] = reinterpret_cast<const float4 *>(w2p)[(n * NT1 + decltype(G)::value) * 64 + lane]; });
+            bb2[n] = b2 ? *reinterpret_cast<const float4 *>(b2 + 16 * n + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        });
+    }
+    const bool relu1 = flags1 & SIS3D_EPI_RELU, relu2 = flags2 & SIS3D_EPI_RELU;
+    const int nvox = oX * oY * oZ, nmt = (nvox + 15) / 16;
+    const int ci = q >> 1, dx = q & 1;
+    for (int mt = blockIdx.x * 4 + wave; mt < nmt; mt += gridDim.x * 4) {
+        const int v = 16 * mt + li;
+        const bool ok = v < nvox;
+        const int vc = ok ? v : nvox - 1;
+        const int oz = vc % oZ, oy = (vc / oZ) % oY, ox = vc / (oZ * oY);
+        const float *p = in + ci * is_c + (int64_t)(2 * ox + dx) * is_x + (int64_t)(2 * oy) * is_y + 2 * oz;
+        float4 y[1];
+        y[0].x = p[0]; y[0].y = p[1]; y[0].z = p[is_y]; y[0].w = p[is_y + 1];
+        f32x4 acc[NT1];
+        gemm_t<NT1, 1>(w1, y, acc);
+        float4 z[NT1];
+        static_for<0, NT1>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            z[n] = relu4(make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]), relu1);
+            if (ok) *reinterpret_cast<float4 *>(out + (size_t)v * out_stride + 16 * n + 4 * q) = z[n];
+        });
+        if constexpr (NT2 > 0) {
+            f32x4 acc2[NT2];
+            gemm_t<NT2, NT1>(w2, z, acc2);
+            static_for<0, NT2>([&](auto N) {
+                constexpr int n = decltype(N)::value;
+                float4 t;
+                t.x = acc2[n][0] + bb2[n].x; t.y = acc2[n][1] + bb2[n].y; t.z = acc2[n][2] + bb2[n].z; t.w = acc2[n][3] + bb2[n].w;
+                if (ok) *reinterpret_cast<float4 *>(out2 + (size_t)v * out2_stride + 16 * n + 4 * q) = relu4(t, relu2);
+            });
+        }
+    }
+}
+
+// The two 1x1x1 RPN heads of one pyramid level as ONE GEMM (lib/nets/network.py:41-42,541-549): rows [0,2A) =
+// rpn_cls_score_net, [2A,8A) = rpn_bbox_pred_net, K = 256 channels split over the 4 waves of a workgroup (one voxel tile of
+// 16 per workgroup), partial tiles summed through LDS; the epilogue writes the reference's permuted layouts directly --
+// score (2,X,Y,Z,A), prob = softmax over the two class planes, bbox (X,Y,Z,6A).  blockIdx.y selects the level (the
+// two levels have different anchor counts, hence different NT).
+struct HeadLevel {
+    const float *in, *wp, *bias;
+    float *score, *prob, *bbox;
+    int A;
+};
+struct HeadArgs {
+    HeadLevel lv[2];
+    int nvox, in_stride;
+};
+
+template <int NT, int C0>
+__device__ __forceinline__ void rpn_head_body(const HeadLevel &h, int nvox, int in_stride, float *lds)
+{
+    constexpr int KGW = C0 / 16 / 4;            // channel groups per wave
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mt = blockIdx.x;
+    int v = 16 * mt + li;
+    v = v < nvox ? v : nvox - 1;
+    float4 y[KGW];
+    const float *yp = h.in + (size_t)v * in_stride + 16 * KGW * wave + 4 * q;
+    static_for<0, KGW>([&](auto G) { y[decltype(G)::value] = *reinterpret_cast<const float4 *>(yp + 16 * decltype(G)::value); });
+    float4 w[NT][KGW];
+    static_for<0, NT>([&](auto N) {
+        constexpr int n = decltype(N)::value;
+        static_for<0, KGW>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            w[n][g] = reinterpret_cast<const float4 *>(h.wp)[((size_t)n * (C0 / 16) + KGW * wave + g) * 64 + lane];
+        });
+    });
+    f32x4 acc[NT];
+    gemm_t<NT, KGW>(w, y, acc);
+    // partial tiles -> LDS as [wave][cout][voxel] (cout-major rows of 16 voxels + 1 pad)
+    constexpr int RSZ = NT * 16 * 17;
+    static_for<0, NT>([&](auto N) {
+        constexpr int n = decltype(N)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[wave * RSZ + (16 * n + 4 * q + r) * 17 + li] = acc[n][r];
+    });
+    __syncthreads();
+    const int A = h.A, nout = 8 * A;
+    float *fin = lds + 4 * RSZ;                  // [cout][voxel] final sums (+ bias)
+    for (int i = threadIdx.x; i < nout * 16; i += 256) {
+        const int c = i >> 4, vv = i & 15;
+        const int o = c * 17 + vv;
+        fin[o] = (lds[o] + lds[RSZ + o]) + (lds[2 * RSZ + o] + lds[3 * RSZ + o]) + (h.bias ? h.bias[c] : 0.0f);
+    }
+    __syncthreads();
+    // score / prob: element (plane p, voxel, anchor a) at (p * nvox + voxel) * A + a ; bbox: voxel * 6A + j
+    for (int i = threadIdx.x; i < 16 * 2 * A; i += 256) {
+        const int vv = i / (2 * A), c = i % (2 * A);
+        const int vox = 16 * mt + vv;
+        if (vox >= nvox) continue;
+        const int pl = c / A, an = c % A;
+        const float s = fin[c * 17 + vv], sp = fin[(pl ? c - A : c + A) * 17 + vv];
+        const size_t o = ((size_t)pl * nvox + vox) * A + an;
+        h.score[o] = s;
+        if (h.prob) {
+            const float mx = fmaxf(s, sp);
+            const float e = expf(s - mx), ep = expf(sp - mx);
+            h.prob[o] = e / (e + ep);
+        }
+    }
+    for (int i = threadIdx.x; i < 16 * 6 * A; i += 256) {
+        const int vv = i / (6 * A), j = i % (6 * A);
+        const int vox = 16 * mt + vv;
+        if (vox < nvox) h.bbox[(size_t)vox * (6 * A) + j] = fin[(2 * A + j) * 17 + vv];
+    }
+}
+
+template <int NTA, int NTB, int C0>
+__global__ __launch_bounds__(256) void rpn_heads_kernel(const HeadArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (blockIdx.y == 0) rpn_head_body<NTA, C0>(a.lv[0], a.nvox, a.in_stride, lds);
+    else rpn_head_body<NTB, C0>(a.lv[1], a.nvox, a.in_stride, lds);
+}
+
 
 // (Cout,Cin[,1,1,1]) -> [cout/16][cin/16][lane 64][4]: lane (i = lane & 15, k = lane >> 4) holds W[16 n + i][16 g + 4 k + e]
 __global__ __launch_bounds__(256) void pack_weight_pw16_kernel(const float *__restrict__ w, int cout, int cin, int nt, int kg,
@@ -213,16 +379,29 @@ __global__ __launch_bounds__(256) void pack_weight_pw16_kernel(const float *__re
     }
 }
 
-template <int C0, int C1, int C2, int WS>
+template <int C0, int C1, int C2, int WS, int TAPS = 1>
 int launch_pw(const PwArgs &a, hipStream_t st)
 {
     const int nmt = (a.nvox + 15) / 16;
+    if constexpr (TAPS != 1) {
+        hipLaunchKernelGGL((pw16_kernel<C0, C1, C2, WS, TAPS>), dim3(WS == 1 ? (nmt + 3) / 4 : nmt), dim3(256), 0, st, a);
+        return sis3d_check_launch();
+    }
     // WS == 1: ~2 waves per SIMD, every wave loops over its tiles with the weights in registers; WS == 4: one tile per
     // workgroup pass
     int blocks = WS == 1 ? (nmt + 3) / 4 : nmt;
     const int cap = WS == 1 ? 512 : 2048;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((pw16_kernel<C0, C1, C2, WS>), dim3(blocks), dim3(256), 0, st, a);
+    return sis3d_check_launch();
+}
+
+template <int NTA, int NTB>
+int launch_heads(const HeadArgs &a, hipStream_t st)
+{
+    constexpr int NTM = NTA > NTB ? NTA : NTB;
+    const size_t lds = (size_t)5 * NTM * 16 * 17 * sizeof(float);
+    hipLaunchKernelGGL((rpn_heads_kernel<NTA, NTB, 256>), dim3((a.nvox + 15) / 16, 2), dim3(256), lds, st, a);
     return sis3d_check_launch();
 }
 
@@ -279,4 +458,78 @@ extern "C" int sis3d_conv3d_pw16(const float *in, int64_t nvox, int cin, int cin
     case 128 * 1000000 + 128 * 1000 + 0: return launch_pw<128, 128, 0, 4>(a, st);
     default: return SIS3D_EUNSUPPORTED;
     }
+}
+
+extern "C" int sis3d_conv3d_k2s2_pw16(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                                      int cout, int flags, float *out, int out_stride, int out_coff, const float *packed_w2,
+                                      const float *bias2, int cout2, int flags2, float *out2, int out2_stride, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || X < 2 || Y < 2 || Z < 2 || cin <= 0 || cout <= 0 || cout2 < 0) return SIS3D_EINVAL;
+    if ((cin_stride % 4) || cin_stride < cin || (out_stride % 4) || (out_coff % 4)) return SIS3D_EINVAL;
+    if (!out && cout2 == 0) return SIS3D_EINVAL;
+    if (cout2 > 0 && (!packed_w2 || !out2 || (out2_stride % 4) || out2_stride < cout2)) return SIS3D_EINVAL;
+    if ((flags & ~SIS3D_EPI_RELU) || (flags2 & ~SIS3D_EPI_RELU)) return SIS3D_EUNSUPPORTED;
+    const int64_t nvox = (int64_t)(X / 2) * (Y / 2) * (Z / 2);
+    if (nvox > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    PwArgs a;
+    a.in = in; a.in_stride = cin_stride; a.w1p = packed_w; a.b1 = bias; a.res = nullptr; a.res_stride = 0;
+    a.out = out; a.out_stride = out_stride; a.out_coff = out_coff; a.flags1 = flags;
+    a.w2p = packed_w2; a.b2 = bias2; a.out2 = out2; a.out2_stride = out2_stride; a.flags2 = flags2;
+    a.nvox = (int)nvox; a.iY = Y; a.iZ = Z; a.oY = Y / 2; a.oZ = Z / 2;
+    hipStream_t st = as_stream(stream);
+    const int key = cin * 1000000 + cout * 1000 + cout2;
+    switch (key) {
+    case 32 * 1000000 + 128 * 1000 + 32: return launch_pw<32, 128, 32, 4, 8>(a, st);
+    case 32 * 1000000 + 128 * 1000 + 0: return launch_pw<32, 128, 0, 4, 8>(a, st);
+    case 32 * 1000000 + 64 * 1000 + 32: return launch_pw<32, 64, 32, 4, 8>(a, st);
+    case 32 * 1000000 + 64 * 1000 + 0: return launch_pw<32, 64, 0, 4, 8>(a, st);
+    case 64 * 1000000 + 64 * 1000 + 32: return launch_pw<64, 64, 32, 4, 8>(a, st);
+    case 64 * 1000000 + 64 * 1000 + 0: return launch_pw<64, 64, 0, 4, 8>(a, st);
+    case 64 * 1000000 + 128 * 1000 + 32: return launch_pw<64, 128, 32, 4, 8>(a, st);
+    default: return SIS3D_EUNSUPPORTED;
+    }
+}
+
+extern "C" int sis3d_conv3d_stem_planar2(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, int X, int Y, int Z,
+                                         const float *packed_w, int cout, int flags, float *out, int out_stride,
+                                         const float *packed_w2, const float *bias2, int cout2, int flags2, float *out2,
+                                         int out2_stride, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || X < 2 || Y < 2 || Z < 2 || (out_stride % 4) || out_stride < cout) return SIS3D_EINVAL;
+    if (cout2 > 0 && (!packed_w2 || !out2 || (out2_stride % 4) || out2_stride < cout2)) return SIS3D_EINVAL;
+    if ((flags & ~SIS3D_EPI_RELU) || (flags2 & ~SIS3D_EPI_RELU)) return SIS3D_EUNSUPPORTED;
+    const int oX = X / 2, oY = Y / 2, oZ = Z / 2;
+    const int64_t nmt = ((int64_t)oX * oY * oZ + 15) / 16;
+    if (nmt > 0x7ffffff) return SIS3D_EUNSUPPORTED;
+    int blocks = (int)((nmt + 3) / 4);
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = as_stream(stream);
+#define STEM(C1, C2)                                                                                                              \
+    hipLaunchKernelGGL((stem_planar_kernel<C1, C2>), dim3(blocks), dim3(256), 0, st, in, is_c, is_x, is_y, oX, oY, oZ, packed_w, flags, \
+                       out, out_stride, packed_w2, bias2, flags2, out2, out2_stride);                                             \
+    return sis3d_check_launch();
+    if (cout == 32 && cout2 == 32) { STEM(32, 32) }
+    if (cout == 32 && cout2 == 0) { STEM(32, 0) }
+    if (cout == 64 && cout2 == 32) { STEM(64, 32) }
+    if (cout == 64 && cout2 == 0) { STEM(64, 0) }
+#undef STEM
+    return SIS3D_EUNSUPPORTED;
+}
+
+extern "C" int sis3d_rpn_heads(const float *in1, const float *packed_w1, const float *bias1, int anchors1, float *score1, float *prob1,
+                               float *bbox1, const float *in2, const float *packed_w2, const float *bias2, int anchors2, float *score2,
+                               float *prob2, float *bbox2, int64_t nvox, int cin, int cin_stride, sis3d_stream_t stream)
+{
+    if (!in1 || !in2 || !packed_w1 || !packed_w2 || !score1 || !score2 || !bbox1 || !bbox2 || nvox <= 0 || nvox > 0x7fffffff)
+        return SIS3D_EINVAL;
+    if (cin != 256 || (cin_stride % 4) || cin_stride < cin || anchors1 <= 0 || anchors2 <= 0) return SIS3D_EUNSUPPORTED;
+    HeadArgs a;
+    a.lv[0] = HeadLevel{in1, packed_w1, bias1, score1, prob1, bbox1, anchors1};
+    a.lv[1] = HeadLevel{in2, packed_w2, bias2, score2, prob2, bbox2, anchors2};
+    a.nvox = (int)nvox; a.in_stride = cin_stride;
+    hipStream_t st = as_stream(stream);
+    const int nta = (8 * anchors1 + 15) / 16, ntb = (8 * anchors2 + 15) / 16;
+    if (nta == 2 && ntb == 6) return launch_heads<2, 6>(a, st);       // ScanNet: 3 + 11 anchors
+    if (nta == 2 && ntb == 3) return launch_heads<2, 3>(a, st);       // SUNCG: 3 + 6 anchors
+    return SIS3D_EUNSUPPORTED;
 }

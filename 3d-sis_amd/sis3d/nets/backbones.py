@@ -135,6 +135,12 @@ class FusedSequential(nn.Sequential):
                 continue
             elif isinstance(m, HipMaxPool3d) and last and last_out is not None:
                 x, y1 = m(x, last_out, last_coff), None
+            elif isinstance(m, HipConv3d) and m.in_channels == 2 and m.kernel_size[0] == 2 and m.bias is None and m.fuse_relu \
+                    and torch.is_tensor(x) and not ops.is_cl(x) and self._stem_planar(m, consumer(i), x) is not None:
+                x, y1 = self._stem_out
+            elif isinstance(m, HipConv3d) and m.kernel_size[0] == 2 and consumer(i) is not None and torch.is_tensor(x) and ops.is_cl(x) \
+                    and self._stem_k2s2(m, consumer(i), x) is not None:
+                x, y1 = self._stem_out
             elif isinstance(m, HipConv3d) and FUSE_BOTTLENECK and consumer(i) is not None and not (m.in_channels == 2 and not ops.is_cl(x)) \
                     and not (SPLIT_BOTTLENECK and m.kernel_size[0] == 3 and m._packed.get(m).packed_t16 is not None):
                 nb = consumer(i)
@@ -151,6 +157,32 @@ class FusedSequential(nn.Sequential):
                     x = x.dense()
                 x, y1 = m(x), None
         return x
+
+
+def _stem_planar(self, m, nb, x):
+    """geometry1[0] + the first Bottleneck's conv1 as one register-chained launch; None if this shape has no instantiation"""
+    try:
+        stage = dict(pc=nb.conv1._packed.get(nb.conv1), relu=True) if nb is not None else None
+        ver = (m.weight._version, m.weight.data_ptr())
+        if getattr(m, "_stem_pack", None) is None or m._stem_pack[0] != ver:      # lives on the module that owns the parameter
+            m._stem_pack = (ver, ops.pack_stem_planar2(m.weight))
+        self._stem_out = ops.stem_planar2(x, m._stem_pack[1], m.out_channels, relu=True, stage=stage)
+    except ops.Sis3dUnsupported:
+        return None
+    return self._stem_out
+
+
+def _stem_k2s2(self, m, nb, x):
+    """a k2 s2 stem + the following Bottleneck's conv1 as one register-chained launch; None if unsupported"""
+    try:
+        self._stem_out = ops.conv3d_k2s2_pw16(x, m._packed.get(m), relu=m.fuse_relu, stage=dict(pc=nb.conv1._packed.get(nb.conv1), relu=True))
+    except ops.Sis3dUnsupported:
+        return None
+    return self._stem_out
+
+
+FusedSequential._stem_planar = _stem_planar
+FusedSequential._stem_k2s2 = _stem_k2s2
 
 
 def _conv_relu(cin, cout, k, stride=1, padding=0):

@@ -90,7 +90,7 @@ class Network(nn.Module):
         if hit is None or hit[0] != ver:
             w = torch.cat([cls.weight.detach(), box.weight.detach()], 0)
             b = torch.cat([cls.bias.detach(), box.bias.detach()], 0)
-            hit = (ver, ops.PackedConv(w, b))
+            hit = (ver, ops.PackedConv(w, b, pad_cout16=True))
             self._head_cache[lv] = hit
         return hit[1]
 
@@ -125,13 +125,16 @@ class Network(nn.Module):
         return [[self.mask_backbone(self._scene, None, window=w) for w in windows]]
 
     # ------------------------------------------------------------------ forward --
-    def _rpn_level(self, lv, feat, rpn=None):
+    def _rpn_level(self, lv, feat, rpn=None, heads=None):
         """network.py:539-549 for one pyramid level: k3 conv + ReLU, fused cls/bbox 1x1x1 heads, 2-way softmax"""
         cfg = self.cfg
         A = cfg["NUM_ANCHORS_LEVEL%d" % lv]
-        if rpn is None:
-            rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
-        score, bbox, prob = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)     # softmax fused into the head epilogue
+        if heads is not None:
+            score, bbox, prob = heads                      # both levels' heads came out of one launch (ops.rpn_heads)
+        else:
+            if rpn is None:
+                rpn = getattr(self, "rpn_net_level%d" % lv)(feat)
+            score, bbox, prob = ops.conv3d(rpn, self._rpn_head(lv), rpn_anchors=A)     # softmax fused into the head epilogue
         self._predictions["rpn_cls_score_level%d" % lv] = score
         self._predictions["rpn_cls_prob_level%d" % lv] = prob
         self._predictions["rpn_bbox_pred_level%d" % lv] = bbox
@@ -176,8 +179,12 @@ class Network(nn.Module):
         if cfg.NUM_ANCHORS_LEVEL1 != 0 and cfg.NUM_ANCHORS_LEVEL2 != 0 and self.batch_rpn and l1.shape == l2.shape:
             c1, c2 = self.rpn_net_level1, self.rpn_net_level2
             r1, r2 = ops.conv3d_batched([l1, l2], [c1._packed.get(c1), c2._packed.get(c2)], relu=True)
-            levels.append(self._rpn_level(1, l1, r1))
-            levels.append(self._rpn_level(2, l2, r2))
+            try:
+                h1, h2 = ops.rpn_heads(r1, self._rpn_head(1), cfg.NUM_ANCHORS_LEVEL1, r2, self._rpn_head(2), cfg.NUM_ANCHORS_LEVEL2)
+            except ops.Sis3dUnsupported:
+                h1 = h2 = None
+            levels.append(self._rpn_level(1, l1, r1, h1))
+            levels.append(self._rpn_level(2, l2, r2, h2))
         else:
             if cfg.NUM_ANCHORS_LEVEL1 != 0:
                 levels.append(self._rpn_level(1, l1))
@@ -208,7 +215,12 @@ class Network(nn.Module):
             self._scene, self._scene_info = scenes[i], scenes[i].shape[2:]
             self._predictions = {}
             self._net_conv = (l1, l2)
-            levels = [self._rpn_level(1, l1, rs[2 * i]), self._rpn_level(2, l2, rs[2 * i + 1])]
+            try:
+                h1, h2 = ops.rpn_heads(rs[2 * i], self._rpn_head(1), cfg.NUM_ANCHORS_LEVEL1, rs[2 * i + 1], self._rpn_head(2),
+                                       cfg.NUM_ANCHORS_LEVEL2)
+            except ops.Sis3dUnsupported:
+                h1 = h2 = None
+            levels = [self._rpn_level(1, l1, rs[2 * i], h1), self._rpn_level(2, l2, rs[2 * i + 1], h2)]
             outs.append((l1, l2, levels, self._predictions))
         return outs
 

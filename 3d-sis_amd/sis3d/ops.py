@@ -462,10 +462,96 @@ def conv3d_pw_chain(x, pc, residual=None, relu=True, out=None, out_coff=0, stage
     return out, so
 
 
+def conv3d_k2s2_pw16(x, pc, relu=True, stage=None, want_main=True):
+    """Conv3d(k2, s2) (+bias, ReLU) [+ the following 1x1x1 conv on its result] as one register-chained launch
+    (sis3d_conv3d_k2s2_pw16).  -> (main | None, stage_out | None); raises Sis3dUnsupported."""
+    if pc.k != 2 or pc.packed_pw16 is None or (stage is not None and stage["pc"].packed_pw16 is None) or not is_cl(x):
+        raise Sis3dUnsupported("no pw16 pack for this k2 s2 layer")
+    _, cin_t, X, Y, Z = x.shape
+    if cin_t != pc.cin:
+        raise _lib.Sis3dError("conv3d_k2s2_pw16: activation has %d channels, packed weight expects %d" % (cin_t, pc.cin))
+    od = (X // 2, Y // 2, Z // 2)
+    main = new_act(pc.cout, od, x.device) if want_main else None
+    so, spc = None, None
+    if stage is not None:
+        spc = stage["pc"]
+        if spc.k != 1 or spc.cin != pc.cout:
+            raise _lib.Sis3dError("conv3d_k2s2_pw16: stage expects %d input channels, k=1" % pc.cout)
+        so = new_act(spc.cout, od, x.device)
+    rc = lib().sis3d_conv3d_k2s2_pw16(_ptr(x), X, Y, Z, pc.cin, cin_t, _ptr(pc.packed_pw16), _ptr(pc.bias), pc.cout,
+                                      EPI_RELU if relu else 0, _ptr(main), pc.cout, 0, _ptr(spc.packed_pw16) if spc else None,
+                                      _ptr(spc.bias) if spc else None, spc.cout if spc else 0,
+                                      (EPI_RELU if stage.get("relu", True) else 0) if spc else 0, _ptr(so), spc.cout if spc else 0, _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no k2s2 pw16 instantiation for %d -> %d -> %s" % (pc.cin, pc.cout, spc.cout if spc else None))
+    check(rc, "sis3d_conv3d_k2s2_pw16")
+    return main, so
+
+
+def pack_stem_planar2(weight):
+    """pw16 pack of a Conv3d(2, C, k2, s2) weight viewed as (C, 16) (column = ci*8 + 4 dx + 2 dy + dz).  The caller owns the
+    result (HipConv3d keeps it next to the parameter it was made from)."""
+    cout = weight.shape[0]
+    w2 = _dev(weight.detach(), "weight").reshape(cout, 16).contiguous()
+    pk = torch.empty(lib().sis3d_conv_pw16_packed_floats(cout, 16), device=w2.device)
+    check(lib().sis3d_conv_pw16_pack_weight(_ptr(w2), cout, 16, _ptr(pk), _stream()), "sis3d_conv_pw16_pack_weight")
+    return pk
+
+
+def stem_planar2(x, packed, cout, relu=True, stage=None):
+    """geometry1[0] (Conv3d(2, C, k2, s2, bias=False) + ReLU on the planar grid) chained into the first Bottleneck's conv1
+    (sis3d_conv3d_stem_planar2).  packed: pack_stem_planar2(weight).  -> (x0 channels-last, conv1 output | None); raises
+    Sis3dUnsupported."""
+    x = _dev(x, "scene")
+    if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != 2 or x.stride(4) != 1 or PW_LEGACY:
+        raise Sis3dUnsupported("stem_planar2 expects the planar (1,2,X,Y,Z) grid")
+    _, _, X, Y, Z = x.shape
+    pk = packed
+    od = (X // 2, Y // 2, Z // 2)
+    out = new_act(cout, od, x.device)
+    so, spc = None, None
+    if stage is not None:
+        spc = stage["pc"]
+        if spc.packed_pw16 is None or spc.k != 1 or spc.cin != cout:
+            raise Sis3dUnsupported("stem_planar2: stage needs a pw16-packed 1x1x1 conv on %d channels" % cout)
+        so = new_act(spc.cout, od, x.device)
+    st = x.stride()
+    rc = lib().sis3d_conv3d_stem_planar2(_ptr(x), st[1], st[2], st[3], X, Y, Z, _ptr(pk), cout, EPI_RELU if relu else 0, _ptr(out), cout,
+                                         _ptr(spc.packed_pw16) if spc else None, _ptr(spc.bias) if spc else None, spc.cout if spc else 0,
+                                         (EPI_RELU if stage.get("relu", True) else 0) if spc else 0, _ptr(so), spc.cout if spc else 0,
+                                         _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no planar stem instantiation for 2 -> %d -> %s" % (cout, spc.cout if spc else None))
+    check(rc, "sis3d_conv3d_stem_planar2")
+    return out, so
+
+
+def rpn_heads(r1, pc1, A1, r2, pc2, A2):
+    """both RPN heads of both pyramid levels in one launch (sis3d_rpn_heads).  r?: rpn_net outputs (channels-last, 256 ch),
+    pc?: PackedConv of the stacked (8A, 256) head matrix.  -> ((score, bbox, prob) level 1, (score, bbox, prob) level 2)"""
+    if pc1.packed_pw16 is None or pc2.packed_pw16 is None or not is_cl(r1) or not is_cl(r2) or r1.shape != r2.shape:
+        raise Sis3dUnsupported("rpn_heads: needs pw16 packs and two channels-last maps of one shape")
+    _, C, X, Y, Z = r1.shape
+    od = (X, Y, Z)
+    outs = []
+    for A in (A1, A2):
+        score = torch.empty((1, 2) + od + (A,), device=r1.device)
+        outs.append((score, torch.empty((1,) + od + (6 * A,), device=r1.device), torch.empty_like(score)))
+    (s1, b1, p1), (s2, b2, p2) = outs
+    rc = lib().sis3d_rpn_heads(_ptr(r1), _ptr(pc1.packed_pw16), _ptr(pc1.bias), int(A1), _ptr(s1), _ptr(p1), _ptr(b1),
+                               _ptr(r2), _ptr(pc2.packed_pw16), _ptr(pc2.bias), int(A2), _ptr(s2), _ptr(p2), _ptr(b2),
+                               X * Y * Z, C, C, _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("rpn_heads: no instantiation for %d / %d anchors on %d channels" % (A1, A2, C))
+    check(rc, "sis3d_rpn_heads")
+    return outs[0], outs[1]
+
+
 class PackedConv:
     """Weights of one nn.Conv3d repacked into MFMA fragment order (sis3d_conv_pack_weight)."""
 
-    def __init__(self, weight, bias=None, cin_pad=None):
+    def __init__(self, weight, bias=None, cin_pad=None, pad_cout16=False):
+        """pad_cout16: also build the pw16 pack when cout is not a multiple of 16 (zero rows appended; the RPN heads)"""
         w = _dev(weight.detach(), "weight").contiguous()
         self.cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
         if not (w.shape[2] == w.shape[3] == w.shape[4]):
@@ -483,10 +569,17 @@ class PackedConv:
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
         # 1x1x1: second pack for the register-chained pointwise kernels (csrc/pointwise.hip): [cout/16][cin/16][64][4]
         self.packed_pw16 = None
-        if k == 1 and self.cin % 16 == 0 and self.cout % 16 == 0 and not PW_LEGACY:
+        if k == 1 and self.cin % 16 == 0 and (self.cout % 16 == 0 or pad_cout16) and not PW_LEGACY:
             npw = lib().sis3d_conv_pw16_packed_floats(self.cout, self.cin)
             self.packed_pw16 = torch.empty(npw, device=w.device)
             check(lib().sis3d_conv_pw16_pack_weight(_ptr(w), self.cout, self.cin, _ptr(self.packed_pw16), _stream()),
+                  "sis3d_conv_pw16_pack_weight")
+        # k2 s2: the same register-chained kernel with 8 gathered rows (column index tap*Cin + ci)
+        if k == 2 and self.cin % 16 == 0 and self.cout % 16 == 0 and not PW_LEGACY:
+            w2 = w.permute(0, 2, 3, 4, 1).reshape(self.cout, 8 * self.cin).contiguous()
+            npw = lib().sis3d_conv_pw16_packed_floats(self.cout, 8 * self.cin)
+            self.packed_pw16 = torch.empty(npw, device=w.device)
+            check(lib().sis3d_conv_pw16_pack_weight(_ptr(w2), self.cout, 8 * self.cin, _ptr(self.packed_pw16), _stream()),
                   "sis3d_conv_pw16_pack_weight")
         # second pack for the balanced k3 kernel (csrc/conv3d_t16.hip): [cout/16][cin/32][4][27][64][2]
         self.packed_t16 = None

@@ -268,6 +268,27 @@ int sis3d_conv3d_pw16(const float *in, int64_t nvox, int cin, int cin_stride, co
                       const float *packed_w2, const float *bias2, int cout2, int flags2, float *out2, int out2_stride,
                       sis3d_stream_t stream);
 
+/* Conv3d(cin, cout, k=2, s=2) (+ bias, ReLU) as the same register-chained GEMM with 8 gathered input rows per output voxel
+ * (the stems geometry1[4] / color[4], lib/nets/backbones.py:193,207), optionally chained into the following Bottleneck's
+ * conv1 (cout -> cout2).  in: (X,Y,Z) channels-last; output grid (X/2,Y/2,Z/2).  packed_w = sis3d_conv_pw16_pack_weight of
+ * the weight viewed as (Cout, 8*Cin) with column index tap*Cin + ci, tap = 4 dx + 2 dy + dz. */
+int sis3d_conv3d_k2s2_pw16(const float *in, int X, int Y, int Z, int cin, int cin_stride, const float *packed_w, const float *bias,
+                           int cout, int flags, float *out, int out_stride, int out_coff, const float *packed_w2,
+                           const float *bias2, int cout2, int flags2, float *out2, int out2_stride, sis3d_stream_t stream);
+/* geometry1[0] = Conv3d(2, cout, k=2, s=2, bias=False) + ReLU on the PLANAR 2-channel grid (backbones.py:188; same input
+ * addressing as sis3d_conv3d_planar2) chained into the first Bottleneck's conv1 (cout -> cout2, + bias2, ReLU).
+ * packed_w = sis3d_conv_pw16_pack_weight of the weight viewed as (Cout, 16) (column = ci*8 + 4 dx + 2 dy + dz). */
+int sis3d_conv3d_stem_planar2(const float *in, int64_t is_c, int64_t is_x, int64_t is_y, int X, int Y, int Z,
+                              const float *packed_w, int cout, int flags, float *out, int out_stride, const float *packed_w2,
+                              const float *bias2, int cout2, int flags2, float *out2, int out2_stride, sis3d_stream_t stream);
+/* Both RPN heads of BOTH pyramid levels in one launch (lib/nets/network.py:41-42,541-549): per level the 1x1x1 convs
+ * rpn_cls_score_net (2A rows) and rpn_bbox_pred_net (6A rows) stacked into one (8A, 256) matrix (pw16 pack), outputs in the
+ * reference's permuted layouts: score / prob (2,X,Y,Z,A) (prob = softmax over the two class planes; may be NULL),
+ * bbox (X,Y,Z,6A).  in?: the level's rpn_net output, nvox rows of cin_stride floats, cin = 256. */
+int sis3d_rpn_heads(const float *in1, const float *packed_w1, const float *bias1, int anchors1, float *score1, float *prob1,
+                    float *bbox1, const float *in2, const float *packed_w2, const float *bias2, int anchors2, float *score2,
+                    float *prob2, float *bbox2, int64_t nvox, int cin, int cin_stride, sis3d_stream_t stream);
+
 /* Conv3d(cin, cout, 3, padding=1) + bias + ReLU in the balanced "one workgroup per CU, one wave per SIMD" form
  * (csrc/conv3d_t16.hip): v_mfma_f32_16x16x4_f32, workgroup = brick of voxels x one 16-wide cout tile, the four waves
  * split the input channels.  Replaces the same cuDNN calls as sis3d_conv3d(ksize 3) for cin % 32 == 0, cout % 4 == 0;

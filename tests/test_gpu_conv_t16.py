@@ -172,3 +172,67 @@ def test_plain_k1_conv_routes_through_pw16_and_matches_legacy(ops):
     pc.packed_pw16 = saved
     assert (new - old).abs().max().item() <= 2e-5
     assert (new.cpu() - F.relu(F.conv3d(x.cpu(), w.cpu(), b.cpu()))).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,cnext,dims", [(32, 128, 32, (48, 24, 48)), (32, 128, None, (10, 6, 14)), (64, 64, 32, (20, 12, 16)),
+                                                 (32, 64, 32, (9, 7, 11)), (64, 128, 32, (8, 8, 8))])
+def test_k2s2_stem_register_chained_vs_torch_cpu(ops, cin, cout, cnext, dims):
+    """Conv3d(k2, s2, bias=False) + ReLU [+ next conv1] (backbones.py:193,207 + :29-31); odd extents floor like nn.Conv3d"""
+    g = torch.Generator().manual_seed(cin + cout + dims[0])
+    x = torch.randn(1, cin, *dims, generator=g)
+    w = _w(cout, cin, 2, g)
+    pc = ops.PackedConv(w.cuda(), None)
+    stage, w1, b1 = None, None, None
+    if cnext is not None:
+        w1, b1 = _w(cnext, cout, 1, g), torch.randn(cnext, generator=g) * 0.1
+        stage = dict(pc=ops.PackedConv(w1.cuda(), b1.cuda()), relu=True)
+    main, so = ops.conv3d_k2s2_pw16(cl(x), pc, relu=True, stage=stage)
+    want = F.relu(F.conv3d(x, w, None, stride=2))
+    assert main.shape == want.shape and (main.cpu() - want).abs().max().item() <= TOL
+    if cnext is not None:
+        assert (so.cpu() - F.relu(F.conv3d(want, w1, b1))).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("cout,cnext,dims", [(32, 32, (96, 48, 96)), (64, 32, (30, 22, 18)), (32, None, (7, 9, 5))])
+def test_planar_stem_register_chained_vs_torch_cpu(ops, cout, cnext, dims):
+    """geometry1[0] on the planar 2-channel grid + the first Bottleneck's conv1 (backbones.py:188 + :29-31)"""
+    g = torch.Generator().manual_seed(cout + dims[2])
+    x = torch.randn(1, 2, *dims, generator=g)
+    w = _w(cout, 2, 2, g)
+    stage, w1, b1 = None, None, None
+    if cnext is not None:
+        w1, b1 = _w(cnext, cout, 1, g), torch.randn(cnext, generator=g) * 0.1
+        stage = dict(pc=ops.PackedConv(w1.cuda(), b1.cuda()), relu=True)
+    pk = ops.pack_stem_planar2(w.cuda())
+    x0, y1 = ops.stem_planar2(x.cuda(), pk, cout, relu=True, stage=stage)
+    want = F.relu(F.conv3d(x, w, None, stride=2))
+    assert ops.is_cl(x0) and x0.shape == want.shape and (x0.cpu() - want).abs().max().item() <= TOL
+    if cnext is not None:
+        assert (y1.cpu() - F.relu(F.conv3d(want, w1, b1))).abs().max().item() <= TOL
+    # a window view of a larger grid (non-contiguous x / y strides), as the mask head and whole-scene callers pass
+    big = torch.randn(1, 2, dims[0] + 4, dims[1] + 2, dims[2], generator=g).cuda()
+    sub = big[:, :, 2:2 + dims[0], 1:1 + dims[1], :]
+    x0b, _ = ops.stem_planar2(sub, pk, cout, relu=True, stage=None)
+    assert (x0b.cpu() - F.relu(F.conv3d(sub.cpu(), w, None, stride=2))).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("A1,A2", [(3, 11), (3, 6)])
+def test_rpn_heads_one_launch_vs_torch_cpu(ops, A1, A2):
+    """network.py:541-549 for both levels: cls 1x1x1 -> view(1,2,A,..).permute(0,1,3,4,5,2), softmax over dim 1; bbox 1x1x1 -> permute"""
+    g = torch.Generator().manual_seed(A1 * 100 + A2)
+    dims = (24, 12, 24)
+    outs, ins, pcs = [], [], []
+    for A in (A1, A2):
+        r = torch.randn(1, 256, *dims, generator=g).clamp_(min=0)
+        wc, bc = _w(2 * A, 256, 1, g) * 4, torch.randn(2 * A, generator=g)
+        wb, bb = _w(6 * A, 256, 1, g), torch.randn(6 * A, generator=g) * 0.1
+        bbox = F.conv3d(r, wb, bb).permute(0, 2, 3, 4, 1).contiguous()
+        score = F.conv3d(r, wc, bc).view(1, 2, A, *dims).permute(0, 1, 3, 4, 5, 2).contiguous()
+        outs.append((score, bbox, F.softmax(score, dim=1)))
+        ins.append(cl(r))
+        pcs.append(ops.PackedConv(torch.cat([wc, wb], 0).cuda(), torch.cat([bc, bb], 0).cuda(), pad_cout16=True))
+    got = ops.rpn_heads(ins[0], pcs[0], A1, ins[1], pcs[1], A2)
+    for (s, b, p), (ws, wb_, wp) in zip(got, outs):
+        assert s.shape == ws.shape and b.shape == wb_.shape and s.is_contiguous() and b.is_contiguous()
+        assert (s.cpu() - ws).abs().max().item() <= TOL and (b.cpu() - wb_).abs().max().item() <= TOL
+        assert (p.cpu() - wp).abs().max().item() <= TOL
