@@ -40,59 +40,68 @@ def pack_block(records, num, origin):
 
 
 def gather_blocks(local_blocks, n_chunks, k_rows, group=None, solo=False):
-    """local_blocks: list of flat blocks for this rank's chunks (ascending chunk id).  Returns a
-    (n_chunks, block_floats) tensor ordered by chunk id, identical on every rank.  solo: a world of one whatever
-    process group exists (no collective)."""
+    """local_blocks: this rank's flat record blocks in ascending chunk order -- a list of 1-D tensors or one (n_local, bf)
+    tensor.  Returns a (n_chunks, block_floats) tensor ordered by chunk id, identical on every rank: ONE collective
+    (`all_gather_into_tensor` under RCCL) per scene.  solo: a world of one whatever process group exists (no collective)."""
     live = dist.is_initialized() and not solo
     world = dist.get_world_size(group) if live else 1
     rank = dist.get_rank(group) if live else 0
     per_rank = (n_chunks + world - 1) // world
     bf = block_floats(k_rows)
-    ref = local_blocks[0] if local_blocks else None
-    device = ref.device if ref is not None else torch.device("cpu")
-    send = torch.zeros(per_rank, bf, device=device)
-    for i, b in enumerate(local_blocks):
-        send[i] = b
-    if world == 1:
-        allb = send.unsqueeze(0)
+    if torch.is_tensor(local_blocks):
+        mine = local_blocks
+        device = mine.device
     else:
-        recv = torch.empty(world, per_rank, bf, device=device)
-        if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(recv, send, group=group)       # one RCCL collective per scene
-        else:
-            parts = [torch.empty_like(send) for _ in range(world)]
-            dist.all_gather(parts, send, group=group)
-            recv = torch.stack(parts, 0)
-        allb = recv
-    # (rank r, slot i) holds chunk r + i*world
-    out = torch.zeros(n_chunks, bf, device=device)
-    for r in range(world):
-        ids = shard_chunks(n_chunks, r, world)
-        if ids:
-            out[ids] = allb[r, :len(ids)]
-    return out
+        device = local_blocks[0].device if local_blocks else torch.device("cpu")
+        mine = torch.stack(list(local_blocks)) if local_blocks else torch.zeros(0, bf, device=device)
+    if world == 1:
+        return mine if mine.shape[0] == n_chunks else torch.cat([mine, torch.zeros(n_chunks - mine.shape[0], bf, device=device)])
+    if mine.shape[0] == per_rank:
+        send = mine.contiguous()
+    else:                                                    # ranks with one chunk fewer pad their slot with an empty block
+        send = torch.zeros(per_rank, bf, device=device)
+        send[:mine.shape[0]] = mine
+    recv = torch.empty(world, per_rank, bf, device=device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, send, group=group)       # one RCCL collective per scene
+    else:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send, group=group)
+        recv = torch.stack(parts, 0)
+    # (rank r, slot i) holds chunk r + i*world: chunk c sits at flat row (c % world) * per_rank + c // world
+    idx = torch.tensor([(c % world) * per_rank + c // world for c in range(n_chunks)], device=device)
+    return recv.view(world * per_rank, bf).index_select(0, idx)
 
 
-def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_chunk_ids=False):
+def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_chunk_ids=False, box_cols=(0, 6)):
     """Whole-scene NMS over the gathered blocks.  Valid rows are taken in (chunk id, row) order and sorted by
     score with a STABLE descending sort, so ties break by (chunk, row) -- deterministic and rank-independent.
     Returns (records_sorted (N,W), keep LongTensor) with keep indexing records_sorted
-    (+ the producing chunk id of every sorted record if with_chunk_ids)."""
+    (+ the producing chunk id of every sorted record if with_chunk_ids).
+
+    Which boxes: the north star asks for an all-gather of per-chunk PROPOSALS before the whole-scene NMS, so by default
+    the suppression runs on the proposal box (columns 0:6) ordered by the RPN objectness (column 6) -- the same quantities
+    the per-chunk NMS used, which makes the merged list exactly what a single NMS over all chunks' proposals would keep.
+    Callers that want duplicates judged on the class-refined detections pass box_cols=(10, 16), score_col=9."""
     n_chunks = blocks.shape[0]
+    dev = blocks.device
     counts = blocks[:, 0].round().long().clamp(0, k_rows)
-    rows = blocks[:, 1:].reshape(n_chunks, k_rows, RECORD_WIDTH)
-    valid = torch.arange(k_rows, device=blocks.device).view(1, -1) < counts.view(-1, 1)
-    recs = rows[valid]                                            # (N, W) in (chunk,row) order
-    cids = torch.arange(n_chunks, device=blocks.device).view(-1, 1).expand(n_chunks, k_rows)[valid]
-    if recs.shape[0] == 0:
-        keep = torch.zeros(0, dtype=torch.long, device=blocks.device)
+    rows = blocks[:, 1:].reshape(n_chunks * k_rows, RECORD_WIDTH)
+    valid = (torch.arange(k_rows, device=dev).view(1, -1) < counts.view(-1, 1)).reshape(-1)
+    # invalid (padding) rows sort behind every real record; one stable sort of the fixed-size table, one count readback
+    key = torch.where(valid, rows[:, score_col], torch.full_like(rows[:, score_col], float("-inf")))
+    _, order = torch.sort(key, descending=True, stable=True)
+    total = int(counts.sum().item())
+    order = order[:total]
+    recs = rows.index_select(0, order)
+    cids = order // k_rows
+    if total == 0:
+        keep = torch.zeros(0, dtype=torch.long, device=dev)
         return (recs, keep, cids) if with_chunk_ids else (recs, keep)
-    _, order = torch.sort(recs[:, score_col], descending=True, stable=True)
-    recs = recs[order]
-    keep = nms_fn(recs[:, :6].contiguous(), thresh)
+    keep = nms_fn(recs[:, box_cols[0]:box_cols[1]].contiguous(), thresh)
     if max_keep > 0:
         keep = keep[:max_keep]
-    return (recs, keep, cids[order]) if with_chunk_ids else (recs, keep)
+    return (recs, keep, cids) if with_chunk_ids else (recs, keep)
 
 
 def mask_windows_of(rows, origin, class_thresh):

@@ -18,6 +18,8 @@ class SceneRunner:
         self.solo = bool(solo)
         self.k_rows = int(net.cfg.TEST.RPN_POST_NMS_TOP_N)
         self.pipes = PipelinedEngines(net, inflight, dims=dims, stage="detect", use_graph=use_graph).prepare()
+        self._origins = {}
+        self._send = None
 
     def mask_fn(self, payload, windows, classes):
         """mask head of one chunk's surviving detections: one ragged launch per layer for all its boxes, then the predicted
@@ -29,33 +31,52 @@ class SceneRunner:
         t = float(self.net.cfg.MASK_THRESH)
         return [(p[0, k] >= t).float() for p, k in zip(preds, classes)]
 
-    def infer(self, chunks, thresh=None, group=None, max_keep=0, with_masks=False):
-        """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d) or None)] for the whole scene (entries of other
-        ranks' chunks may carry None).  -> (records (N,16) sorted by score, keep LongTensor) on the GPU, identical on
-        every rank; with_masks adds this rank's {position in keep: (scene window, mask)} (parallel.scene_masks)."""
-        thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
+    def _origin(self, origin):
+        """device copy of a chunk origin, made once per distinct origin (a pageable H2D copy per chunk would stall the host)"""
+        key = (float(origin[0]), float(origin[1]), float(origin[2]))
+        t = self._origins.get(key)
+        if t is None:
+            t = torch.tensor(key, device=self.pipes.engines[0].device)
+            self._origins[key] = t
+        return t
+
+    def run_chunks(self, chunks, group=None):
+        """this rank's chunks through the captured per-chunk graphs, `inflight` at a time -> (n_local, block_floats) tensor of
+        record blocks in ascending chunk order (rows are written by async device copies on the pipelines' streams; the
+        current stream waits for all of them before returning)"""
         live = dist.is_initialized() and not self.solo
         world = dist.get_world_size(group) if live else 1
         rank = dist.get_rank(group) if live else 0
-        n_chunks = len(chunks)
-        main = torch.cuda.current_stream()
-        local = []
+        mine = parallel.shard_chunks(len(chunks), rank, world)
+        bf = parallel.block_floats(self.k_rows)
+        dev = self.pipes.engines[0].device
+        if self._send is None or self._send.shape[0] != len(mine):
+            self._send = torch.zeros(max(1, len(mine)), bf, device=dev)
+        send = self._send
         with torch.no_grad():
-            for j, c in enumerate(parallel.shard_chunks(n_chunks, rank, world)):
+            for j, c in enumerate(mine):
                 cid, origin, payload = chunks[c]
                 e = j % len(self.pipes.engines)
                 if isinstance(payload, (tuple, list)):
                     self.pipes.load(e, *payload)
                 else:
                     self.pipes.load(e, payload)
+                eng = self.pipes.engines[e]
                 with torch.cuda.stream(self.pipes.streams[e]):
-                    self.pipes.engines[e].set_origin(origin)
-                out = self.pipes.run(e)
-                with torch.cuda.stream(self.pipes.streams[e]):
-                    blk = out["block"].clone()                 # packed inside the captured graph; copy out of the static buffer
-                blk.record_stream(main)
-                local.append(blk)
+                    eng.origins[0].copy_(self._origin(origin), non_blocking=True)
+                    out = eng.run()
+                    send[j].copy_(out["block"], non_blocking=True)     # out of the graph's static buffer before its next replay
             self.pipes.join()
+        return send[:len(mine)]
+
+    def infer(self, chunks, thresh=None, group=None, max_keep=0, with_masks=False):
+        """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d) or None)] for the whole scene (entries of other
+        ranks' chunks may carry None).  -> (records (N,16) sorted by score, keep LongTensor) on the GPU, identical on
+        every rank; with_masks adds this rank's {position in keep: (scene window, mask)} (parallel.scene_masks)."""
+        thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
+        n_chunks = len(chunks)
+        with torch.no_grad():
+            local = self.run_chunks(chunks, group)
             blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group, solo=self.solo)
             if not with_masks:
                 return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep)
