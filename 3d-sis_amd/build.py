@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "sis3d", "libsis3d_hip.so")
 OBJ = os.path.join(HERE, "build")
 
 EXACT = ["nms.hip", "roi_pool.hip", "projection.hip", "frustum.hip", "proposal.hip", "pool_misc.hip", "api.hip", "topk.hip"]
-FAST = ["conv3d.hip", "conv3d_t16.hip", "pointwise.hip", "mlp.hip"]
+FAST = ["conv3d.hip", "conv3d_t16.hip", "pointwise.hip", "mlp.hip", "mlp16.hip"]
 
 
 def _newer(src, dst):
@@ -28,7 +28,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "sis3d.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma16.h"), os.path.join(ROOT, "include", "sis3d.h")]
     objs = []
     for name in EXACT + FAST:
         src = os.path.join(CSRC, name)

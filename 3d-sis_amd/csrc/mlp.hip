@@ -23,8 +23,9 @@ constexpr int FC_KW = 4;        // waves splitting the k-groups of a chunk
 // x [R][K] row-major (row stride ldx), wp packed [N/32][K/8][64][4]; part [S][Rpad][N]
 __global__ __launch_bounds__(64 * FC_NW *FC_KW) void fc_splitk_kernel(const float *__restrict__ x, int R, int K, int ldx,
                                                                      const float *__restrict__ wp, int N, int chunks_per_slice,
-                                                                     float *__restrict__ part, int Rpad)
+                                                                     float *__restrict__ part, int Rpad, const int32_t *__restrict__ nrows)
 {
+    if (nrows && (int)blockIdx.x * 32 >= nrows[0]) return;     // a row tile past the live rows: the tail writes its zeros
     constexpr int RS = FC_CK + 4, KGC = FC_CK / 8, KGW = KGC / FC_KW;
     __shared__ __attribute__((aligned(16))) float lds[32 * RS > (FC_KW - 1) * FC_NW * 1024 ? 32 * RS : (FC_KW - 1) * FC_NW * 1024];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +97,7 @@ struct TailArgs {
     int NC;
     float *cls_score, *cls_prob, *bbox_pred;   // [R][NC], [R][NC], [R][6NC]
     int64_t *cls_pred;                         // [R]
+    const int32_t *nrows;                      // device count of live rows (may be NULL): tiles past it are zero-filled
 };
 
 constexpr int TAIL_WAVES = 8;
@@ -151,6 +153,17 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void mlp_tail_kernel(const TailArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * 32;
     const int nh = a.NC * 7, nh_pad = (nh + 31) / 32 * 32;
+    if (a.nrows && m0 >= a.nrows[0]) {
+        // padded rows only (RPN_POST_NMS_TOP_N rows are allocated, `num` are proposals): defined, zero outputs, no work
+        for (int idx = tid; idx < 32 * nh; idx += 64 * TAIL_WAVES) {
+            const int row = idx / nh, c = idx % nh;
+            if (m0 + row >= a.R) continue;
+            if (c < a.NC) { a.cls_score[(size_t)(m0 + row) * a.NC + c] = 0.0f; a.cls_prob[(size_t)(m0 + row) * a.NC + c] = 0.0f; }
+            else a.bbox_pred[(size_t)(m0 + row) * (6 * a.NC) + (c - a.NC)] = 0.0f;
+        }
+        if (tid < 32 && m0 + tid < a.R) a.cls_pred[m0 + tid] = 0;
+        return;
+    }
     const int wmax = max(max(a.C1, nh_pad), max(a.C2, a.C3));
     float *t0 = lds, *t1 = lds + 32 * (wmax + 4);
     // fc1: sum of the K-slices + bias + ReLU -> t0 [32][C1+4]
@@ -215,6 +228,16 @@ extern "C" int sis3d_classifier_forward(const float *x, int R, int K, int ldx, c
                                         int64_t *cls_pred, float *bbox_pred, float *workspace, size_t workspace_floats,
                                         sis3d_stream_t stream)
 {
+    return sis3d_classifier_forward_n(x, R, nullptr, K, ldx, w1p, b1, C1, w2p, b2, C2, w3p, b3, C3, whp, bh, NC, cls_score, cls_prob,
+                                      cls_pred, bbox_pred, workspace, workspace_floats, stream);
+}
+
+extern "C" int sis3d_classifier_forward_n(const float *x, int R, const int32_t *nrows_dev, int K, int ldx, const float *w1p,
+                                          const float *b1, int C1, const float *w2p, const float *b2, int C2, const float *w3p,
+                                          const float *b3, int C3, const float *whp, const float *bh, int NC, float *cls_score,
+                                          float *cls_prob, int64_t *cls_pred, float *bbox_pred, float *workspace,
+                                          size_t workspace_floats, sis3d_stream_t stream)
+{
     if (R < 0) return SIS3D_EINVAL;
     if (R == 0) return SIS3D_OK;
     if (!x || !w1p || !b1 || !w2p || !b2 || !w3p || !b3 || !whp || !bh || !cls_score || !cls_prob || !cls_pred || !bbox_pred)
@@ -226,13 +249,13 @@ extern "C" int sis3d_classifier_forward(const float *x, int R, int K, int ldx, c
     if (!workspace || workspace_floats < (size_t)slices * Rpad * C1) return SIS3D_EWORKSPACE;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(fc_splitk_kernel, dim3(Rpad / 32, (C1 / 32 + FC_NW - 1) / FC_NW, slices), dim3(64 * FC_NW * FC_KW), 0, st, x, R,
-                       K, ldx, w1p, C1, (K / FC_CK) / slices, workspace, Rpad);
+                       K, ldx, w1p, C1, (K / FC_CK) / slices, workspace, Rpad, nrows_dev);
     int rc = sis3d_check_launch();
     if (rc) return rc;
     TailArgs a;
     a.part = workspace; a.S = slices; a.R = R; a.Rpad = Rpad; a.C1 = C1; a.b1 = b1;
     a.w2 = w2p; a.b2 = b2; a.C2 = C2; a.w3 = w3p; a.b3 = b3; a.C3 = C3; a.wh = whp; a.bh = bh; a.NC = NC;
-    a.cls_score = cls_score; a.cls_prob = cls_prob; a.bbox_pred = bbox_pred; a.cls_pred = cls_pred;
+    a.cls_score = cls_score; a.cls_prob = cls_prob; a.bbox_pred = bbox_pred; a.cls_pred = cls_pred; a.nrows = nrows_dev;
     const int cmax = C1 > C2 ? (C1 > C3 ? C1 : C3) : (C2 > C3 ? C2 : C3);
     const int nh_pad = (NC * 7 + 31) / 32 * 32;
     const int w = cmax > nh_pad ? cmax : nh_pad;

@@ -54,13 +54,13 @@ __device__ __forceinline__ Box load_box(const float *boxes, const int64_t *order
 // One wave computes the 64 mask words of tile (rb, cb): word for row 64*rb+r has bit j set
 // iff box 64*cb+j is suppressed by row box, j > i.  rows[] = the 64 row boxes in LDS.
 __device__ __forceinline__ uint64_t tile_word(const Box *rows, const Box &col, bool col_valid, int rb, int cb, int n,
-                                              float thresh, int lane)
+                                              float thresh, int lane, int r0 = 0, int r1 = 64)
 {
     uint64_t mine = 0;
     const int col_idx = 64 * cb + lane;
-    const int nrows = min(64, n - 64 * rb);
+    const int nrows = min(r1, n - 64 * rb);
 #pragma unroll 4
-    for (int r = 0; r < nrows; ++r) {
+    for (int r = r0; r < nrows; ++r) {
         const Box a = rows[r];                       // LDS broadcast (same address in all lanes)
         const float v = iou3d(a, col);
         const bool sup = col_valid && (col_idx > 64 * rb + r) && !(v <= thresh);
@@ -71,25 +71,30 @@ __device__ __forceinline__ uint64_t tile_word(const Box *rows, const Box &col, b
 }
 
 // ---------------------------------------------------------------- global-matrix path
+// one 64x64 tile per workgroup of MASK_WAVES waves: wave w walks rows [R w, R (w+1)), R = 64 / MASK_WAVES (the 64
+// dependent ballot steps of a tile were the latency of this kernel: 11.9 us at n = 400 with one wave per tile)
+constexpr int MASK_WAVES = 4;
+
 template <bool INDIRECT>
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order, int n,
-                                                      float thresh, uint64_t *__restrict__ mask)
+__global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order,
+                                                                   int n, float thresh, uint64_t *__restrict__ mask)
 {
-    const int cb = blockIdx.x, rb = blockIdx.y, lane = threadIdx.x;
+    const int cb = blockIdx.x, rb = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col_blocks = (n + 63) / 64;
+    constexpr int R = 64 / MASK_WAVES;
     __shared__ Box rows[64];
     const int ri = 64 * rb + lane;
     if (cb < rb) {                                   // strictly-lower tiles are never read by the sweep
-        if (ri < n) mask[(size_t)ri * col_blocks + cb] = 0;
+        if (wave == 0 && ri < n) mask[(size_t)ri * col_blocks + cb] = 0;
         return;
     }
-    if (ri < n) rows[lane] = load_box<INDIRECT>(boxes, order, ri);
+    if (wave == 0 && ri < n) rows[lane] = load_box<INDIRECT>(boxes, order, ri);
     __syncthreads();
     const int ci = 64 * cb + lane;
     Box col = {0, 0, 0, 0, 0, 0, 1, 0};
     if (ci < n) col = load_box<INDIRECT>(boxes, order, ci);
-    const uint64_t w = tile_word(rows, col, ci < n, rb, cb, n, thresh, lane);
-    if (ri < n) mask[(size_t)ri * col_blocks + cb] = w;
+    const uint64_t w = tile_word(rows, col, ci < n, rb, cb, n, thresh, lane, R * wave, R * (wave + 1));
+    if (lane >= R * wave && lane < R * (wave + 1) && ri < n) mask[(size_t)ri * col_blocks + cb] = w;
 }
 
 // Greedy sweep: ONE workgroup of 1024 threads over the bit matrix produced by nms_mask_kernel.
@@ -211,7 +216,7 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     uint64_t *mask = (uint64_t *)ws;
     if (n > 0) {
         // the bit matrix on as many CUs as it has 64x64 tiles (a single workgroup is VALU-bound: 28 us for n = 400)
-        hipLaunchKernelGGL((nms_mask_kernel<INDIRECT>), dim3(cb, cb), dim3(64), 0, st, boxes, order, n, thresh, mask);
+        hipLaunchKernelGGL((nms_mask_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, thresh, mask);
         int rc = sis3d_check_launch();
         if (rc) return rc;
     }
@@ -252,7 +257,7 @@ extern "C" int sis3d_nms_mask(const float *boxes, int n, float thresh, uint64_t 
 {
     if (n <= 0 || !mask) return n == 0 ? SIS3D_OK : SIS3D_EINVAL;
     const int cb = (n + 63) / 64;
-    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(cb, cb), dim3(64), 0, as_stream(stream), boxes, nullptr, n, thresh, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, as_stream(stream), boxes, nullptr, n, thresh, mask);
     return sis3d_check_launch();
 }
 

@@ -18,6 +18,7 @@
 // read that all 64 lanes consume.  The 3.5 MB maps stay L2-resident.
 #include "common.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -100,6 +101,93 @@ __global__ void roi_pool_kernel(const float *__restrict__ f1, const float *__res
     }
 }
 
+// ---- two-level pooling on channels-last maps, values only (the network's path: no argmax is kept in TEST mode).
+// The bin-per-workgroup form above launches bins x R = 12,800 two-wave workgroups whose life is one or two dependent L2 round
+// trips: the launch rate and the exposed latency, not bytes, set its 22 us.  Here a workgroup owns (RoI, pw): its 4 waves
+// take the PH*PL bins of that slab four at a time, lanes hold V consecutive channels (C = 64 V), and the first voxels of all
+// four windows are requested together (16 loads in flight per lane).  max() is order-independent, so the values equal the
+// scan-order maximum of the reference bit for bit (up to the sign of a zero, which no comparison sees).
+template <int V> struct VecOf;
+template <> struct VecOf<1> { typedef float T; };
+template <> struct VecOf<2> { typedef float2 T; };
+template <> struct VecOf<4> { typedef float4 T; };
+
+template <int V>
+__global__ __launch_bounds__(256) void roi_pool_slab_kernel(const float *__restrict__ f1, const float *__restrict__ f2, int W, int H, int L,
+                                                            int64_t fs_w, int64_t fs_h, int64_t fs_l, const float *__restrict__ rois,
+                                                            const float *__restrict__ levels, int PW, int PH, int PL, float scale,
+                                                            float *__restrict__ out, int64_t os_n, int64_t os_bin)
+{
+    typedef typename VecOf<V>::T vec;
+    const int pw = blockIdx.x, n = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float lv = levels[n];
+    const float *feat = lv == 1.0f ? f1 : f2;
+    const bool live = lv == 1.0f || lv == 2.0f;
+    RoiGeom g = {0, 0, 0, 0.f, 0.f, 0.f};
+    int ws = 0, we = 0;
+    if (live) {
+        g = roi_geom(rois + 6 * n, scale, PW, PH, PL);
+        bin_range(pw, g.bw, g.rs_w, W, ws, we);
+    }
+    const int nb = PH * PL;
+    for (int b0 = 4 * wave; b0 < nb; b0 += 16) {
+        int hs[4], ls[4], nh[4], nl[4], nwin[4];
+        int maxwin = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + k;
+            int he = 0, le = 0;
+            hs[k] = ls[k] = 0;
+            if (live && b < nb) {
+                bin_range(b / PL, g.bh, g.rs_h, H, hs[k], he);
+                bin_range(b % PL, g.bl, g.rs_l, L, ls[k], le);
+            }
+            nh[k] = max(he - hs[k], 0);
+            nl[k] = max(le - ls[k], 0);
+            nwin[k] = max(we - ws, 0) * nh[k] * nl[k];
+            maxwin = max(maxwin, nwin[k]);
+        }
+        float mx[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) mx[k][e] = nwin[k] > 0 ? -FLT_MAX : 0.0f;
+        for (int i0 = 0; i0 < maxwin; i0 += 4) {
+            vec v[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = min(i0 + j, max(nwin[k] - 1, 0));
+                    const int hl = max(nh[k] * nl[k], 1), nlk = max(nl[k], 1);
+                    const int w = ws + i / hl, h = hs[k] + (i / nlk) % max(nh[k], 1), l = ls[k] + i % nlk;
+                    const bool ok = nwin[k] > 0;
+                    v[k][j] = *reinterpret_cast<const vec *>(feat + (ok ? (int64_t)w * fs_w + (int64_t)h * fs_h + (int64_t)l * fs_l : 0) + V * lane);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j < nwin[k]) {
+                        const float *pv = reinterpret_cast<const float *>(&v[k][j]);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) mx[k][e] = fmaxf(mx[k][e], pv[e]);
+                    }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + k;
+            if (b >= nb) continue;
+            vec o;
+            float *po = reinterpret_cast<float *>(&o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) po[e] = mx[k][e];
+            *reinterpret_cast<vec *>(out + (int64_t)n * os_n + (int64_t)(pw * nb + b) * os_bin + V * lane) = o;
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int sis3d_roi_pool_forward(const float *features, int C, int W, int H, int L, int64_t fs_c, int64_t fs_w,
@@ -123,6 +211,16 @@ extern "C" int sis3d_roi_pool_levels(const float *f1, const float *f2, int C, in
     if (!f1 || !f2 || !out || !levels || C <= 0 || W <= 0 || H <= 0 || L <= 0 || pooled <= 0 || R < 0) return SIS3D_EINVAL;
     if (R == 0) return SIS3D_OK;
     if (!rois) return SIS3D_EINVAL;
+    // channels-last maps and rows (the network's layout): the slab kernel
+    if (fs_c == 1 && os_c == 1 && (C == 64 || C == 128 || C == 256) && (fs_w % 4) == 0 && (fs_h % 4) == 0 && (fs_l % 4) == 0 &&
+        (os_n % 4) == 0 && (os_bin % 4) == 0 && !getenv("SIS3D_ROIPOOL_LEGACY")) {
+        const dim3 grid(pooled, R), block(256);
+        hipStream_t st = as_stream(stream);
+        if (C == 64) hipLaunchKernelGGL((roi_pool_slab_kernel<1>), grid, block, 0, st, f1, f2, W, H, L, fs_w, fs_h, fs_l, rois, levels, pooled, pooled, pooled, scale, out, os_n, os_bin);
+        else if (C == 128) hipLaunchKernelGGL((roi_pool_slab_kernel<2>), grid, block, 0, st, f1, f2, W, H, L, fs_w, fs_h, fs_l, rois, levels, pooled, pooled, pooled, scale, out, os_n, os_bin);
+        else hipLaunchKernelGGL((roi_pool_slab_kernel<4>), grid, block, 0, st, f1, f2, W, H, L, fs_w, fs_h, fs_l, rois, levels, pooled, pooled, pooled, scale, out, os_n, os_bin);
+        return sis3d_check_launch();
+    }
     const int threads = C >= 256 ? 256 : (C > 64 ? 128 : 64);
     hipLaunchKernelGGL((roi_pool_kernel<true>), dim3(pooled * pooled * pooled, R), dim3(threads), 0, as_stream(stream), f1, f2, C,
                        W, H, L, fs_c, fs_w, fs_h, fs_l, rois, levels, pooled, pooled, pooled, scale, out, nullptr, os_n, os_c,

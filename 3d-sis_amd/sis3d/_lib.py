@@ -35,6 +35,11 @@ SIGNATURES = {
     "sis3d_classifier_workspace_floats": (c_sz, [c_int, c_int, c_int]),
     "sis3d_classifier_forward": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp,
                                          c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sis3d_classifier_forward_n": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
+                                           c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sis3d_classifier16_workspace_floats": (c_sz, [c_int, c_int, c_int]),
+    "sis3d_classifier16_forward": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
+                                           c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_conv_packed_floats": (c_sz, [c_int, c_int, c_int]),
     "sis3d_conv_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,

@@ -111,7 +111,7 @@ class Network(nn.Module):
         if hit is None or hit.version != ver:
             hit = ops.PackedClassifier(fcs, heads[0], heads[1], pool5.shape[1], ps ** 3)
             self._head_cache["mlp"] = hit
-        return ops.classifier_forward(x, hit)
+        return ops.classifier_forward(x, hit, p.get("num"))      # device-side row count: dead 32-row tiles are skipped
 
     # network.py:283-317
     def _mask_branch(self, n):

@@ -40,7 +40,7 @@ def nms_raw(dets, thresh, max_keep=0):
         raise _lib.Sis3dError("dets must be (N,6)")
     n = dets.shape[0]
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=dets.device)
-    num = torch.zeros(1, dtype=torch.int32, device=dets.device)
+    num = torch.empty(1, dtype=torch.int32, device=dets.device)      # written by the sweep kernel on every path
     wsb = lib().sis3d_nms_workspace_bytes(n)
     ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dets.device)
     check(lib().sis3d_nms(_ptr(dets), n, float(thresh), int(max_keep), _ptr(keep), _ptr(num), _ptr(ws), wsb, _stream()), "sis3d_nms")
@@ -71,7 +71,7 @@ def nms_select(boxes_all, level_all, scores_sorted, order, n, thresh, max_keep):
     scores = torch.empty(max_keep, device=dev)
     levels = torch.empty(max_keep, device=dev)
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    num = torch.empty(1, dtype=torch.int32, device=dev)               # written by the sweep kernel on every path
     wsb = lib().sis3d_nms_workspace_bytes(n)
     ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
     check(lib().sis3d_nms_select(_ptr(_dev(boxes_all, "boxes_all")), _ptr(_dev(level_all, "level_all")),
@@ -351,6 +351,7 @@ import os as _os
 
 K3_LEGACY = bool(_os.environ.get("SIS3D_K3_LEGACY"))       # A/B switch: every k3 conv through conv3d.hip's 32x32 tiles
 K3_BRICK = int(_os.environ.get("SIS3D_K3_BRICK", "-1"))    # tuning hook: force a brick of sis3d_conv3d_k3t16
+MLP_LEGACY = bool(_os.environ.get("SIS3D_MLP_LEGACY"))     # A/B switch: classifier through mlp.hip (32x32 tiles)
 PW_LEGACY = bool(_os.environ.get("SIS3D_PW_LEGACY"))       # A/B switch: 1x1x1 convs through conv3d.hip only
 
 
@@ -764,7 +765,7 @@ class PackedClassifier:
     def __init__(self, fcs, cls_head, box_head, pool_c, pool_bins):
         (w1, b1), (w2, b2), (w3, b3) = [(m.weight.detach(), m.bias.detach()) for m in fcs]
         w1 = w1.view(w1.shape[0], pool_c, pool_bins).permute(0, 2, 1).reshape(w1.shape[0], -1).contiguous()
-        mk = lambda w, b: PackedConv(w.reshape(w.shape[0], w.shape[1], 1, 1, 1), b)
+        mk = lambda w, b: PackedConv(w.reshape(w.shape[0], w.shape[1], 1, 1, 1), b, pad_cout16=True)
         self.l1, self.l2, self.l3 = mk(w1, b1), mk(w2, b2), mk(w3, b3)
         wh = torch.cat([cls_head.weight.detach(), box_head.weight.detach()], 0)
         bh = torch.cat([cls_head.bias.detach(), box_head.bias.detach()], 0)
@@ -773,7 +774,7 @@ class PackedClassifier:
         self.version = tuple(p._version for m in list(fcs) + [cls_head, box_head] for p in (m.weight, m.bias)) + (fcs[0].weight.data_ptr(),)
 
 
-def classifier_forward(x, pk):
+def classifier_forward(x, pk, num=None):
     """x (R, K) fp32 rows on the GPU -> (cls_score (R,NC), cls_pred (R,) int64, cls_prob (R,NC), bbox_pred (R,6NC))"""
     x = _dev(x, "pool5")
     if x.dim() != 2 or x.stride(1) != 1:
@@ -785,12 +786,22 @@ def classifier_forward(x, pk):
     cls_prob = torch.empty(R, nc, device=dev)
     cls_pred = torch.empty(R, dtype=torch.int64, device=dev)
     bbox_pred = torch.empty(R, 6 * nc, device=dev)
+    if all(l.packed_pw16 is not None for l in (pk.l1, pk.l2, pk.l3, pk.head)) and not MLP_LEGACY:
+        nws = lib().sis3d_classifier16_workspace_floats(R, K, pk.l1.cout)
+        ws = torch.empty(max(nws, 1), device=dev)
+        rc = lib().sis3d_classifier16_forward(_ptr(x), R, _ptr(num), K, x.stride(0), _ptr(pk.l1.packed_pw16), _ptr(pk.l1.bias), pk.l1.cout,
+                                              _ptr(pk.l2.packed_pw16), _ptr(pk.l2.bias), pk.l2.cout, _ptr(pk.l3.packed_pw16),
+                                              _ptr(pk.l3.bias), pk.l3.cout, _ptr(pk.head.packed_pw16), _ptr(pk.head.bias), nc,
+                                              _ptr(cls_score), _ptr(cls_prob), _ptr(cls_pred), _ptr(bbox_pred), _ptr(ws), nws, _stream())
+        if rc != -4:
+            check(rc, "sis3d_classifier16_forward")
+            return cls_score, cls_pred, cls_prob, bbox_pred
     nws = lib().sis3d_classifier_workspace_floats(R, K, pk.l1.cout)
     ws = torch.empty(max(nws, 1), device=dev)
-    check(lib().sis3d_classifier_forward(_ptr(x), R, K, x.stride(0), _ptr(pk.l1.packed), _ptr(pk.l1.bias), pk.l1.cout,
+    check(lib().sis3d_classifier_forward_n(_ptr(x), R, _ptr(num), K, x.stride(0), _ptr(pk.l1.packed), _ptr(pk.l1.bias), pk.l1.cout,
                                          _ptr(pk.l2.packed), _ptr(pk.l2.bias), pk.l2.cout, _ptr(pk.l3.packed), _ptr(pk.l3.bias),
                                          pk.l3.cout, _ptr(pk.head.packed), _ptr(pk.head.bias), nc, _ptr(cls_score), _ptr(cls_prob),
-                                         _ptr(cls_pred), _ptr(bbox_pred), _ptr(ws), nws, _stream()), "sis3d_classifier_forward")
+                                           _ptr(cls_pred), _ptr(bbox_pred), _ptr(ws), nws, _stream()), "sis3d_classifier_forward_n")
     return cls_score, cls_pred, cls_prob, bbox_pred
 
 

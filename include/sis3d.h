@@ -190,6 +190,25 @@ int sis3d_classifier_forward(const float *x, int R, int K, int ldx, const float 
                              int64_t *cls_pred, float *bbox_pred, float *workspace, size_t workspace_floats,
                              sis3d_stream_t stream);
 
+/* the same with a DEVICE-side count of live rows (the padded-row detection pass: R = RPN_POST_NMS_TOP_N rows are
+ * allocated, nrows_dev[0] <= R of them are proposals): 32-row tiles entirely past the count are not computed, their
+ * outputs are zero-filled.  nrows_dev may be NULL (= all R rows live). */
+int sis3d_classifier_forward_n(const float *x, int R, const int32_t *nrows_dev, int K, int ldx, const float *w1p, const float *b1,
+                               int C1, const float *w2p, const float *b2, int C2, const float *w3p, const float *b3, int C3,
+                               const float *whp, const float *bh, int NC, float *cls_score, float *cls_prob, int64_t *cls_pred,
+                               float *bbox_pred, float *workspace, size_t workspace_floats, sis3d_stream_t stream);
+
+/* The same classifier in its latency form (csrc/mlp16.hip: 16x16x4 tiles, weights of the first layer held in registers by
+ * (K/256) x (C1/32) workgroups, a 16-row tail workgroup per tile).  Weight packs: sis3d_conv_pw16_pack_weight of the
+ * (Cout, Cin) matrices (heads stacked as for sis3d_classifier_forward; rows beyond 7*NC zero).  K % 256 == 0;
+ * (C1, C2, C3) = (256, 256, 128) (lib/nets/backbones.py:225-231), 7*NC <= 256.  workspace:
+ * sis3d_classifier16_workspace_floats(R, K, C1) floats. */
+size_t sis3d_classifier16_workspace_floats(int R, int K, int C1);
+int sis3d_classifier16_forward(const float *x, int R, const int32_t *nrows_dev, int K, int ldx, const float *w1p, const float *b1,
+                               int C1, const float *w2p, const float *b2, int C2, const float *w3p, const float *b3, int C3,
+                               const float *whp, const float *bh, int NC, float *cls_score, float *cls_prob, int64_t *cls_pred,
+                               float *bbox_pred, float *workspace, size_t workspace_floats, sis3d_stream_t stream);
+
 /* ------------------------------------------------------------ 3D convolution --
  * Replaces the cuDNN calls behind nn.Conv3d / nn.MaxPool3d / nn.ReLU / residual
  * add in lib/nets/backbones.py:17-40,171-287 and lib/nets/network.py:38-47.
