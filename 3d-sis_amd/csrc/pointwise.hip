@@ -250,12 +250,6 @@ __device__ __forceinline__ void rpn_head_body(const HeadLevel &h, int nvox, int 
     constexpr int KGW = C0 / 16 / 4;            // channel groups per wave
     const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mt = blockIdx.x;
-    int v = 16 * mt + li;
-    v = v < nvox ? v : nvox - 1;
-    float4 y[KGW];
-    const float *yp = h.in + (size_t)v * in_stride + 16 * KGW * wave + 4 * q;
-    static_for<0, KGW>([&](auto G) { y[decltype(G)::value] = *reinterpret_cast<const float4 *>(yp + 16 * decltype(G)::value); });
     float4 w[NT][KGW];
     static_for<0, NT>([&](auto N) {
         constexpr int n = decltype(N)::value;
@@ -264,6 +258,13 @@ __device__ __forceinline__ void rpn_head_body(const HeadLevel &h, int nvox, int 
             w[n][g] = reinterpret_cast<const float4 *>(h.wp)[((size_t)n * (C0 / 16) + KGW * wave + g) * 64 + lane];
         });
     });
+    const int nmt = (nvox + 15) / 16;
+    for (int mt = blockIdx.x; mt < nmt; mt += gridDim.x) {
+    int v = 16 * mt + li;
+    v = v < nvox ? v : nvox - 1;
+    float4 y[KGW];
+    const float *yp = h.in + (size_t)v * in_stride + 16 * KGW * wave + 4 * q;
+    static_for<0, KGW>([&](auto G) { y[decltype(G)::value] = *reinterpret_cast<const float4 *>(yp + 16 * decltype(G)::value); });
     f32x4 acc[NT];
     gemm_t<NT, KGW>(w, y, acc);
     // partial tiles -> LDS as [wave][cout][voxel] (cout-major rows of 16 voxels + 1 pad)
@@ -302,6 +303,8 @@ __device__ __forceinline__ void rpn_head_body(const HeadLevel &h, int nvox, int 
         const int vox = 16 * mt + vv;
         if (vox < nvox) h.bbox[(size_t)vox * (6 * A) + j] = fin[(2 * A + j) * 17 + vv];
     }
+    __syncthreads();                             // the LDS tiles are rewritten by the next voxel tile
+    }
 }
 
 template <int NTA, int NTB, int C0>
@@ -332,7 +335,10 @@ int launch_pw(const PwArgs &a, hipStream_t st)
 {
     const int nmt = (a.nvox + 15) / 16;
     if constexpr (TAPS != 1) {
-        hipLaunchKernelGGL((pw16_kernel<C0, C1, C2, WS, TAPS>), dim3(WS == 1 ? (nmt + 3) / 4 : nmt), dim3(256), 0, st, a);
+        // two voxel tiles per workgroup: a wave's 32 KB of weight fragments (the PMC table showed 55 MB of L2 weight re-reads for
+        // 11.6 MB of activations with one tile each) are fetched half as often
+        const int nb = WS == 1 ? (nmt + 3) / 4 : (nmt + 1) / 2;
+        hipLaunchKernelGGL((pw16_kernel<C0, C1, C2, WS, TAPS>), dim3(nb), dim3(256), 0, st, a);
         return sis3d_check_launch();
     }
     // WS == 1: ~2 waves per SIMD, every wave loops over its tiles with the weights in registers; WS == 4: one tile per
@@ -349,7 +355,8 @@ int launch_heads(const HeadArgs &a, hipStream_t st)
 {
     constexpr int NTM = NTA > NTB ? NTA : NTB;
     const size_t lds = (size_t)5 * NTM * 16 * 17 * sizeof(float);
-    hipLaunchKernelGGL((rpn_heads_kernel<NTA, NTB, 256>), dim3((a.nvox + 15) / 16, 2), dim3(256), lds, st, a);
+    const int nmt = (a.nvox + 15) / 16;
+    hipLaunchKernelGGL((rpn_heads_kernel<NTA, NTB, 256>), dim3((nmt + 1) / 2, 2), dim3(256), lds, st, a);   // 2 tiles per workgroup
     return sis3d_check_launch();
 }
 

@@ -21,7 +21,15 @@ __global__ __launch_bounds__(256) void maxpool3_kernel(const float4 *__restrict_
     const int nseg = (Z + ZSEG - 1) / ZSEG;
     const int64_t total = (int64_t)X * Y * nseg * C4;
     const float ninf = -__builtin_huge_valf();
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    // XCD-aware block order (block b runs on XCD b % 8, each with its own L2): every XCD takes one contiguous range of the
+    // x-major work list, i.e. a slab of x-planes, so a voxel's 27 taps hit the L2 that already holds its neighbours
+    // (PMC, round 2: 21-125 MB fetched for 3.5-14 MB maps when consecutive blocks alternate XCDs)
+    int64_t vb;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
+        vb = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    for (int64_t t = vb * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(t % C4);
         int64_t v = t / C4;
         const int sg = (int)(v % nseg);
