@@ -280,28 +280,71 @@ class ScanNet_Backbone(Base_Backbone):
 
 
 class MaskBackbone(nn.Module):
-    """backbones.py:236-287 (geometry-only mask head; MASK_USE_IMAGES variants are not on the benchmark path)."""
+    """backbones.py:236-287.  geometry: 5 x (Conv3d k3 + ReLU) on the 2-channel crop + a 1x1x1 conv; with MASK_USE_IMAGES a
+    second stack `color` of the same shape on the crop of the back-projected image volume and `combine` (k3 128->128, ReLU,
+    1x1x1 -> classes) on their concatenation; MASK_ONLY_IMAGES uses the colour stack alone.  All convs bias-free; sigmoid in
+    eval mode.  Parameter names = the reference's (`geometry.N.weight`, `color.N.weight`, `combine.N.weight`)."""
 
     def __init__(self, cfg=None):
         super().__init__()
         cfg = cfg or _default_cfg
-        if cfg.MASK_USE_IMAGES or cfg.MASK_ONLY_IMAGES:
-            raise NotImplementedError("MASK_USE_IMAGES / MASK_ONLY_IMAGES are outside the ScanNet benchmark path")
+        self.use_images = bool(cfg.MASK_USE_IMAGES)
+        self.only_images = bool(cfg.MASK_ONLY_IMAGES)
+        if self.only_images and not self.use_images:
+            raise ValueError("MASK_ONLY_IMAGES needs MASK_USE_IMAGES (the reference builds `color` only under it, backbones.py:253)")
+        nc = cfg.NUM_CLASSES
         mods = _conv_relu(2, 64, 3, 1, 1)
         for _ in range(4):
             mods += _conv_relu(64, 64, 3, 1, 1)
-        mods.append(HipConv3d(64, cfg.NUM_CLASSES, 1, bias=False))
+        mods.append(HipConv3d(64, 64 if self.use_images else nc, 1, bias=False))
         self.geometry = nn.Sequential(*mods)
+        if self.use_images:
+            cm = _conv_relu(cfg.NUM_IMAGE_CHANNELS, 64, 3, 1, 1)
+            for _ in range(4):
+                cm += _conv_relu(64, 64, 3, 1, 1)
+            cm.append(HipConv3d(64, nc if self.only_images else 64, 1, bias=False))
+            self.color = nn.Sequential(*cm)
+            self.combine = nn.Sequential(*_conv_relu(128, 128, 3, 1, 1), HipConv3d(128, nc, 1, bias=False))
+
+    @staticmethod
+    def _stack(seq, x, first=0, last_out=None, last_coff=0, sigmoid=False):
+        """conv+ReLU pairs seq[first], seq[first+2], ... then the final 1x1x1 conv (optionally into a channel range / sigmoid)"""
+        n = len(seq)
+        for i in range(first, n - 1, 2):
+            x = seq[i](x)
+        last = seq[n - 1]
+        last.fuse_sigmoid = bool(sigmoid)
+        return last(x, out=last_out, out_coff=last_coff)
 
     def forward(self, scene, imageft=None, window=None):
         """scene: (1,2,dx,dy,dz) crop (any view of the planar grid with contiguous z), or the full grid +
-        window=(x0,y0,z0,x1,y1,z1).  Returns logical (1,NUM_CLASSES,dx,dy,dz); sigmoid in eval mode."""
+        window=(x0,y0,z0,x1,y1,z1); imageft: the matching crop of the back-projected volume (1,C,dx,dy,dz) (or the full
+        volume with `window`).  Returns logical (1,NUM_CLASSES,dx,dy,dz); sigmoid in eval mode."""
         g = self.geometry
+        sig = not self.training
+        if self.use_images:
+            if imageft is None:
+                raise ops._lib.Sis3dError("MASK_USE_IMAGES: the mask head needs the image volume crop")
+            if isinstance(imageft, ops.ProjectedVolume):
+                imageft = imageft.dense()
+            if window is not None:
+                x0, y0, z0, x1, y1, z1 = window
+                imageft = imageft[:, :, x0:x1, y0:y1, z0:z1]
+            # a crop of the channels-last volume is a strided view: one copy into a dense channels-last tile
+            col_in = ops.to_cl(imageft.contiguous(memory_format=torch.channels_last_3d) if not ops.is_cl(imageft) else imageft)
+            if self.only_images:
+                return self._stack(self.color, col_in, sigmoid=sig)
+            od = tuple(col_in.shape[2:])
+            both = ops.new_act(128, od, col_in.device)       # torch.cat([geometry, color], 1) written in place (backbones.py:282)
+            x = ops.conv3d_planar2(scene, g[0].weight, 3, relu=True, window=window)
+            self._stack(g, x, first=2, last_out=both, last_coff=0)
+            self._stack(self.color, col_in, last_out=both, last_coff=64)
+            return self._stack(self.combine, both, sigmoid=sig)
         x = ops.conv3d_planar2(scene, g[0].weight, 3, relu=True, window=window)
         for i in (2, 4, 6, 8):
             x = g[i](x)
         last = g[10]
-        last.fuse_sigmoid = not self.training
+        last.fuse_sigmoid = sig
         return last(x)
 
 

@@ -120,6 +120,10 @@ class Network(nn.Module):
         _, _, pred_box, keep = final_detections(self._predictions, self._scene_info, self.cfg)
         self.mask_backbone.eval()
         windows = mask_windows(pred_box, keep)
+        if getattr(self.mask_backbone, "use_images", False):
+            # network.py:307-316 with USE_IMAGES: every box's crop of the scene AND of the back-projected volume
+            vol = self._imageft
+            return [[self.mask_backbone(self._scene, vol, window=w) for w in windows]]
         if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
             return [self.mask_backbone.forward_batched(self._scene, windows)]   # one launch per layer for ALL boxes
         return [[self.mask_backbone(self._scene, None, window=w) for w in windows]]

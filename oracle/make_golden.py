@@ -136,9 +136,13 @@ def enet_case(ns):
           "%.1f KB" % (os.path.getsize(os.path.join(OUT, "enet_cases.npz")) / 1024))
 
 
-def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3, only_images=False, rgb=False):
-    """rgb: the views are RGB images and the reference runs its own ENet on them (USE_IMAGES_GT=False, network.py:203-205)"""
+def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3, only_images=False, rgb=False, mask_images=None):
+    """rgb: the views are RGB images and the reference runs its own ENet on them (USE_IMAGES_GT=False, network.py:203-205);
+    mask_images: 'use' / 'only' = MASK_USE_IMAGES / + MASK_ONLY_IMAGES (backbones.py:253-284); only the mask-related arrays
+    are stored for those"""
     ns.cfg.ONLY_IMAGES = bool(only_images)
+    ns.cfg.MASK_USE_IMAGES = mask_images in ("use", "only")
+    ns.cfg.MASK_ONLY_IMAGES = mask_images == "only"
     ckpt = None
     if rgb:
         from lib.nets import enet as renet
@@ -192,6 +196,11 @@ def e2e(ns, name, use_images, dims, chunk_id, n_views=5, n_per_view=3000, sub=3,
         out["imageft_stride"] = np.array(ift.stride())
     ns.cfg.ONLY_IMAGES = False
     ns.cfg.USE_IMAGES_GT = True
+    ns.cfg.MASK_USE_IMAGES = ns.cfg.MASK_ONLY_IMAGES = False
+    if mask_images:
+        keep = ("num_classes", "dims", "chunk_id", "n_views", "n_per_view", "sub", "shapes_keys", "rois", "cls_pred", "cls_prob", "bbox_pred",
+                "n_masks", "mask_shapes", "mask_0", "mask_1", "mask_2", "mask_3")
+        out = {k: v for k, v in out.items() if k in keep}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "R=%d" % out["rois"].shape[0], "masks=%d" % len(masks),
           "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
@@ -334,6 +343,10 @@ def suncg_case():
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
+    if "--mask-images" in sys.argv:              # round 2: the mask head's colour variants
+        e2e(ns, "e2e_mask_use_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="use")
+        e2e(ns, "e2e_mask_only_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="only")
+        return
     if "--enet" in sys.argv:                     # only the round-2 additions (2D encoder + RGB end-to-end)
         enet_case(ns)
         e2e(ns, "e2e_rgb_small", True, (64, 32, 48), 6, n_views=3, n_per_view=400, sub=2, rgb=True)
