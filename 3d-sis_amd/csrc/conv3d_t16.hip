@@ -26,6 +26,7 @@
 // Epilogue: + bias, ReLU, 16 B stores.  FMA contraction is irrelevant here (the MFMA is an fmaf chain; tolerance 1e-4).
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -274,6 +275,8 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st)
     return sis3d_check_launch();
 }
 
+std::atomic<int> g_brick_cap{0};          // sis3d_conv3d_k3t16_set_brick_cap
+
 struct Brick { int bx, by, bz; };
 constexpr Brick BRICKS[] = {{6, 6, 12}, {6, 6, 6}, {3, 6, 6}, {3, 3, 6}, {4, 4, 4}, {4, 4, 8}, {4, 8, 8}};
 constexpr int NBRICKS = sizeof(BRICKS) / sizeof(BRICKS[0]);
@@ -309,12 +312,20 @@ extern "C" int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, f
     return sis3d_check_launch();
 }
 
+extern "C" int sis3d_conv3d_k3t16_set_brick_cap(int max_voxels)
+{
+    if (max_voxels < 0) return SIS3D_EINVAL;
+    g_brick_cap.store(max_voxels, std::memory_order_relaxed);
+    return SIS3D_OK;
+}
+
 extern "C" int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob)
 {
     if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nprob < 1) return SIS3D_EINVAL;
     // tuning hook: SIS3D_K3_MAXVOX caps the brick volume (smaller bricks = less LDS / fewer registers per workgroup, so
     // workgroups of other streams' kernels can share the CU)
-    static const int maxvox = [] { const char *e = getenv("SIS3D_K3_MAXVOX"); return e ? atoi(e) : 0; }();
+    static const int env_maxvox = [] { const char *e = getenv("SIS3D_K3_MAXVOX"); return e ? atoi(e) : -1; }();
+    const int maxvox = env_maxvox >= 0 ? env_maxvox : g_brick_cap.load(std::memory_order_relaxed);
     int best = -1;
     int64_t bc = -1;
     for (int i = 0; i < NBRICKS; ++i) {

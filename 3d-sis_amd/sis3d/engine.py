@@ -41,6 +41,7 @@ class ChunkEngine:
         self.scenes = [torch.zeros((1, 2) + self.dims, device=self.device) for _ in range(G)]
         self.use_images = bool(cfg.USE_IMAGES)
         self.from_depth = False
+        self.rgb = False
         if self.use_images:
             nvox = self.dims[0] * self.dims[1] * self.dims[2]
             h, w = cfg.DEPTH_SHAPE[1], cfg.DEPTH_SHAPE[0]
@@ -48,6 +49,13 @@ class ChunkEngine:
             self.feats_ = [torch.zeros(self.n_views, cfg.NUM_IMAGE_CHANNELS, h, w, device=self.device) for _ in range(G)]
             self.i3d_ = [torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device) for _ in range(G)]
             self.i2d_ = [torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device) for _ in range(G)]
+            # RGB input (USE_IMAGES_GT=False): the 2D encoder (PyTorch-ROCm operators) runs inside the step, in its own captured
+            # graph in front of the 3D graph (falls back to eager launches if the capture of those library calls is refused)
+            self.rgb = bool(cfg.USE_IMAGES and not cfg.USE_IMAGES_GT)
+            if self.rgb:
+                iw, ih = cfg.IMAGE_SHAPE
+                self.images_ = [torch.zeros(self.n_views, 3, ih, iw, device=self.device) for _ in range(G)]
+                self.enet_graph = None
             self.from_depth = bool(from_depth)
             if self.from_depth:
                 from .layer_utils.projection import ProjectionHelper
@@ -85,6 +93,8 @@ class ChunkEngine:
 
     def _step(self):
         net = self.net
+        if self.rgb and (self.graph is None and not torch.cuda.is_current_stream_capturing()):
+            self._encode_views()
         if self.group == 1:
             imageft = self._imageft(0)
             if self.stage == "backbone":
@@ -111,6 +121,21 @@ class ChunkEngine:
             for _ in range(max(1, warmup)):
                 self.out = self._step()
             torch.cuda.synchronize()
+            if self.rgb and self.use_graph:
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._encode_views()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._encode_views()
+                    self.enet_graph = g
+                except Exception:                                   # library calls that cannot be captured: keep them eager
+                    self.enet_graph = None
+                torch.cuda.synchronize()
             if self.mask_boxes > 0 and self.stage == "detect" and self.group == 1:
                 self.mask_plan = self._plan_masks()
                 self.out = self._step()
@@ -127,6 +152,18 @@ class ChunkEngine:
                     self.out = self._step()
                 torch.cuda.synchronize()
         return self
+
+    def _encode_views(self):
+        """RGB views -> ENet feature maps, written into the static feature buffers the 3D graph reads"""
+        for g in range(self.group):
+            self.feats_[g].copy_(self.net.image_features(self.images_[g]))
+
+    def load_rgb(self, data, images, i3d, i2d, slot=0):
+        """rgb engines: grid, RGB views (V,3,H,W), packed index lists"""
+        self._copy(self.scenes[slot], data)
+        self._copy(self.images_[slot], images)
+        self._copy(self.i3d_[slot], i3d)
+        self._copy(self.i2d_[slot], i2d)
 
     def _plan_masks(self):
         """crop windows of the stand-in detections of the chunk currently loaded (one D2H read, before the capture)"""
@@ -183,6 +220,11 @@ class ChunkEngine:
         """one pass over the chunk(s) currently in the static buffers; returns the (static) output dict (list of dicts
         for group > 1)"""
         with torch.no_grad():
+            if self.rgb and self.graph is not None:
+                if self.enet_graph is not None:
+                    self.enet_graph.replay()
+                else:
+                    self._encode_views()
             if self.graph is not None:
                 self.graph.replay()
             else:
@@ -199,7 +241,11 @@ class PipelinedEngines:
     alone, 0.466 with two, 0.449 with three in flight; the detect pass (long single-workgroup tail kernels) gains
     11 % from the third stream; a fourth loses again."""
 
-    def __init__(self, net, n=2, **kw):
+    def __init__(self, net, n=2, brick_cap=None, **kw):
+        """brick_cap: cap (voxels) on the k3 kernel's brick for the graphs captured here; default 108 when n >= 2 (small
+        bricks = several workgroups per CU, so the pipelines' kernels interleave), none for a single pipeline"""
+        cap = (108 if n >= 2 else 0) if brick_cap is None else int(brick_cap)
+        self._brick_cap = cap
         self.streams = [torch.cuda.Stream() for _ in range(n)]
         self.engines = []
         for s in self.streams:
@@ -208,10 +254,15 @@ class PipelinedEngines:
                 self.engines.append(ChunkEngine(net, **kw))
 
     def prepare(self, warmup=2):
-        for e, s in zip(self.engines, self.streams):
-            with torch.cuda.stream(s):
-                e.prepare(warmup)
-        torch.cuda.synchronize()
+        # the brick choice is made at launch (= capture) time: set the cap for the captures, restore afterwards
+        ops.lib().sis3d_conv3d_k3t16_set_brick_cap(self._brick_cap)
+        try:
+            for e, s in zip(self.engines, self.streams):
+                with torch.cuda.stream(s):
+                    e.prepare(warmup)
+            torch.cuda.synchronize()
+        finally:
+            ops.lib().sis3d_conv3d_k3t16_set_brick_cap(0)
         return self
 
     def load(self, i, *a, **kw):

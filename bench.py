@@ -80,6 +80,8 @@ def parse(argv=None):
     ap.add_argument("--group", type=int, default=1, help="chunks per captured graph (2: the pair's four RPN convs in one launch)")
     ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
                     "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
+    ap.add_argument("--rgb", action="store_true", help="images workload: the views are RGB images and the ENet 2D encoder "
+                    "(PyTorch-ROCm operators, own captured graph) runs inside the timed step (BASELINE config[3] from pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -160,16 +162,17 @@ def selftest_cpu(args, rank, world):
 
 
 # ---------------------------------------------------------------------------------------------------- GPU workloads --
-def build_net(workload, masks=False):
+def build_net(workload, masks=False, rgb=False):
     from sis3d import config, synthetic
     from sis3d.nets import backbones
     cfg = config.scannet_benchmark_cfg()
     cfg.USE_IMAGES = workload == "images"
+    cfg.USE_IMAGES_GT = not (rgb and workload == "images")
     cfg.USE_MASK = bool(masks)
     net = backbones.ScanNet_Backbone(cfg=cfg)
     net.init_modules()
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
+    sd = synthetic.synth_checkpoint(shapes, seed=0)
     net.load_state_dict(sd)
     return net.cuda().eval(), cfg, sd
 
@@ -268,10 +271,12 @@ def cpu_baseline(workload, sd, cfg, seconds):
     feats = i3d = i2d = None
     if workload == "images":
         feats, i3d, i2d = synthetic.synth_views(0)
+        if not cfg["USE_IMAGES_GT"]:
+            feats = synthetic.synth_images(0, cfg["NUM_IMAGES"])
 
     def one():
         with torch.no_grad():
-            if workload in ("detect", "scene"):
+            if workload in ("detect", "scene") or not cfg["USE_IMAGES_GT"]:
                 net.forward(data, feats, i3d, i2d)
             else:
                 imageft = orc.project_views_max(feats, i3d, i2d, data.shape[2:]) if workload == "images" else None
@@ -366,6 +371,10 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
                 depth, c2w, w2g = synthetic.synth_cameras(cid, feats.shape[0], voxel_size=cfg.VOXEL_SIZE)
                 with torch.cuda.stream(eng.streams[i]):
                     eng.engines[i].load_views(data, feats, depth, c2w, w2g, slot=g)
+            elif workload == "images" and args.rgb:
+                _, i3d, i2d = synthetic.synth_views(cid)
+                with torch.cuda.stream(eng.streams[i]):
+                    eng.engines[i].load_rgb(data, synthetic.synth_images(cid, cfg.NUM_IMAGES), i3d, i2d, slot=g)
             elif workload == "images":
                 feats, i3d, i2d = synthetic.synth_views(cid)
                 eng.load(i, data, feats, i3d, i2d, slot=g)
@@ -381,6 +390,9 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
     barrier()
     dt = time.perf_counter() - t0
     extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl}
+    if workload == "images" and args.rgb:
+        extra["views_from"] = "RGB images (5 x 3 x 256 x 328) through the ENet encoder inside the step (5.2 GFLOP, PyTorch-ROCm operators)"
+        extra["enet_graph_captured"] = eng.engines[0].enet_graph is not None
     if from_depth:
         torch.cuda.synchronize()
         extra.update({"views_from": "depth maps + poses (lists computed on device inside the step)",
@@ -475,7 +487,7 @@ def main(argv=None):
 
     from sis3d import ops
     ops.lib()
-    net, cfg, sd = build_net(workload, masks=args.masks)
+    net, cfg, sd = build_net(workload, masks=args.masks, rgb=args.rgb)
     kt = time_dominant_kernel(net) if rank == 0 else 0.0
 
     def barrier():

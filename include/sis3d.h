@@ -317,6 +317,10 @@ int sis3d_rpn_heads(const float *in1, const float *packed_w1, const float *bias1
  * brick: index of the voxel brick (0: 6x6x12, 1: 6x6x6, 2: 3x6x6, 3: 3x3x6, 4: 4x4x4, 5: 4x4x8, 6: 4x8x8) or -1 =
  * sis3d_conv3d_k3t16_brick's choice (fewest SIMD-cycles on the busiest CU for this grid).  Any grid size; partial
  * bricks are masked. */
+/* process-wide cap on the brick volume sis3d_conv3d_k3t16_brick may choose (0 = none).  One chunk alone is fastest on the
+ * largest brick (one workgroup per CU); with several chunks in flight on separate streams bricks of <= 108 voxels (46 KB of
+ * LDS, 3 workgroups per CU) let the streams' kernels share the CUs (+3-4 % throughput, profiles/README.md). */
+int sis3d_conv3d_k3t16_set_brick_cap(int max_voxels);
 size_t sis3d_conv_k3t16_packed_floats(int cout, int cin);
 int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
 int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob);
