@@ -50,6 +50,14 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+struct T16Ragged {
+    int X, Y, Z;          // grid of this problem
+    int nbx, nby, nbz;    // bricks per axis for the launched brick
+    int block0;           // first workgroup of this problem in the launch
+    int pad;
+    int64_t in_off, out_off;   // element offsets of this problem's activations inside the packed in / out buffers
+};
+
 struct T16Args {
     const float *in[T16_MAXP];
     const float *wp[T16_MAXP];
@@ -62,6 +70,10 @@ struct T16Args {
     int flags;
     int out_stride, out_coff;
     int nbx, nby, nbz;
+    // ragged batch (the mask head: one launch for all detected boxes' crops): problems of different grid sizes packed back
+    // to back; descriptor layout shared with conv3d.hip's ragged launch
+    const T16Ragged *rag;
+    int nrag;
 };
 
 template <int BX, int BY, int BZ, int G, int RB>
@@ -88,11 +100,25 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     const int prob = blockIdx.y;
     const float *__restrict__ p_in = a.in[prob];
     const float *__restrict__ p_wp = a.wp[prob];
+    int gX = a.X, gY = a.Y, gZ = a.Z, nby = a.nby, nbz = a.nbz;
+    int64_t out_off = 0;
+    if (a.nrag > 0) {
+        // find this workgroup's problem (block0 ascending): uniform -> scalar loads
+        int lo = 0, hi = a.nrag - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.rag[mid].block0 <= wid) lo = mid; else hi = mid - 1;
+        }
+        const T16Ragged d = a.rag[lo];
+        wid -= d.block0;
+        gX = d.X; gY = d.Y; gZ = d.Z; nby = d.nby; nbz = d.nbz;
+        p_in += d.in_off;
+        out_off = d.out_off;
+    }
     const int nt = wid % a.ntiles;
     int brick = wid / a.ntiles;
-    const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
+    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
     const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
-    const int gX = a.X, gY = a.Y, gZ = a.Z;
 
     // halo staging: item = (row, 16 B piece); global element offset (-1: outside the grid -> zero).  Rows advance by 32 per
     // item: (hx, hy, hz) is carried incrementally instead of re-dividing (this address math sits in front of the very first
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     const int co = 16 * nt + 4 * c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias[prob] && co < a.cout) bv = *reinterpret_cast<const float4 *>(a.bias[prob] + co);
-    float *__restrict__ p_out = a.out[prob];
+    float *__restrict__ p_out = a.out[prob] + out_off;
     for (int t = wave; t < MT; t += 4) {
         const float4 *src = reinterpret_cast<const float4 *>(lds + t * 256 + row * 16 + c4 * 4);
         const float4 s0 = src[0], s1 = src[MT * 64], s2 = src[2 * MT * 64], s3 = src[3 * MT * 64];
@@ -257,7 +283,7 @@ __global__ __launch_bounds__(256) void pack_weight_t16_kernel(const float *__res
 }
 
 template <int BX, int BY, int BZ>
-int launch_t16(T16Args &a, int nprob, hipStream_t st)
+int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
     constexpr int G = (MT % 3 == 0) ? 3 : (MT >= 4 ? 4 : MT);
@@ -269,7 +295,7 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st)
     a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
     auto kern = conv3d_k3t16_kernel<BX, BY, BZ, G, RB>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * a.ntiles;
+    const int64_t nwg = ragged_blocks > 0 ? ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * a.ntiles;
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(256), lds, st, a);
     return sis3d_check_launch();
@@ -353,6 +379,7 @@ extern "C" int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int
     }
     a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
+    a.rag = nullptr; a.nrag = 0;
     if (brick < 0) brick = sis3d_conv3d_k3t16_brick(X, Y, Z, cin, cout, nprob);
     hipStream_t st = as_stream(stream);
     switch (brick) {
@@ -364,5 +391,41 @@ extern "C" int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int
     case 5: return launch_t16<4, 4, 8>(a, nprob, st);
     case 6: return launch_t16<4, 8, 8>(a, nprob, st);
     default: return SIS3D_EINVAL;
+    }
+}
+
+// ---- ragged batch: every detected box's mask-head crop (lib/nets/network.py:303-317) through ONE launch per k3 layer.
+// The caller picks the brick (3x6x6, 3x3x6, 4x4x4 or 4x4x8) that wastes the fewest tile slots on its crops: detections are
+// 10-40 voxels across, so the padding of partial bricks decides the efficiency (3x6x6 is best on a 30x30x36 crop -- 65 us
+// vs 89 us for conv3d.hip's 32x32 tiles -- but covers a 14^3 crop with 56 % fill).
+extern "C" int sis3d_ragged_tiling_k3t16(int cin, int cout, int brick, int *bx, int *by, int *bz, int *ngroups, int *tiles_per_wave)
+{
+    if (!bx || !by || !bz || !ngroups) return SIS3D_EINVAL;
+    if ((cin % CK) || (cout % 4) || brick < 0 || brick >= NBRICKS) return SIS3D_EUNSUPPORTED;
+    *bx = BRICKS[brick].bx; *by = BRICKS[brick].by; *bz = BRICKS[brick].bz;
+    *ngroups = (cout + 15) / 16;
+    if (tiles_per_wave) *tiles_per_wave = (BRICKS[brick].bx * BRICKS[brick].by * BRICKS[brick].bz + 15) / 16;
+    return SIS3D_OK;
+}
+
+extern "C" int sis3d_conv3d_k3t16_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                                         int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks,
+                                         int brick, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || !desc_dev || ndesc <= 0 || total_blocks <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
+    if ((cin % CK) || (cout % 4) || (cin_stride % 4) || cin_stride < cin || (out_stride % 4) || out_stride < cout) return SIS3D_EUNSUPPORTED;
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    T16Args a;
+    for (int p = 0; p < T16_MAXP; ++p) { a.in[p] = in; a.wp[p] = packed_w; a.bias[p] = bias; a.out[p] = out; }
+    a.X = a.Y = a.Z = 1; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = 0;
+    a.rag = (const T16Ragged *)desc_dev; a.nrag = ndesc;
+    hipStream_t st = as_stream(stream);
+    switch (brick) {
+    case 2: return launch_t16<3, 6, 6>(a, 1, st, total_blocks);
+    case 3: return launch_t16<3, 3, 6>(a, 1, st, total_blocks);
+    case 4: return launch_t16<4, 4, 4>(a, 1, st, total_blocks);
+    case 5: return launch_t16<4, 4, 8>(a, 1, st, total_blocks);
+    default: return SIS3D_EUNSUPPORTED;
     }
 }

@@ -847,6 +847,32 @@ class MaskPlan:
             d["block0"] = blks[:-1]
             d["in_off"] = voffs[:-1] * C
             d["out_off"] = voffs[:-1] * ostr
+        # the k3 layers on the balanced kernel (csrc/conv3d_t16.hip): its own brick / workgroup numbering
+        self.t16, self.brick_t16, self.blocks_t16 = False, -1, 0
+        d3t = np.zeros(0, dtype=rdt)
+        if not K3_LEGACY:
+            best = None
+            forced = int(_os.environ.get("SIS3D_MASK_BRICK", "-1"))        # tuning hook
+            for brick in ((forced,) if forced >= 0 else (2, 4, 5, 3)):   # 3x6x6, 4x4x4, 4x4x8, 3x3x6: least estimated SIMD time wins
+                tb = [ctypes.c_int() for _ in range(5)]
+                if lib().sis3d_ragged_tiling_k3t16(C, C, brick, *[ctypes.byref(v) for v in tb]) != 0:
+                    continue
+                tbx, tby, tbz, tng, tmt = (v.value for v in tb)
+                nbt = -(-ext // np.array([tbx, tby, tbz]))
+                # per workgroup: MFMA issue of its tile slots (padded or not) + a fixed prologue / epilogue share
+                slots = int(nbt.prod(1).sum()) * (tmt * 27 * (C // 16) * 32 + 3000)
+                if best is None or slots < best[0]:
+                    best = (slots, brick, nbt, tng)
+            if best is not None:
+                _, brick, nbt, tng = best
+                blt = np.concatenate([[0], np.cumsum(nbt.prod(1) * tng)])
+                d3t = np.zeros(n, dtype=rdt)
+                d3t["X"], d3t["Y"], d3t["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
+                d3t["nbx"], d3t["nby"], d3t["nbz"] = nbt[:, 0], nbt[:, 1], nbt[:, 2]
+                d3t["block0"] = blt[:-1]
+                d3t["in_off"] = voffs[:-1] * C
+                d3t["out_off"] = voffs[:-1] * C
+                self.t16, self.brick_t16, self.blocks_t16 = True, brick, int(blt[-1])
         dp["x0"], dp["y0"], dp["z0"] = w[:, 0], w[:, 1], w[:, 2]
         dp["dx"], dp["dy"], dp["dz"] = ext[:, 0], ext[:, 1], ext[:, 2]
         dp["t0"] = voffs[:-1] * (C // 4)
@@ -854,13 +880,15 @@ class MaskPlan:
         self.voxels, self.blocks, self.items = int(voffs[-1]), int(blks[-1]), int(voffs[-1]) * (C // 4)
         self.dims = [tuple(int(v) for v in e) for e in ext]
         # ONE upload for the three descriptor tables (each is a blocking pageable copy)
-        parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1)]
+        parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1),
+                 d3t.view(np.uint8).reshape(-1)]
         pad = [(-p.size) % 16 for p in parts]
         host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
         self.devbuf = torch.from_numpy(host).to(device)
         o1 = parts[0].size + pad[0]
         o2 = o1 + parts[1].size + pad[1]
-        self.g3, self.g1, self.gp = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:]
+        o3 = o2 + parts[2].size + pad[2]
+        self.g3, self.g1, self.gp, self.g3t = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:o3], self.devbuf[o3:]
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
         self.out = torch.empty(self.voxels, NC, device=device)
@@ -888,8 +916,12 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
           "sis3d_conv3d_planar2_ragged")
     src, dst = plan.a, plan.b
     for pc in pcs:
-        check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(plan.g3), n,
-                                        plan.blocks, _stream()), "sis3d_conv3d_ragged")
+        if plan.t16 and pc.packed_t16 is not None:
+            check(lib().sis3d_conv3d_k3t16_ragged(_ptr(src), C, C, _ptr(pc.packed_t16), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
+                                                  _ptr(plan.g3t), n, plan.blocks_t16, plan.brick_t16, _stream()), "sis3d_conv3d_k3t16_ragged")
+        else:
+            check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(plan.g3), n,
+                                            plan.blocks, _stream()), "sis3d_conv3d_ragged")
         src, dst = dst, src
     check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
                                     _ptr(plan.out), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")

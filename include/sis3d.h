@@ -360,6 +360,14 @@ int sis3d_conv3d_planar2_ragged(const float *in, int64_t is_c, int64_t is_x, int
                                 int64_t total_items, const float *w, int cout, int flags, float *out, int out_stride,
                                 sis3d_stream_t stream);
 
+/* the k3 layers of the ragged mask-head batch on the balanced kernel (csrc/conv3d_t16.hip); same descriptor struct as
+ * sis3d_conv3d_ragged, bricks / groups from sis3d_ragged_tiling_k3t16(brick in {2,3,4,5} of the sis3d_conv3d_k3t16 list; the
+ * caller picks the one with the fewest padded tile slots over its crops); packed_w from sis3d_conv_k3t16_pack_weight */
+int sis3d_ragged_tiling_k3t16(int cin, int cout, int brick, int *bx, int *by, int *bz, int *ngroups, int *tiles_per_wave);
+int sis3d_conv3d_k3t16_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout, int flags,
+                              float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks, int brick,
+                              sis3d_stream_t stream);
+
 /* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding.  The C output channels land at
  * [out_coff, out_coff + C) of rows of out_stride floats (out_stride = C, out_coff = 0: a plain tensor; otherwise a channel
  * range of a wider tensor = the torch.cat of backbones.py:109 done in place). */
