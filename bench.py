@@ -109,6 +109,8 @@ def self_launch(args, argv):
     if not args.selftest_cpu:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if os.environ.get("SIS3D_BENCH_SHARE_GPU") and have >= 1:
+            have = args.gpus        # functional test hook: every rank on GPU 0, gloo instead of RCCL (see main())
         if have < args.gpus:
             sys.stderr.write("bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to run a smaller world\n"
                              % (args.gpus, have))
@@ -464,6 +466,11 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
+    # functional test hook (one-GPU boxes): SIS3D_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and swaps RCCL for gloo (RCCL refuses
+    # two ranks on one device); everything else -- sharding, gather, merge, timing, the JSON line -- is the N-rank code path
+    share = bool(os.environ.get("SIS3D_BENCH_SHARE_GPU"))
+    if share:
+        local = 0
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
         sys.stderr.write("bench.py: rank %d needs GPU %d, this box exposes %d\n" % (rank, local, torch.cuda.device_count()
                                                                                        if torch.cuda.is_available() else 0))
@@ -478,7 +485,10 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     workload = args.workload
     if workload == "auto":
         workload = "backbone_rpn" if world == 1 else "scene"
@@ -546,6 +556,7 @@ def main(argv=None):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[workload] + (" + mask head" if args.masks else ""),
                        "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world,
+                       **({"TEST_HOOK": "all ranks share GPU 0, gloo instead of RCCL: functional run, not a measurement"} if share else {}),
                        "chunks_per_step_per_gpu": nchunk_step, "single_chunk_latency_ms": res["single_ms"], **res["extra"]},
             "roofline": {"bound": "mfma", "kernel": "rpn_net k3 128->256 conv (exact fp32 MFMA)",
                          "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
