@@ -214,3 +214,61 @@ extern "C" int sis3d_project_views_prepare(const float *feats, int V, int C, int
                        feat_rows);
     return sis3d_check_launch();
 }
+
+// ---- backward of Projection (training only; lib/layer_utils/projection.py:139-153).  The reference clones grad_output, resizes
+// the clone to (C, h, w) -- so pixels no voxel maps to keep the clone's LEADING elements, a quirk kept here -- and index_copy_()s
+// grad_output[:, i3d[1:1+n]] into columns i2d[1:1+n]; when several voxels share a pixel the last list entry wins (the sequential
+// CPU index_copy_).  Three small launches: init, winner = max list position per pixel, copy by the winners.
+namespace {
+
+__global__ __launch_bounds__(256) void projb_init_kernel(const float *__restrict__ gout, int64_t gout_elems, int64_t n_out, float *__restrict__ gl,
+                                                         int32_t *__restrict__ winner, int64_t npix)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_out) gl[i] = i < gout_elems ? gout[i] : 0.0f;
+    if (i < npix) winner[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void projb_winner_kernel(const int64_t *__restrict__ i3d, const int64_t *__restrict__ i2d, int64_t nvox,
+                                                           int64_t npix, int32_t *__restrict__ winner)
+{
+    const int64_t n = min(max(i3d[0], (int64_t)0), nvox);
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t p = i2d[1 + k];
+    if (p >= 0 && p < npix) atomicMax(winner + p, (int32_t)k);
+}
+
+__global__ __launch_bounds__(256) void projb_copy_kernel(const float *__restrict__ gout, const int64_t *__restrict__ i3d,
+                                                         const int64_t *__restrict__ i2d, int64_t nvox, int64_t npix, int C,
+                                                         const int32_t *__restrict__ winner, float *__restrict__ gl)
+{
+    const int64_t n = min(max(i3d[0], (int64_t)0), nvox);
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t k = t / C;
+    const int c = (int)(t % C);
+    if (k >= n) return;
+    const int64_t p = i2d[1 + k], v = i3d[1 + k];
+    if (p < 0 || p >= npix || v < 0 || v >= nvox || winner[p] != (int32_t)k) return;
+    gl[(int64_t)c * npix + p] = gout[(int64_t)c * nvox + v];
+}
+
+} // namespace
+
+extern "C" size_t sis3d_projection_backward_workspace_bytes(int64_t npix) { return npix > 0 ? (size_t)npix * 4 : 0; }
+
+extern "C" int sis3d_projection_backward(const float *grad_out, int C, int64_t nvox, const int64_t *lin3d, const int64_t *lin2d,
+                                         int64_t npix, float *grad_label, void *workspace, size_t workspace_bytes, sis3d_stream_t stream)
+{
+    if (!grad_out || !lin3d || !lin2d || !grad_label || C <= 0 || nvox <= 0 || npix <= 0) return SIS3D_EINVAL;
+    if (!workspace || workspace_bytes < (size_t)npix * 4) return SIS3D_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int64_t n_out = (int64_t)C * npix;
+    int32_t *winner = (int32_t *)workspace;
+    hipLaunchKernelGGL(projb_init_kernel, dim3((unsigned)((max(n_out, npix) + 255) / 256)), dim3(256), 0, st, grad_out, (int64_t)C * nvox, n_out,
+                       grad_label, winner, npix);
+    hipLaunchKernelGGL(projb_winner_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, lin3d, lin2d, nvox, npix, winner);
+    hipLaunchKernelGGL(projb_copy_kernel, dim3((unsigned)((nvox * C + 255) / 256)), dim3(256), 0, st, grad_out, lin3d, lin2d, nvox, npix, C,
+                       winner, grad_label);
+    return sis3d_check_launch();
+}

@@ -188,7 +188,43 @@ __global__ __launch_bounds__(256) void roi_pool_slab_kernel(const float *__restr
     }
 }
 
+// ---- backward (training only).  Replaces ROIPoolBackward (roi_pooling_kernel.cu:137-248): the reference
+// visits EVERY input element and scans all RoIs x bins for argmax == index (O(voxels * R * bins)); the same sum is an atomic
+// scatter of grad_output through the saved argmax.  Sum order differs from the reference's (RoI-major) only in fp32 rounding.
+__global__ __launch_bounds__(256) void roi_pool_backward_kernel(const float *__restrict__ gout, const int32_t *__restrict__ argmax,
+                                                                int64_t total, int C, int nb, int64_t os_n, int64_t os_c, int64_t os_bin,
+                                                                int W, int H, int L, float *__restrict__ gin, int64_t gs_c, int64_t gs_w,
+                                                                int64_t gs_h, int64_t gs_l)
+{
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int64_t r = t / C;
+        const int b = (int)(r % nb);
+        const int64_t n = r / nb;
+        const int64_t o = n * os_n + (int64_t)c * os_c + (int64_t)b * os_bin;
+        const int idx = argmax[o];
+        if (idx < 0) continue;                              // empty bin
+        const int l = idx % L, h = (idx / L) % H, w = (idx / (L * H)) % W, cc = idx / (L * H * W);
+        atomicAdd(gin + (int64_t)cc * gs_c + (int64_t)w * gs_w + (int64_t)h * gs_h + (int64_t)l * gs_l, gout[o]);
+    }
+}
+
 } // namespace
+
+extern "C" int sis3d_roi_pool_backward(const float *grad_out, const int32_t *argmax, int R, int C, int pw, int ph, int pl, int64_t os_n,
+                                       int64_t os_c, int64_t os_bin, int W, int H, int L, float *grad_in, int64_t gs_c, int64_t gs_w,
+                                       int64_t gs_h, int64_t gs_l, sis3d_stream_t stream)
+{
+    if (R < 0 || C <= 0 || pw <= 0 || ph <= 0 || pl <= 0 || W <= 0 || H <= 0 || L <= 0) return SIS3D_EINVAL;
+    if (R == 0) return SIS3D_OK;
+    if (!grad_out || !argmax || !grad_in) return SIS3D_EINVAL;
+    const int nb = pw * ph * pl;
+    const int64_t total = (int64_t)R * nb * C;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(roi_pool_backward_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream), grad_out,
+                       argmax, total, C, nb, os_n, os_c, os_bin, W, H, L, grad_in, gs_c, gs_w, gs_h, gs_l);
+    return sis3d_check_launch();
+}
 
 extern "C" int sis3d_roi_pool_forward(const float *features, int C, int W, int H, int L, int64_t fs_c, int64_t fs_w,
                                       int64_t fs_h, int64_t fs_l, const float *rois, int R, int pw, int ph, int pl,

@@ -20,6 +20,10 @@ SIGNATURES = {
                                        c_int, c_f32, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "sis3d_roi_pool_levels": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_int,
                                       c_int, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "sis3d_roi_pool_backward": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64,
+                                        c_i64, c_i64, c_i64, c_vp]),
+    "sis3d_projection_backward_workspace_bytes": (c_sz, [c_i64]),
+    "sis3d_projection_backward": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_projection_forward": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "sis3d_project_views_workspace_bytes": (c_sz, [c_int, c_int, c_i64, c_i64]),
     "sis3d_project_views_max": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64,

@@ -54,15 +54,24 @@ def roi_pooling_forward_cuda(pooled_width, pooled_height, pooled_length, spatial
     return 1
 
 
+def roi_pooling_backward_cuda(pooled_width, pooled_height, pooled_length, spatial_scale, top_grad, rois, bottom_grad, argmax):
+    """int roi_pooling_backward_cuda(int,int,int,float, THCudaTensor* top_grad, rois, bottom_grad, THCudaIntTensor* argmax)
+    (roi_pooling_cuda.h): accumulates into the caller's (zeroed) bottom_grad"""
+    g = ops.roi_pool_backward(top_grad, argmax, bottom_grad.shape, channels_last=ops.is_cl(bottom_grad))
+    bottom_grad.add_(g)
+    return 1
+
+
 def install_extension_stubs():
     """Make `from ._ext import nms` / `from ._ext import roi_pooling` of the reference resolve to the HIP library
     (replaces the prebuilt cpython-36 / sm_61 cffi objects under lib/layer_utils/*/_ext)."""
     nms_ns = types.SimpleNamespace(gpu_nms=gpu_nms)
-    roi_ns = types.SimpleNamespace(roi_pooling_forward_cuda=roi_pooling_forward_cuda)
+    roi_ns = types.SimpleNamespace(roi_pooling_forward_cuda=roi_pooling_forward_cuda, roi_pooling_backward_cuda=roi_pooling_backward_cuda)
     _mod("lib.layer_utils.nms._ext", nms=nms_ns).__path__ = []
     _mod("lib.layer_utils.nms._ext.nms", gpu_nms=gpu_nms)
     _mod("lib.layer_utils.roi_pooling._ext", roi_pooling=roi_ns).__path__ = []
-    _mod("lib.layer_utils.roi_pooling._ext.roi_pooling", roi_pooling_forward_cuda=roi_pooling_forward_cuda)
+    _mod("lib.layer_utils.roi_pooling._ext.roi_pooling", roi_pooling_forward_cuda=roi_pooling_forward_cuda,
+         roi_pooling_backward_cuda=roi_pooling_backward_cuda)
 
 
 def install(ref_cfg=None):

@@ -116,14 +116,24 @@ def prepare_projection(blobs, cfg, helper=None):
     return killing_inds
 
 
-class Projection(object):
-    """`Projection.apply(label, lin_indices_3d, lin_indices_2d, volume_dims)` -> (C,Z,Y,X) fp32.
+class Projection(torch.autograd.Function):
+    """`Projection.apply(label, lin_indices_3d, lin_indices_2d, volume_dims)` -> (C,Z,Y,X) fp32, an autograd Function as in the
+    reference (projection.py:124-153).
 
     label: (C,h,w) or (h,w) feature map; the index tensors are the packed int64 lists of
-    ProjectionHelper.compute_projection (slot 0 = count).  Forward only."""
+    ProjectionHelper.compute_projection (slot 0 = count).  backward: sis3d_projection_backward."""
 
     @staticmethod
-    def apply(label, lin_indices_3d, lin_indices_2d, volume_dims):
+    def forward(ctx, label, lin_indices_3d, lin_indices_2d, volume_dims):
+        ctx.save_for_backward(lin_indices_3d, lin_indices_2d)
+        ctx.image_hw = tuple(label.shape[-2:])
+        ctx.label_dim = label.dim()
         return ops.projection(label, lin_indices_3d, lin_indices_2d, volume_dims)
 
-    forward = apply
+    @staticmethod
+    def backward(ctx, grad_output):
+        i3d, i2d = ctx.saved_tensors
+        g = ops.projection_backward(grad_output, i3d, i2d, ctx.image_hw)
+        if ctx.label_dim == 2:
+            g = g[0]
+        return g, None, None, None

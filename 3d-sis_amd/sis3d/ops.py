@@ -111,6 +111,46 @@ def roi_pool(features, rois, pooled, scale, want_argmax=True, out_channels_last=
     return (out, arg) if want_argmax else out
 
 
+def roi_pool_backward(grad_output, argmax, feature_size, channels_last=False):
+    """ROIPoolBackward (roi_pooling_kernel.cu:137-248): scatter grad_output through the argmax saved by roi_pool.
+    grad_output / argmax: (R,C,pw,ph,pl), any strides (both the same); -> grad_input, logical feature_size (1,C,W,H,L)."""
+    g = _dev(grad_output, "grad_output")
+    a = _dev(argmax, "argmax", torch.int32)
+    if g.shape != a.shape or g.dim() != 5:
+        raise _lib.Sis3dError("grad_output and argmax must both be (R,C,pw,ph,pl)")
+    if g.stride() != a.stride():
+        g = g.contiguous()
+        a = a.contiguous()
+    R, C, pw, ph, pl = g.shape
+    _, C2, W, H, L = (int(v) for v in feature_size)
+    if C2 != C or int(feature_size[0]) != 1:
+        raise _lib.Sis3dError("feature_size must be (1,%d,W,H,L)" % C)
+    gin = new_act(C, (W, H, L), g.device).zero_() if channels_last else torch.zeros(1, C, W, H, L, device=g.device)
+    st, gs = g.stride(), gin.stride()
+    if st[3] != pl * st[4] or st[2] != ph * st[3]:
+        raise _lib.Sis3dError("roi_pool_backward: bins must be contiguous in (pw,ph,pl) order")
+    check(lib().sis3d_roi_pool_backward(_ptr(g), _ptr(a), R, C, pw, ph, pl, st[0], st[1], st[4], W, H, L, _ptr(gin), gs[1], gs[2], gs[3],
+                                        gs[4], _stream()), "sis3d_roi_pool_backward")
+    return gin
+
+
+def projection_backward(grad_output, lin3d, lin2d, image_hw=(32, 41)):
+    """Projection.backward (projection.py:139-153): (C,Z,Y,X) gradient -> (C,h,w) gradient of the label image, with the
+    reference's clone-and-resize initial values (see sis3d_projection_backward)."""
+    g = _dev(grad_output, "grad_output").contiguous()
+    C = g.shape[0]
+    nvox = g[0].numel()
+    a = _dev(lin3d, "lin_indices_3d", torch.int64).contiguous()
+    b = _dev(lin2d, "lin_indices_2d", torch.int64).contiguous()
+    npix = int(image_hw[0]) * int(image_hw[1])
+    out = torch.empty(C, int(image_hw[0]), int(image_hw[1]), device=g.device)
+    wsb = lib().sis3d_projection_backward_workspace_bytes(npix)
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=g.device)
+    check(lib().sis3d_projection_backward(_ptr(g), C, nvox, _ptr(a), _ptr(b), npix, _ptr(out), _ptr(ws), wsb, _stream()),
+          "sis3d_projection_backward")
+    return out
+
+
 def roi_pool_levels(f1, f2, rois, levels, pooled, scale, out_channels_last=True):
     f1, f2 = _dev(f1, "features1"), _dev(f2, "features2")
     if f1.shape != f2.shape or f1.stride() != f2.stride():

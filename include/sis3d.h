@@ -90,6 +90,14 @@ int sis3d_roi_pool_levels(const float *features1, const float *features2, int C,
                           int pooled, float spatial_scale, float *out, int64_t os_n, int64_t os_c, int64_t os_bin,
                           sis3d_stream_t stream);
 
+/* backward (training).  Replaces int roi_pooling_backward_cuda(int,int,int,float, THCudaTensor* top_grad,
+ * THCudaTensor* rois, THCudaTensor* bottom_grad, THCudaIntTensor* argmax)  (roi_pooling_cuda.h, ROIPoolBackward
+ * roi_pooling_kernel.cu:137-248): grad_in[c,w,h,l] += grad_out[n,c,bin] for every (n,c,bin) whose argmax is (c,w,h,l).
+ * grad_out / argmax addressed as in sis3d_roi_pool_forward; grad_in: CALLER-ZEROED map with element strides gs_*. */
+int sis3d_roi_pool_backward(const float *grad_out, const int32_t *argmax, int R, int C, int pw, int ph, int pl, int64_t os_n,
+                            int64_t os_c, int64_t os_bin, int W, int H, int L, float *grad_in, int64_t gs_c, int64_t gs_w,
+                            int64_t gs_h, int64_t gs_l, sis3d_stream_t stream);
+
 /* ------------------------------------------------- 2D -> 3D back-projection --
  * Replaces: Projection.forward   lib/layer_utils/projection.py:124-136
  * feat [C][npix]; lin3d/lin2d int64 [nvox+1], slot 0 = count n (read on the
@@ -119,6 +127,14 @@ int sis3d_project_views_max(const float *feats, int V, int C, int64_t npix, cons
 int sis3d_project_views_prepare(const float *feats, int V, int C, int64_t npix, const int64_t *lin3d, const int64_t *lin2d,
                                 const uint8_t *kill_host, int64_t nvox, int32_t *vox2pix, float *feat_rows, int *nslots_out,
                                 sis3d_stream_t stream);
+
+/* Projection.backward (lib/layer_utils/projection.py:139-153, training only): grad_label [C][npix] = the first C*npix elements
+ * of grad_out's storage (the reference resizes a CLONE of grad_output: pixels no voxel maps to keep those values), then
+ * grad_label[:, lin2d[1+k]] = grad_out[:, lin3d[1+k]] for k < lin3d[0], the last k winning on shared pixels.
+ * grad_out [C][nvox].  workspace: sis3d_projection_backward_workspace_bytes(npix). */
+size_t sis3d_projection_backward_workspace_bytes(int64_t npix);
+int sis3d_projection_backward(const float *grad_out, int C, int64_t nvox, const int64_t *lin3d, const int64_t *lin2d, int64_t npix,
+                              float *grad_label, void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
 
 /* Replaces ProjectionHelper.compute_projection (lib/layer_utils/projection.py:52-121) and its
  * call sites' per-view loop (lib/model/trainval.py:336-337,464-465,663-667,799-803) for V views of

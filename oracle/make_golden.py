@@ -83,6 +83,23 @@ def roi_cases(ns):
     print("roi_pool_cases", ref.shape, py.shape)
 
 
+def roi_backward_case(ns):
+    """the reference's Python RoIPool (roi_pool.py:52-199): forward + backward on a small map; its backward accumulates
+    grad_output through the remembered arg-max positions in (roi, c, pw, ph, pl) order"""
+    from lib.layer_utils.roi_pooling.roi_pool import RoIPool
+    g = torch.Generator().manual_seed(77)
+    feat = torch.randn(1, 6, 9, 7, 8, generator=g)
+    lo = torch.rand(7, 3, generator=g) * torch.tensor([20.0, 14.0, 16.0])
+    rois = torch.cat([lo, lo + torch.rand(7, 3, generator=g) * 18.0 + 1.0], 1)
+    rp = RoIPool(2, 2, 2, 0.25)
+    out = rp.forward(feat, rois)
+    gout = torch.randn(out.shape, generator=g)
+    gin = rp.backward(gout)
+    np.savez_compressed(os.path.join(OUT, "roi_pool_backward_case.npz"), feat=feat.numpy(), rois=rois.numpy(), out=out.numpy(),
+                        grad_out=gout.numpy(), grad_in=gin.numpy())
+    print("roi_pool_backward_case", float(gin.abs().sum()))
+
+
 def projection_cases(ns):
     dims = (12, 6, 10)
     feats, i3d, i2d = synthetic.synth_views(3, n_views=3, n_per_view=150, channels=5, image_hw=(8, 9), dims=dims)
@@ -343,6 +360,9 @@ def suncg_case():
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.install()
+    if "--backward" in sys.argv:
+        roi_backward_case(ns)
+        return
     if "--mask-images" in sys.argv:              # round 2: the mask head's colour variants
         e2e(ns, "e2e_mask_use_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="use")
         e2e(ns, "e2e_mask_only_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="only")

@@ -56,8 +56,10 @@ def test_roi_pool_function_reference_call_form(oracle, layout):
     assert tuple(out.shape) == (37, 128, 4, 4, 4) and torch.equal(out.cpu(), want)
     assert fn.argmax.dtype == torch.int32 and torch.equal(fn.argmax.cpu(), warg)
     assert fn.rois is not None and tuple(fn.feature_size) == (1, 128, 24, 12, 24)
-    with pytest.raises(NotImplementedError):
-        fn.backward(out)
+    gin, grois = fn.backward(out)                                       # roi_pool.py:40-50: (grad_input, zeros for the rois)
+    assert tuple(gin.shape) == tuple(feat.shape) and tuple(grois.shape) == tuple(rois.shape)
+    want_g = oracle.roi_pool_backward(want, warg, feat.shape)
+    assert float((gin.cpu() - want_g).abs().max()) <= 1e-4 * float(want_g.abs().max())
 
 
 def test_roi_pooling_forward_cuda_cffi_signature(oracle):

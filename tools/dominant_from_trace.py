@@ -1,21 +1,37 @@
 #!/usr/bin/env python
-"""rocprofv3 kernel-trace CSV -> durations of the dominant conv template split by launch grid.
-The template conv3d_mfma_kernel<3,1,4,4,4,2,2,3,1,32,false,...> serves geometry2.0 (216 workgroups), ONE 128->256 RPN conv
-(432 workgroups: the launches bench.py times for `roofline.achieved`) and the batched pair of RPN convs (864)."""
-import collections
+"""The dominant kernel's launches inside a rocprofv3 kernel trace of `bench.py`: bench.py times the rpn_net k3 128->256 conv with 100
+warm + 50 timed launches BEFORE anything else of that template runs, so the first 150 dispatches of conv3d_k3t16_kernel<6, 6, 12, ...>
+with a 256 x 1 grid (start-time order) are exactly those; the last 50 of them are the timed ones.  The kernel_stats row of the
+template averages every layer that uses the instantiation (the 48x24x48 Bottleneck convs share its grid).
+Usage: python tools/dominant_from_trace.py <kernel_trace.csv> [bench.json]  -> JSON on stdout"""
 import csv
 import json
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv3d_mfma_kernel<3, 1, 4, 4, 4, 2, 2, 3, 1, 32, false" in r["Kernel_Name"]]
-by = collections.defaultdict(list)
-for r in rows:
-    by[int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-out = {"kernel": "conv3d_mfma_kernel<3,1,4,4,4,2,2,3,1,32,false,4,false>", "by_workgroups": {}}
-for g, v in sorted(by.items()):
-    out["by_workgroups"][str(g)] = {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
-d = out["by_workgroups"].get("432")
-if d:
-    out["dominant_single_rpn_conv"] = {"avg_us": d["avg_us"], "tflops": 2.0 * 6912 * 256 * 128 * 27 / d["avg_us"] / 1e6,
-                                       "note": "432-workgroup launches = bench.py's timing launches of the dominant kernel"}
-print(json.dumps(out, indent=1))
+
+def main():
+    rows = []
+    for r in csv.DictReader(open(sys.argv[1])):
+        if "conv3d_k3t16_kernel<6, 6, 12" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 256 * 256 and int(r.get("Grid_Size_Y", 1)) == 1:
+            rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    rows.sort()
+    first = [d for _, d in rows[:150]]
+    timed = first[100:150]
+    out = {"kernel": "conv3d_k3t16_kernel<6,6,12,3,3> (rpn_net 128->256 on 24x12x24, 256 workgroups x 256 threads)",
+           "launches_of_this_grid_in_trace": len(rows), "bench_timing_launches": len(first),
+           "timed_50_mean_us": sum(timed) / max(1, len(timed)), "timed_50_min_us": min(timed) if timed else None,
+           "timed_50_max_us": max(timed) if timed else None, "warm_100_mean_us": sum(first[:100]) / max(1, len(first[:100])),
+           "flop_per_launch": 2.0 * 6912 * 256 * 128 * 27}
+    out["tflops"] = out["flop_per_launch"] / out["timed_50_mean_us"] / 1e6 if timed else None
+    out["frac_of_157.3TF"] = out["tflops"] / 157.3 if timed else None
+    if len(sys.argv) > 2:
+        try:
+            b = json.load(open(sys.argv[2]))
+            out["bench_py_launch_us_same_run"] = b["roofline"]["launch_us"]
+        except Exception:
+            pass
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
