@@ -1,0 +1,429 @@
+// The body of a Bottleneck (lib/nets/backbones.py:27-40) after its conv1, as ONE launch on gfx950:
+//     y2   = relu(conv2(y1) + b2)               nn.Conv3d(planes, planes, 3, padding=1)       (backbones.py:21,32-33)
+//     out  = relu(conv3(y2) + b3 + x)           nn.Conv3d(planes, inplanes, 1) + residual     (backbones.py:22,35-40)
+//     y1n  = relu(conv1_next(out) + b1n)        optional: the NEXT block's conv1               (backbones.py:20,29-31)
+// conv3d_t16.hip + pointwise.hip run this as two launches (the k3 conv, then the register-chained 1x1x1 pair) with y2
+// making a round trip through L2; each of those launches costs 5-9 us on the 24x12x24 / 48x24x48 grids of a 96x48x96
+// chunk where the arithmetic is worth 1-3 us.  Here the workgroup that owns a brick of voxels owns ALL `planes` output
+// channels of conv2, so the 1x1x1 tail can run on the brick while it is still on the CU:
+//   * conv2 exactly as conv3d_k3t16_kernel (one wave per SIMD, reduction split by input channel over the four waves,
+//     LDS halo image with taps as immediate offsets, weight fragments through a register ring), but with NTC = planes/16
+//     accumulator tiles per voxel tile -- one ds_read_b64 now feeds 2 NTC MFMAs;
+//   * the cross-wave sum goes through LDS as [voxel][cout] tiles; read back as 16 B per lane (voxel = lane & 15,
+//     channels 4 (lane >> 4) .. +3) it IS the B operand of the transposed GEMM  D^T[cout][voxel] = W3 * y2^T  of
+//     pointwise.hip, whose result is again the operand layout of conv1_next: no further staging;
+//   * same summation orders as the two-launch path (wave partials (s0+s1)+(s2+s3)+bias; acc+bias+residual), so `out` is
+//     bit-identical to it.
+// Bricks: 6x6x6 (256 workgroups on 48x24x48) and 3x3x3 (256 workgroups on 24x12x24); planes = 32 only: with 64 planes a
+// 27-voxel brick would stream the whole 442 KB conv2 weight through every workgroup (measured slower than two launches).
+#include "common.h"
+#include "mfma16.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int CK = 32;         // channels per LDS image
+constexpr int RS = CK + 4;     // padded row stride (floats)
+constexpr int TAPS = 27;
+
+template <int K>
+__device__ __forceinline__ float comp(const float4 &v)
+{
+    if constexpr (K == 0) return v.x;
+    else if constexpr (K == 1) return v.y;
+    else if constexpr (K == 2) return v.z;
+    else return v.w;
+}
+
+struct BnArgs {
+    const float *y1;           // conv1 output, rows of `planes` floats
+    const float *w2p, *b2;     // conv2: sis3d_conv_k3t16_pack_weight, bias (may be NULL)
+    const float *w3p, *b3;     // conv3: sis3d_conv_pw16_pack_weight, bias (may be NULL)
+    const float *res;          // the block input x, rows of res_stride floats
+    float *out;                // block output at channel out_coff of rows of out_stride floats
+    const float *w1n, *b1n;    // next block's conv1 (pw16 pack), bias; unused when C2 == 0
+    float *y1n;                // rows of C2 floats
+    int res_stride, out_stride, out_coff;
+    int X, Y, Z, nby, nbz, nbricks;
+#ifdef BN_TIMING
+    long long *dbg;            // tools/bn_timing.cpp: wall_clock64() at phase boundaries, [workgroup][wave][8]
+#endif
+};
+
+#ifdef BN_TIMING
+#define BN_T(k)                                                                                            \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = (long long)wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+#else
+#define BN_T(k)
+#endif
+
+template <int BX, int BY, int BZ, int PL, int CIO, int C2>
+__global__ __launch_bounds__(256, 1) void bottleneck16_kernel(const BnArgs a)
+{
+    constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
+    constexpr int NTC = PL / 16, NQ = PL / CK, NT3 = CIO / 16, NTN = C2 / 16;
+    constexpr int IBX = BX + 2, IBY = BY + 2, IBZ = BZ + 2, ROWS = IBX * IBY * IBZ;
+    constexpr int PPR = PL / 4;                              // 16 B pieces per row
+    constexpr int RPI = 256 / PPR;                           // rows staged per pass of the workgroup
+    constexpr int ITEMS = ROWS * PPR, NIT = (ITEMS + 255) / 256;
+    constexpr int IMG = ROWS * RS;                           // floats per 32-channel image
+    constexpr int G = MT >= 2 ? 2 : 1, NG = (MT + G - 1) / G;
+    constexpr int RB = MT >= 14 ? 3 : 9;                     // weight ring depth (taps)
+    constexpr int NKT = NQ * TAPS, NSTEP = NKT * NG;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [NQ][ROWS][RS]; then [4 waves][MT][NTC][16][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    BN_T(0);
+
+    // consecutive bricks on one XCD (block b runs on XCD b % 8): neighbours share halo rows in that XCD's L2
+    int brick;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
+        brick = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int gX = a.X, gY = a.Y, gZ = a.Z;
+    const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
+    const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
+
+    // ---- halo image of y1 (zero outside the grid: conv2's padding), all NQ images at once
+    float4 sv[NIT];
+    {
+        const int row0 = tid / PPR, pc = tid % PPR;
+        int hz = row0 % IBZ, hy = (row0 / IBZ) % IBY, hx = row0 / (IBZ * IBY);
+        constexpr int DZ = RPI % IBZ, DY = (RPI / IBZ) % IBY, DX = RPI / (IBZ * IBY);
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
+            const bool ok = (tid + it * 256 < ITEMS) && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
+            const size_t o = ok ? ((size_t)((gx * gY + gy) * gZ + gz) * PL + pc * 4) : 0;
+            const float4 v = *reinterpret_cast<const float4 *>(a.y1 + o);
+            sv[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            hz += DZ;
+            const int cz = hz >= IBZ;
+            hz -= cz * IBZ;
+            hy += DY + cz;
+            const int cy = hy >= IBY;
+            hy -= cy * IBY;
+            hx += DX + cy;
+        });
+    }
+    // conv2 B operand: packed [ntile][chunk][wave][tap][lane][2]
+    const float2 *bp = reinterpret_cast<const float2 *>(a.w2p) + (size_t)wave * (TAPS * 64) + lane;
+    auto load_b = [&](auto KT, auto N) {
+        constexpr int kt = decltype(KT)::value, n = decltype(N)::value;
+        constexpr int q = kt / TAPS, tap = kt % TAPS;
+        return bp[(size_t)((n * NQ + q) * 4) * (TAPS * 64) + tap * 64];
+    };
+    float2 bq[RB][NTC];
+    static_for<0, RB - 1>([&](auto D) {
+        static_for<0, NTC>([&](auto N) { bq[decltype(D)::value][decltype(N)::value] = load_b(D, N); });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    int abase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = 16 * t + li;
+        m = m < M ? m : M - 1;                               // surplus rows of the last tile recompute a valid voxel, never stored
+        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        abase[t] = (((lx * IBY + ly) * IBZ + lz) * RS + 8 * wave + 2 * kq) * 4;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NIT>([&](auto I) {
+        constexpr int it = decltype(I)::value;
+        const int idx = tid + it * 256;
+        const int row = idx / PPR, pc = idx % PPR;
+        if (idx < ITEMS) *reinterpret_cast<float4 *>(lds + (pc >> 3) * IMG + row * RS + (pc & 7) * 4) = sv[it];
+    });
+    BN_T(1);
+    __syncthreads();
+    BN_T(2);
+
+    // ---- operands of the 1x1x1 tail, requested BEFORE the conv2 loop so that they land under it (a barrier drains the
+    // vector-memory counter: requested after the loop they cost 1.3-1.6 us of pure latency, tools/bn_timing.cpp): weights /
+    // biases of this lane, and the residual rows of the voxel tiles t = wave, wave + 4, ... this wave will finish
+    constexpr int NTW = (MT + 3) / 4;
+    float4 w3[NT3][NTC], bb3[NT3], bb2[NTC];
+    static_for<0, NT3>([&](auto N) {
+        constexpr int n = decltype(N)::value;
+        static_for<0, NTC>([&](auto Gq) {
+            constexpr int g = decltype(Gq)::value;
+            w3[n][g] = reinterpret_cast<const float4 *>(a.w3p)[(size_t)(n * NTC + g) * 64 + lane];
+        });
+        bb3[n] = a.b3 ? *reinterpret_cast<const float4 *>(a.b3 + 16 * n + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    static_for<0, NTC>([&](auto Gq) {
+        constexpr int g = decltype(Gq)::value;
+        bb2[g] = a.b2 ? *reinterpret_cast<const float4 *>(a.b2 + 16 * g + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    constexpr int NTNA = NTN > 0 ? NTN : 1;
+    float4 wn[NTNA][NT3], bbn[NTNA];
+    if constexpr (NTN > 0) {
+        static_for<0, NTN>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            static_for<0, NT3>([&](auto Gq) {
+                constexpr int g = decltype(Gq)::value;
+                wn[n][g] = reinterpret_cast<const float4 *>(a.w1n)[(size_t)(n * NT3 + g) * 64 + lane];
+            });
+            bbn[n] = a.b1n ? *reinterpret_cast<const float4 *>(a.b1n + 16 * n + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        });
+    }
+    constexpr bool PRE = NTW * NT3 <= 16;                    // residual rows requested ahead only while they fit the register file
+    float4 rr[PRE ? NTW : 1][NT3];
+    size_t vox[NTW];
+    bool okv[NTW];
+    static_for<0, NTW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int t = wave + 4 * i;
+        const int m = 16 * t + li;
+        const int mc = m < M ? m : M - 1;
+        const int lx = mc / (BY * BZ), ly = (mc / BZ) % BY, lz = mc % BZ;
+        const int ox = ox0 + lx, oy = oy0 + ly, oz = oz0 + lz;
+        okv[i] = t < MT && m < M && ox < gX && oy < gY && oz < gZ;
+        vox[i] = okv[i] ? (size_t)(ox * gY + oy) * gZ + oz : 0;
+        if constexpr (PRE) {
+            const float *rp = a.res + vox[i] * a.res_stride + 4 * kq;
+            static_for<0, NT3>([&](auto N) { rr[i][decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
+        }
+    });
+
+    f32x4 acc[MT][NTC];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- conv2: steps (chunk, tap, group of G voxel tiles)
+    {
+        f32x2 ar[2][G];
+        auto read_group = [&](auto BUF, auto STEP) {
+            constexpr int buf = decltype(BUF)::value, step = decltype(STEP)::value;
+            constexpr int kt = step / NG, g = step % NG, q = kt / TAPS, tap = kt % TAPS;
+            constexpr int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+            constexpr int toff = (q * IMG + ((dx * IBY + dy) * IBZ + dz) * RS) * 4;
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value, t = g * G + j;
+                if constexpr (t < MT)
+                    ar[buf][j] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(lds) + abase[t] + toff);
+            });
+        };
+        read_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, NSTEP>([&](auto STEP) {
+            constexpr int step = decltype(STEP)::value;
+            constexpr int kt = step / NG, g = step % NG;
+            if constexpr (g == 0 && kt + RB - 1 < NKT) {
+                static_for<0, NTC>([&](auto N) {
+                    bq[(kt + RB - 1) % RB][decltype(N)::value] = load_b(std::integral_constant<int, kt + RB - 1>{}, N);
+                });
+            }
+            if constexpr (step + 1 < NSTEP) read_group(std::integral_constant<int, (step + 1) & 1>{}, std::integral_constant<int, step + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value, t = g * G + j;
+                if constexpr (t < MT)
+                    static_for<0, NTC>([&](auto N) {
+                        constexpr int n = decltype(N)::value;
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].x, bq[kt % RB][n].x, acc[t][n], 0, 0, 0);
+                    });
+            });
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value, t = g * G + j;
+                if constexpr (t < MT)
+                    static_for<0, NTC>([&](auto N) {
+                        constexpr int n = decltype(N)::value;
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].y, bq[kt % RB][n].y, acc[t][n], 0, 0, 0);
+                    });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    BN_T(3);
+    __syncthreads();                                         // every wave is done with the image
+    BN_T(4);
+
+    // ---- cross-wave reduction through LDS: tile (t, n) of wave w as [16 voxels][16 couts] (D layout: column = lane & 15,
+    // rows 4 (lane >> 4) + r)
+    constexpr int TS = 320;                                  // tile stride: the four 64-float row groups 80 apart -> 64 distinct banks per write
+    constexpr int SLAB = MT * NTC * TS;
+    {
+        float *red = lds + (size_t)wave * SLAB;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int n = 0; n < NTC; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(t * NTC + n) * TS + kq * 80 + r * 16 + li] = acc[t][n][r];
+    }
+    BN_T(5);
+    __syncthreads();
+    BN_T(6);
+
+    // ---- 1x1x1 tail: lane = (voxel li, channel quad kq).  TB voxel tiles are finished together, branch-free, so that their
+    // MFMA chains interleave (a lone tile's 8-16 dependent MFMAs run at the 40-cycle accumulator latency); per accumulator the
+    // order stays g ascending, x y z w (= gemm_t).  Tiles past MT recompute tile MT - 1 and store nothing.
+    constexpr int TB = PRE ? NTW : 1;
+    static_for<0, NTW / TB>([&](auto Bq) {
+        constexpr int i0 = decltype(Bq)::value * TB;
+        float4 y2[TB][NTC], r[TB][NT3];
+        static_for<0, TB>([&](auto J) {
+            constexpr int j = decltype(J)::value, i = i0 + j;
+            const int t = wave + 4 * i, tc = t < MT ? t : MT - 1;
+            static_for<0, NTC>([&](auto Gq) {
+                constexpr int g = decltype(Gq)::value;
+                const float4 *src = reinterpret_cast<const float4 *>(lds + (tc * NTC + g) * TS + (li >> 2) * 80 + (li & 3) * 16 + 4 * kq);
+                const float4 s0 = src[0], s1 = src[SLAB / 4], s2 = src[2 * (SLAB / 4)], s3 = src[3 * (SLAB / 4)];
+                float4 u;
+                u.x = (s0.x + s1.x) + (s2.x + s3.x) + bb2[g].x;
+                u.y = (s0.y + s1.y) + (s2.y + s3.y) + bb2[g].y;
+                u.z = (s0.z + s1.z) + (s2.z + s3.z) + bb2[g].z;
+                u.w = (s0.w + s1.w) + (s2.w + s3.w) + bb2[g].w;
+                y2[j][g] = relu4(u, true);
+            });
+            if constexpr (PRE) {
+                static_for<0, NT3>([&](auto N) { r[j][decltype(N)::value] = rr[i][decltype(N)::value]; });
+            } else {
+                const float *rp = a.res + vox[i] * a.res_stride + 4 * kq;
+                static_for<0, NT3>([&](auto N) { r[j][decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
+            }
+        });
+        f32x4 acc3[TB][NT3];
+        static_for<0, TB>([&](auto J) { static_for<0, NT3>([&](auto N) { acc3[decltype(J)::value][decltype(N)::value] = (f32x4){0.f, 0.f, 0.f, 0.f}; }); });
+        static_for<0, NTC>([&](auto Gq) {
+            constexpr int g = decltype(Gq)::value;
+            static_for<0, 4>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                static_for<0, TB>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    static_for<0, NT3>([&](auto N) {
+                        constexpr int n = decltype(N)::value;
+                        acc3[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp<k>(w3[n][g]), comp<k>(y2[j][g]), acc3[j][n], 0, 0, 0);
+                    });
+                });
+            });
+        });
+        float4 z[TB][NT3];
+        static_for<0, TB>([&](auto J) {
+            constexpr int j = decltype(J)::value, i = i0 + j;
+            static_for<0, NT3>([&](auto N) {
+                constexpr int n = decltype(N)::value;
+                float4 u;
+                u.x = acc3[j][n][0] + bb3[n].x + r[j][n].x; u.y = acc3[j][n][1] + bb3[n].y + r[j][n].y;
+                u.z = acc3[j][n][2] + bb3[n].z + r[j][n].z; u.w = acc3[j][n][3] + bb3[n].w + r[j][n].w;
+                z[j][n] = relu4(u, true);
+                if (okv[i]) *reinterpret_cast<float4 *>(a.out + vox[i] * a.out_stride + a.out_coff + 16 * n + 4 * kq) = z[j][n];
+            });
+        });
+        if constexpr (NTN > 0) {
+            f32x4 accn[TB][NTN];
+            static_for<0, TB>([&](auto J) { static_for<0, NTN>([&](auto N) { accn[decltype(J)::value][decltype(N)::value] = (f32x4){0.f, 0.f, 0.f, 0.f}; }); });
+            static_for<0, NT3>([&](auto Gq) {
+                constexpr int g = decltype(Gq)::value;
+                static_for<0, 4>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    static_for<0, TB>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        static_for<0, NTN>([&](auto N) {
+                            constexpr int n = decltype(N)::value;
+                            accn[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp<k>(wn[n][g]), comp<k>(z[j][g]), accn[j][n], 0, 0, 0);
+                        });
+                    });
+                });
+            });
+            static_for<0, TB>([&](auto J) {
+                constexpr int j = decltype(J)::value, i = i0 + j;
+                static_for<0, NTN>([&](auto N) {
+                    constexpr int n = decltype(N)::value;
+                    float4 u;
+                    u.x = accn[j][n][0] + bbn[n].x; u.y = accn[j][n][1] + bbn[n].y; u.z = accn[j][n][2] + bbn[n].z; u.w = accn[j][n][3] + bbn[n].w;
+                    u = relu4(u, true);
+                    if (okv[i]) *reinterpret_cast<float4 *>(a.y1n + vox[i] * C2 + 16 * n + 4 * kq) = u;
+                });
+            });
+        }
+    });
+    BN_T(7);
+}
+
+template <int BX, int BY, int BZ, int PL, int CIO, int C2>
+int launch_bn(BnArgs &a, hipStream_t st)
+{
+    constexpr int M = BX * BY * BZ, MT = (M + 15) / 16, NTC = PL / 16, NQ = PL / CK;
+    constexpr int ROWS = (BX + 2) * (BY + 2) * (BZ + 2);
+    constexpr size_t img = (size_t)NQ * ROWS * RS * sizeof(float), red = (size_t)4 * MT * NTC * 320 * sizeof(float);
+    constexpr size_t lds = img > red ? img : red;
+    static_assert(lds <= 160 * 1024, "LDS brick too large");
+    const int nbx = cdiv(a.X, BX);
+    a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
+    const int64_t nb = (int64_t)nbx * a.nby * a.nbz;
+    if (nb > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    a.nbricks = (int)nb;
+    auto kern = bottleneck16_kernel<BX, BY, BZ, PL, CIO, C2>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return sis3d_check_launch();
+}
+
+template <int BX, int BY, int BZ>
+int dispatch_bn(BnArgs &a, int planes, int cio, int c2, hipStream_t st)
+{
+#ifdef BN_TIMING
+    if (planes == 32 && cio == 32 && c2 == 32) return launch_bn<BX, BY, BZ, 32, 32, 32>(a, st);
+    if (planes == 32 && cio == 128 && c2 == 32) return launch_bn<3, 3, 3, 32, 128, 32>(a, st);
+    return SIS3D_EUNSUPPORTED;
+#else
+    if (planes == 32 && cio == 32 && c2 == 0) return launch_bn<BX, BY, BZ, 32, 32, 0>(a, st);
+    if (planes == 32 && cio == 32 && c2 == 32) return launch_bn<BX, BY, BZ, 32, 32, 32>(a, st);
+    if (planes == 32 && cio == 64 && c2 == 0) return launch_bn<BX, BY, BZ, 32, 64, 0>(a, st);
+    if (planes == 32 && cio == 128 && c2 == 0) return launch_bn<BX, BY, BZ, 32, 128, 0>(a, st);
+    if (planes == 32 && cio == 128 && c2 == 32) return launch_bn<BX, BY, BZ, 32, 128, 32>(a, st);
+    return SIS3D_EUNSUPPORTED;
+#endif
+}
+
+} // namespace
+
+extern "C" int sis3d_bottleneck16_brick(int X, int Y, int Z, int planes)
+{
+    if (X <= 0 || Y <= 0 || Z <= 0 || (planes != 32 && planes != 64)) return -1;
+    // 64 planes: a 27-voxel brick streams the whole 442 KB conv2 weight through every workgroup -- measured 25.8 us against
+    // 17.8 + 7.6 us for the two launches on 24x12x24 (profiles/README.md): the two-launch path serves those blocks
+    if (planes != 32) return -1;
+    const int64_t n6 = (int64_t)cdiv(X, 6) * cdiv(Y, 6) * cdiv(Z, 6), n3 = (int64_t)cdiv(X, 3) * cdiv(Y, 3) * cdiv(Z, 3);
+    if (n6 >= 192) return 0;                                 // the chip is full with 6x6x6 bricks (14 tiles per wave, 96 % fill)
+    if (n3 <= 1024) return 1;                                // small grid: 3x3x3 bricks (256 workgroups on 24x12x24)
+    return 0;
+}
+
+extern "C" int sis3d_bottleneck16(const float *y1, int X, int Y, int Z, int planes, const float *w2_t16, const float *b2,
+                                  const float *w3_pw16, const float *b3, int cio, const float *residual, int res_stride, float *out,
+                                  int out_stride, int out_coff, const float *w1n_pw16, const float *b1n, int c2, float *y1n, int brick,
+                                  sis3d_stream_t stream)
+{
+    if (!y1 || !w2_t16 || !w3_pw16 || !residual || !out || X <= 0 || Y <= 0 || Z <= 0) return SIS3D_EINVAL;
+    if (c2 < 0 || (c2 > 0 && (!w1n_pw16 || !y1n))) return SIS3D_EINVAL;
+    if (res_stride < cio || (res_stride % 4) || (out_stride % 4) || (out_coff % 4) || out_stride < out_coff + cio) return SIS3D_EINVAL;
+    if ((int64_t)X * Y * Z * (int64_t)(res_stride > out_stride ? res_stride : out_stride) > (int64_t)1 << 40) return SIS3D_EUNSUPPORTED;
+    if (brick < 0) brick = sis3d_bottleneck16_brick(X, Y, Z, planes);
+    if (brick < 0) return SIS3D_EUNSUPPORTED;
+    BnArgs a;
+    a.y1 = y1; a.w2p = w2_t16; a.b2 = b2; a.w3p = w3_pw16; a.b3 = b3; a.res = residual; a.out = out;
+    a.w1n = c2 ? w1n_pw16 : nullptr; a.b1n = c2 ? b1n : nullptr; a.y1n = c2 ? y1n : nullptr;
+    a.res_stride = res_stride; a.out_stride = out_stride; a.out_coff = out_coff;
+    a.X = X; a.Y = Y; a.Z = Z;
+#ifdef BN_TIMING
+    extern long long *g_bn_dbg;
+    a.dbg = g_bn_dbg;
+#endif
+    hipStream_t st = as_stream(stream);
+    switch (brick) {
+    case 0: return dispatch_bn<6, 6, 6>(a, planes, cio, c2, st);
+    case 1: return dispatch_bn<3, 3, 3>(a, planes, cio, c2, st);
+    default: return SIS3D_EINVAL;
+    }
+}

@@ -79,6 +79,9 @@ SIGNATURES = {
     "sis3d_conv3d_ragged": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),
     "sis3d_ragged_tiling_k3t16": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_conv3d_k3t16_ragged": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp]),
+    "sis3d_bottleneck16_brick": (c_int, [c_int, c_int, c_int, c_int]),
+    "sis3d_bottleneck16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp,
+                                   c_int, c_vp, c_int, c_vp]),
     "sis3d_conv3d_planar2_ragged": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "sis3d_maxpool3d_3x3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "sis3d_planar_to_cl": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),

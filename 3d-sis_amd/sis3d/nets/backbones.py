@@ -88,9 +88,14 @@ class Bottleneck(nn.Module):
         if SPLIT_BOTTLENECK and pc2.packed_t16 is not None:
             # conv2 on the balanced k3 kernel (every SIMD of the chip gets the same MFMA count), then ONE pointwise launch
             # for conv3 + residual + ReLU (+ the next block's conv1 on the tile while it is on chip)
-            y2 = ops.conv3d_k3t16([y1], [pc2], relu=True)[0]
             pc3 = self.conv3._packed.get(self.conv3)
             stage = dict(pc=nxt.conv1._packed.get(nxt.conv1), relu=True) if nxt is not None else None
+            try:
+                # the whole body in ONE launch: the brick's conv2 tile stays on the CU for conv3 + residual + next conv1
+                return ops.bottleneck16(y1, pc2, pc3, x, out=out, out_coff=out_coff, stage=stage)
+            except ops.Sis3dUnsupported:
+                pass
+            y2 = ops.conv3d_k3t16([y1], [pc2], relu=True)[0]
             try:
                 return ops.conv3d_pw_chain(y2, pc3, residual=x, relu=True, out=out, out_coff=out_coff, stage=stage)
             except ops.Sis3dUnsupported:

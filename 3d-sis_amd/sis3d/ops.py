@@ -461,6 +461,41 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     return outs
 
 
+BNECK_SPLIT = bool(_os.environ.get("SIS3D_BNECK_SPLIT"))  # A/B switch: Bottleneck body as k3t16 + pointwise launches
+
+
+def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick=-1):
+    """Bottleneck body in one launch (sis3d_bottleneck16): relu(conv3(relu(conv2(y1))) + x) -> `out`, and optionally the next
+    block's conv1 on it.  y1: channels-last conv1 output; pc2: k3 PackedConv (.packed_t16); pc3 / stage['pc']: k1 PackedConv
+    (.packed_pw16); residual: the block input.  -> (out, stage_out | None); raises Sis3dUnsupported."""
+    spc = stage["pc"] if stage is not None else None
+    if BNECK_SPLIT or pc2.packed_t16 is None or pc3.packed_pw16 is None or (spc is not None and spc.packed_pw16 is None):
+        raise Sis3dUnsupported("no fused Bottleneck pack")
+    if not is_cl(y1) or not is_cl(residual):
+        raise _lib.Sis3dError("bottleneck16 expects channels-last activations")
+    _, pl, X, Y, Z = y1.shape
+    od = (X, Y, Z)
+    if (pc2.cin, pc2.cout, pc2.k, pc3.cin, pc3.k) != (pl, pl, 3, pl, 1) or tuple(residual.shape[2:]) != od or residual.shape[1] != pc3.cout:
+        raise _lib.Sis3dError("bottleneck16: layer shapes do not form a Bottleneck")
+    if spc is not None and (spc.k != 1 or spc.cin != pc3.cout or not stage.get("relu", True)):
+        raise Sis3dUnsupported("bottleneck16: stage must be a k=1 conv + ReLU on the block output")
+    if lib().sis3d_bottleneck16_brick(X, Y, Z, pl) < 0 and brick < 0:
+        raise Sis3dUnsupported("bottleneck16: the two-launch path serves this grid")
+    if out is None:
+        out, out_coff = new_act(pc3.cout, od, y1.device), 0
+    elif not is_cl(out) or tuple(out.shape[2:]) != od or out_coff + pc3.cout > out.shape[1]:
+        raise _lib.Sis3dError("bottleneck16: bad `out`")
+    so = new_act(spc.cout, od, y1.device) if spc is not None else None
+    rc = lib().sis3d_bottleneck16(_ptr(y1), X, Y, Z, pl, _ptr(pc2.packed_t16), _ptr(pc2.bias), _ptr(pc3.packed_pw16), _ptr(pc3.bias),
+                                  pc3.cout, _ptr(residual), residual.shape[1], _ptr(out), out.shape[1], int(out_coff),
+                                  _ptr(spc.packed_pw16) if spc else None, _ptr(spc.bias) if spc else None, spc.cout if spc else 0,
+                                  _ptr(so), int(brick), _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no fused Bottleneck instantiation for planes %d, %d channels" % (pl, pc3.cout))
+    check(rc, "sis3d_bottleneck16")
+    return out, so
+
+
 def conv3d_pw_chain(x, pc, residual=None, relu=True, out=None, out_coff=0, stage=None):
     """1x1x1 conv + bias + residual + ReLU written to `out` (channel offset out_coff), optionally followed by ONE fused
     1x1x1 stage on the on-chip tile (the next Bottleneck's conv1): sis3d_conv3d_pw_chain.

@@ -384,6 +384,22 @@ int sis3d_conv3d_k3t16_ragged(const float *in, int cin, int cin_stride, const fl
                               float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks, int brick,
                               sis3d_stream_t stream);
 
+/* The body of a Bottleneck after its conv1 (lib/nets/backbones.py:27-40) in ONE launch (csrc/bottleneck.hip):
+ *     y2  = relu(conv2(y1) + b2)            Conv3d(planes, planes, 3, padding=1); y1 = rows of `planes` floats
+ *     out = relu(conv3(y2) + b3 + x)        Conv3d(planes, cio, 1) + residual x (rows of res_stride floats) -> channels
+ *                                           [out_coff, out_coff + cio) of rows of out_stride floats
+ *     y1n = relu(conv1_next(out) + b1n)     optional (c2 > 0): the NEXT block's conv1, rows of c2 floats
+ * The workgroup that owns a brick of voxels owns all `planes` channels of conv2 (the balanced k3 scheme of
+ * sis3d_conv3d_k3t16), so the 1x1x1 tail runs on the brick while it is on the CU; `out` is bit-identical to
+ * sis3d_conv3d_k3t16 followed by sis3d_conv3d_pw16.  w2_t16: sis3d_conv_k3t16_pack_weight(planes, planes); w3_pw16 / w1n_pw16:
+ * sis3d_conv_pw16_pack_weight.  brick: 0 = 6x6x6, 1 = 3x3x3, -1 = sis3d_bottleneck16_brick's choice (which is
+ * -1 itself -> SIS3D_EUNSUPPORTED when the two-launch path is the better one: 64-plane blocks).  (planes, cio, c2)
+ * instantiated: (32,32,{0,32}) (32,64,0) (32,128,{0,32}); others -> SIS3D_EUNSUPPORTED. */
+int sis3d_bottleneck16_brick(int X, int Y, int Z, int planes);
+int sis3d_bottleneck16(const float *y1, int X, int Y, int Z, int planes, const float *w2_t16, const float *b2, const float *w3_pw16,
+                       const float *b3, int cio, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
+                       const float *w1n_pw16, const float *b1n, int c2, float *y1n, int brick, sis3d_stream_t stream);
+
 /* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding.  The C output channels land at
  * [out_coff, out_coff + C) of rows of out_stride floats (out_stride = C, out_coff = 0: a plain tensor; otherwise a channel
  * range of a wider tensor = the torch.cat of backbones.py:109 done in place). */

@@ -1,0 +1,102 @@
+"""The one-launch Bottleneck body (csrc/bottleneck.hip, sis3d_bottleneck16): relu(conv3(relu(conv2(y1))) + x) and the next
+block's conv1, against torch-CPU operators (lib/nets/backbones.py:17-40; tolerance 1e-4, north_star) and -- bit for bit --
+against the two-launch path (sis3d_conv3d_k3t16 + sis3d_conv3d_pw16) whose summation orders it keeps."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sis3d import ops as o
+    o.lib()
+    return o
+
+
+def cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last_3d)
+
+
+def _w(cout, cin, k, g):
+    fan = cin * k ** 3
+    return (torch.rand(cout, cin, k, k, k, generator=g) * 2 - 1) / fan ** 0.5
+
+
+def _case(ops, planes, cio, c2, dims, seed, bias=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, cio, *dims, generator=g)
+    y1 = torch.relu(torch.randn(1, planes, *dims, generator=g))
+    w2, w3 = _w(planes, planes, 3, g), _w(cio, planes, 1, g)
+    b2 = torch.randn(planes, generator=g) * 0.1 if bias else None
+    b3 = torch.randn(cio, generator=g) * 0.1 if bias else None
+    want = F.relu(F.conv3d(F.relu(F.conv3d(y1, w2, b2, padding=1)), w3, b3) + x)
+    pc2 = ops.PackedConv(w2.cuda(), b2.cuda() if bias else None)
+    pc3 = ops.PackedConv(w3.cuda(), b3.cuda() if bias else None)
+    stage, wantn = None, None
+    if c2:
+        w1n, b1n = _w(c2, cio, 1, g), torch.randn(c2, generator=g) * 0.1
+        stage = dict(pc=ops.PackedConv(w1n.cuda(), b1n.cuda()), relu=True)
+        wantn = F.relu(F.conv3d(want, w1n, b1n))
+    return x, y1, pc2, pc3, stage, want, wantn
+
+
+SHAPES = [(32, 32, 32, (48, 24, 48)), (32, 32, 0, (48, 24, 48)), (32, 128, 32, (24, 12, 24)), (32, 128, 0, (24, 12, 24)),
+          (32, 64, 0, (24, 12, 24)), (32, 64, 0, (48, 24, 48))]
+
+
+@pytest.mark.parametrize("planes,cio,c2,dims", SHAPES)
+def test_network_shapes_vs_torch_cpu_and_two_launch_path(ops, planes, cio, c2, dims):
+    x, y1, pc2, pc3, stage, want, wantn = _case(ops, planes, cio, c2, dims, planes + cio + c2 + dims[0])
+    out, y1n = ops.bottleneck16(cl(y1), pc2, pc3, cl(x), stage=stage)
+    assert ops.is_cl(out) and out.shape == want.shape
+    assert (out.cpu() - want).abs().max().item() <= TOL
+    y2 = ops.conv3d_k3t16([cl(y1)], [pc2], relu=True)[0]
+    ref, refn = ops.conv3d_pw16(y2, pc3, residual=cl(x), relu=True, stage=stage)
+    assert torch.equal(out, ref)                                  # same partial-sum order as the two launches
+    if c2:
+        assert (y1n.cpu() - wantn).abs().max().item() <= TOL
+        assert (y1n - refn).abs().max().item() <= 1e-5
+    else:
+        assert y1n is None
+
+
+# partial bricks, grids smaller than a brick, both bricks forced; no bias; output into a channel range of a wider tensor
+@pytest.mark.parametrize("brick", [0, 1])
+@pytest.mark.parametrize("dims", [(13, 9, 11), (5, 3, 2), (7, 6, 19)])
+def test_ragged_grids_both_bricks(ops, brick, dims):
+    x, y1, pc2, pc3, stage, want, wantn = _case(ops, 32, 128, 32, dims, 7 * brick + dims[2], bias=(dims[0] != 5))
+    wide = torch.full((1, 192, *dims), -7.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    out, y1n = ops.bottleneck16(cl(y1), pc2, pc3, cl(x), out=wide, out_coff=64, stage=stage, brick=brick)
+    assert out is wide
+    assert (wide[:, 64:].cpu() - want).abs().max().item() <= TOL
+    assert float(wide[:, :64].min()) == -7.0 and float(wide[:, :64].max()) == -7.0
+    assert (y1n.cpu() - wantn).abs().max().item() <= TOL
+
+
+def test_unsupported_shapes_fall_back_loudly(ops):
+    x, y1, pc2, pc3, stage, want, _ = _case(ops, 64, 128, 0, (24, 12, 24), 5)     # 64 planes: the two-launch path is faster
+    with pytest.raises(ops.Sis3dUnsupported):
+        ops.bottleneck16(cl(y1), pc2, pc3, cl(x))
+    x, y1, pc2, pc3, stage, want, _ = _case(ops, 32, 96, 0, (12, 6, 12), 6)       # no (32, 96) instantiation
+    with pytest.raises(ops.Sis3dUnsupported):
+        ops.bottleneck16(cl(y1), pc2, pc3, cl(x))
+
+
+def test_fused_sequential_uses_it_and_matches_split(ops, monkeypatch):
+    from sis3d.nets import backbones as bb
+    torch.manual_seed(3)
+    seq = bb.FusedSequential(bb.Bottleneck(128, 32), bb.Bottleneck(128, 32)).cuda().eval()
+    x = cl(torch.randn(1, 128, 24, 12, 24))
+    calls = []
+    real = ops.bottleneck16
+    monkeypatch.setattr(ops, "bottleneck16", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        fused = seq(x)
+        assert len(calls) == 2
+        monkeypatch.setattr(ops, "BNECK_SPLIT", True)
+        split = seq(x)
+    assert (fused - split).abs().max().item() <= 1e-5
