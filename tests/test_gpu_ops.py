@@ -260,6 +260,25 @@ def test_topk_desc_matches_stable_sort(ops, n, k):
     assert torch.equal(go.cpu(), wo[:kk]) and torch.equal(gs.cpu(), ws[:kk])
 
 
+# saturated scores: softmax outputs that round to exactly 1.0f (or NaN / +inf piles) overflow the rank-sort fast path; with >= k
+# candidates on the single largest key the winners are the first k of them by index (the ballot-scan path of topk.hip), with
+# fewer the exact selection runs.  Same oracle: torch's stable descending sort.
+@pytest.mark.parametrize("n,k,top,frac", [(33394, 400, 1.0, 0.5), (33394, 400, 1.0, 0.02), (33394, 400, 1.0, 0.011), (40960, 1024, 1.0, 0.9),
+                                          (33394, 400, float("inf"), 0.3), (33394, 400, float("nan"), 0.2), (4096, 400, 0.25, 1.0),
+                                          (33394, 1, 1.0, 0.5)])
+def test_topk_desc_saturated_scores(ops, n, k, top, frac):
+    g = torch.Generator().manual_seed(n + k + int(frac * 1000))
+    s = torch.rand(n, generator=g) * 0.999
+    m = torch.rand(n, generator=g) < frac
+    s[m] = top
+    if top == 1.0:
+        s[torch.rand(n, generator=g) < 0.3] = 0.99999994                 # a second pile one ulp below
+    ws, wo = torch.sort(s, descending=True, stable=True)
+    gs, go = ops.topk_desc(s.cuda(), k)
+    assert torch.equal(go.cpu(), wo[:k])
+    assert torch.equal(gs.cpu().view(torch.int32), ws[:k].view(torch.int32))     # bit compare (NaN == NaN)
+
+
 # ------------------------------------------------------------------------- record packing
 @pytest.mark.parametrize("num", [0, 1, 137, 200])
 def test_pack_records(ops, num):
