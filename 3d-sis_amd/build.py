@@ -29,18 +29,29 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma16.h"), os.path.join(ROOT, "include", "sis3d.h")]
-    objs = []
-    for name in EXACT + FAST:
+    objs, jobs = [], []
+    # slowest translation units first so the pool drains evenly
+    for name in FAST + EXACT:
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
             continue
         obj = os.path.join(OBJ, name.replace(".hip", ".o"))
         if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
-            cmd = base + (["-ffp-contract=off"] if name in EXACT else []) + ["-c", src, "-o", obj]
+            jobs.append(base + (["-ffp-contract=off"] if name in EXACT else []) + ["-c", src, "-o", obj])
+        objs.append(obj)
+    width = max(1, min(len(jobs), int(os.environ.get("SIS3D_BUILD_JOBS", os.cpu_count() or 1))))
+    running = []
+    while jobs or running:
+        while jobs and len(running) < width:
+            cmd = jobs.pop(0)
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-        objs.append(obj)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, proc = running.pop(0)
+        if proc.wait() != 0:
+            for _, other in running:
+                other.kill()
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or any(_newer(o, OUT) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:
