@@ -18,6 +18,7 @@
 // matrix is staged in LDS when it fits.  Measured n = 400: 57 us -> see profiles/.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(const float *
 //  * the matrix is staged into LDS when it fits (n <= ~1400), else read from L2; the candidates' level / score are staged
 //    up front so the select variant never waits on a dependent global load inside the serial part.
 constexpr size_t SWEEP_LDS_MASK_MAX = 120 * 1024;
+std::atomic<int> g_nms_path{0};          // sis3d_nms_set_path: 0 = by size, 1 = sweep, 2 = resolve
 
 template <bool SELECT>
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, int n, int max_keep,
@@ -203,6 +205,117 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restr
     }
 }
 
+
+// ---------------------------------------------------------------- large n: candidate lists + parallel resolve
+// The single-workgroup sweep above reads every kept row's words one 64-box block after the other: at n = 6400 (a whole
+// scene's records, BASELINE config 5) that is 100 dependent rounds over a 5 MB matrix -- ~0.4 ms for a decision that is
+// almost empty (per-chunk NMS already ran; only boxes at chunk borders still meet).  Greedy NMS is a fixed point of
+//     keep[i] = no j < i with IoU(j, i) > thresh is kept,
+// so it is resolved here in parallel sweeps over a SPARSE suppressor table: box i is decided "suppressed" as soon as one of
+// its suppressor candidates is known to be kept, "kept" as soon as all of them are known to be suppressed; boxes without
+// candidates are kept in the first sweep.  The number of sweeps is the longest suppression chain (a handful for a scene),
+// and the result is the sequential algorithm's keep list bit for bit (same IoU arithmetic, same strict comparison).
+//   W[i][jb]  word of suppressor candidates of box i inside block jb (bit j: box 64 jb + j, j < i, IoU > thresh); written
+//             only where non-zero
+//   nz[i][.]  bitmap of the non-zero words of row i (zeroed by the launcher)
+template <bool INDIRECT>
+__global__ __launch_bounds__(64 * MASK_WAVES) void nms_cand_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order,
+                                                                   int n, float thresh, uint64_t *__restrict__ W,
+                                                                   unsigned long long *__restrict__ nz, int nzw)
+{
+    const int jb = blockIdx.x, ib = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (jb > ib) return;
+    const int col_blocks = (n + 63) / 64;
+    constexpr int R = 64 / MASK_WAVES;
+    __shared__ Box rows[64];
+    const int ii = 64 * ib + lane;
+    if (wave == 0 && ii < n) rows[lane] = load_box<INDIRECT>(boxes, order, ii);
+    __syncthreads();
+    const int ji = 64 * jb + lane;
+    Box col = {0, 0, 0, 0, 0, 0, 1, 0};
+    if (ji < n) col = load_box<INDIRECT>(boxes, order, ji);
+    uint64_t mine = 0;
+    const int nrows = min(R * (wave + 1), n - 64 * ib);
+#pragma unroll 4
+    for (int r = R * wave; r < nrows; ++r) {
+        const Box a = rows[r];
+        const float v = iou3d(col, a);                 // suppressor first, as the sweep path (the value is symmetric anyway)
+        const bool sup = ji < n && ji < 64 * ib + r && !(v <= thresh);
+        const uint64_t word = __ballot(sup);
+        if (lane == r) mine = word;
+    }
+    if (mine != 0 && ii < n) {
+        W[(size_t)ii * col_blocks + jb] = mine;
+        atomicOr(&nz[(size_t)ii * nzw + (jb >> 6)], 1ULL << (jb & 63));
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_resolve_kernel(const uint64_t *__restrict__ W, const unsigned long long *__restrict__ nz,
+                                                           int nzw, int n, int max_keep, int64_t *__restrict__ keep,
+                                                           int32_t *__restrict__ num_keep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int cb = (n + 63) / 64;
+    unsigned long long *Kc = (unsigned long long *)smem, *Dc = Kc + cb, *Kn = Dc + cb, *Dn = Kn + cb;   // snapshot / next
+    int *pref = (int *)(Dn + cb);
+    __shared__ int s_changed;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < cb; c += blockDim.x) { Kc[c] = Dc[c] = Kn[c] = Dn[c] = 0; }
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep < n; ++sweep) {
+        bool changed = false;
+        for (int i = tid; i < n; i += blockDim.x) {
+            const unsigned long long bit = 1ULL << (i & 63);
+            if (Dc[i >> 6] & bit) continue;
+            bool any_kept = false, all_dec = true;
+            for (int q = 0; q < nzw; ++q) {
+                unsigned long long bits = nz[(size_t)i * nzw + q];
+                while (bits) {
+                    const int jb = 64 * q + __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const uint64_t w = W[(size_t)i * cb + jb];
+                    any_kept |= (w & Kc[jb]) != 0;
+                    all_dec &= (w & ~Dc[jb]) == 0;
+                }
+            }
+            if (any_kept) {
+                atomicOr(&Dn[i >> 6], bit);
+                changed = true;
+            } else if (all_dec) {
+                atomicOr(&Kn[i >> 6], bit);
+                atomicOr(&Dn[i >> 6], bit);
+                changed = true;
+            }
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        const int any = s_changed;
+        for (int c = tid; c < cb; c += blockDim.x) { Kc[c] = Kn[c]; Dc[c] = Dn[c]; }
+        __syncthreads();
+        if (!any) break;                               // every box is decided (the first undecided box always resolves)
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+    }
+    // keep list = set bits of K in ascending order, cut at max_keep
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < cb; ++c) { pref[c] = run; run += __popcll(Kc[c]); }
+        const int limit = max_keep > 0 ? max_keep : n;
+        num_keep[0] = run < limit ? run : limit;
+    }
+    __syncthreads();
+    const int limit = max_keep > 0 ? max_keep : n;
+    for (int c = tid; c < cb; c += blockDim.x) {
+        unsigned long long bits = Kc[c];
+        int rank = pref[c];
+        while (bits && rank < limit) {
+            keep[rank++] = 64 * c + __builtin_ctzll(bits);
+            bits &= bits - 1;
+        }
+    }
+}
+
 template <bool INDIRECT, bool SELECT>
 int launch_nms(const float *boxes, const int64_t *order, const float *level_all, const float *scores_sorted, int n,
                float thresh, int max_keep, int64_t *keep, int32_t *num_keep, float *rois, float *roi_scores,
@@ -212,8 +325,25 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     if (SELECT && max_keep <= 0) return SIS3D_EINVAL;
     const int cb = (n + 63) / 64;
     const size_t mask_bytes = (size_t)n * cb * 8;
-    if (n > 0 && (ws_bytes < mask_bytes || !ws)) return SIS3D_EWORKSPACE;
+    const int nzw = (cb + 63) / 64;
+    const size_t nz_bytes = (size_t)n * nzw * 8;
+    if (n > 0 && (ws_bytes < mask_bytes + nz_bytes || !ws)) return SIS3D_EWORKSPACE;
     uint64_t *mask = (uint64_t *)ws;
+    const int path = g_nms_path.load(std::memory_order_relaxed);
+    if (!SELECT && n > 0 && (path == 2 || (path == 0 && mask_bytes > SWEEP_LDS_MASK_MAX))) {
+        // the matrix does not fit the sweep workgroup's LDS: sparse candidate table + parallel resolve
+        const size_t lds = (size_t)cb * (4 * 8 + 4) + 16;
+        if (lds > 160 * 1024 - 64) return SIS3D_EUNSUPPORTED;
+        unsigned long long *nz = (unsigned long long *)((char *)ws + mask_bytes);
+        if (hipMemsetAsync(nz, 0, nz_bytes, st) != hipSuccess) return SIS3D_ELAUNCH;
+        hipLaunchKernelGGL((nms_cand_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, thresh, mask, nz, nzw);
+        int rc = sis3d_check_launch();
+        if (rc) return rc;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), lds, st, mask, nz, nzw, n, max_keep, keep, num_keep);
+        return sis3d_check_launch();
+    }
     if (n > 0) {
         // the bit matrix on as many CUs as it has 64x64 tiles (a single workgroup is VALU-bound: 28 us for n = 400)
         hipLaunchKernelGGL((nms_mask_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, thresh, mask);
@@ -243,7 +373,16 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
 
 extern "C" size_t sis3d_nms_workspace_bytes(int n)
 {
-    return n > 0 ? (size_t)n * ((n + 63) / 64) * 8 : 0;
+    if (n <= 0) return 0;
+    const size_t cb = (size_t)(n + 63) / 64;
+    return (size_t)n * cb * 8 + (size_t)n * ((cb + 63) / 64) * 8;      // bit matrix + non-zero-word bitmap (resolve path)
+}
+
+extern "C" int sis3d_nms_set_path(int path)
+{
+    if (path < 0 || path > 2) return SIS3D_EINVAL;
+    g_nms_path.store(path, std::memory_order_relaxed);
+    return SIS3D_OK;
 }
 
 extern "C" int sis3d_nms(const float *boxes, int n, float thresh, int max_keep, int64_t *keep, int32_t *num_keep, void *ws,

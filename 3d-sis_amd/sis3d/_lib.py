@@ -13,6 +13,7 @@ SIGNATURES = {
     "sis3d_strerror": (ctypes.c_char_p, [c_int]),
     "sis3d_last_hip_error": (ctypes.c_char_p, []),
     "sis3d_nms_workspace_bytes": (c_sz, [c_int]),
+    "sis3d_nms_set_path": (c_int, [c_int]),
     "sis3d_nms": (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_nms_mask": (c_int, [c_vp, c_int, c_f32, c_vp, c_vp]),
     "sis3d_nms_select": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

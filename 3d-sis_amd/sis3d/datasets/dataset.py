@@ -5,9 +5,10 @@ of a sample: same constructor, `__len__`, `__getitem__` keys ('id','data','gt_bo
 * parsing is zero-copy (datasets/scene_file.py) and, with `device_encode=True`, the 2-channel TSDF input is built on
   the GPU straight from the file's sdf block (`ops.tsdf_encode`) in the conv stack's channels-last layout -- 'data' is
   then a CUDA tensor of logical shape (2,X,Y',Z); with `device_encode=False` it is the reference's numpy array;
-* colour frames: the container's world2chunk and frame ids are returned ('world2grid', 'frameids'); decoding the
-  per-frame PNG / pose files (dataset.py:142-152, scipy.misc + torchvision) is left to the caller -- out of scope of
-  this build (data loading), and ENet features are supplied as tensors (USE_IMAGES_GT).
+* colour frames (USE_IMAGES, dataset.py:136-190): depth PNG, colour / label image and pose file of every frame the
+  container (chunk mode) or the scene's `depth/` directory (scene / benchmark mode) names are decoded with Pillow -- the
+  library behind the reference's `scipy.misc.imread` and `torchvision.transforms` -- and resized / cropped / normalised by
+  the same rules (`frames.py`); `collate_fn` stacks them into blobs['nearest_images'] exactly as dataloader.py:19-40.
 """
 import csv
 import math
@@ -16,6 +17,7 @@ import os
 import numpy as np
 import torch
 
+from . import frames
 from .scene_file import SceneFile
 
 
@@ -98,23 +100,84 @@ class Dataset(torch.utils.data.Dataset):
             gt_box = gt_box[keep]
             if cfg.USE_MASK:
                 gt_mask = [gt_mask[i] for i in keep]
-        nearest_images = {}
+        nearest_images, image_files = {}, []
         if cfg.USE_IMAGES:
-            nearest_images = {"world2grid": np.linalg.inv(np.transpose(sf.world2chunk).astype(np.float32)),
-                              "frameids": [int(v) for v in sf.frame_ids], "depths": [], "images": [], "poses": []}
+            nearest_images, image_files = self.load_frames(idx, sf)
         boxes, masks = [], []
         for i, b in enumerate(gt_box):
             if b[1] <= max_height and b[4] <= max_height:
                 boxes.append(b)
                 masks.append(gt_mask[i])
         return {"id": self.scenes[idx], "data": data, "gt_box": np.array(boxes), "gt_mask": masks,
-                "nearest_images": nearest_images, "image_files": []}
+                "nearest_images": nearest_images, "image_files": image_files}
+
+    def scene_name(self, idx):
+        """dataset.py:146-151: frame directory of a sample, from the layout BASE_IMAGE_PATH ends with"""
+        base = self.cfg.BASE_IMAGE_PATH.rstrip("/")
+        name = os.path.basename(self.scenes[idx])
+        if base.endswith("augmented"):
+            return name.rsplit("_", 1)[0] if self.mode == "chunk" else name.split(".")[0]
+        if base.endswith("square"):
+            return name.split("__")[0]
+        raise NotImplementedError("BASE_IMAGE_PATH must end with 'augmented' or 'square' (dataset.py:146-151)")
+
+    def load_frames(self, idx, sf):
+        """dataset.py:136-190 -> (nearest_images dict, image_files): chunk mode reads the container's frame ids and its
+        world2chunk; scene / benchmark mode takes every file of <scene>/depth/ (os.listdir order, as the reference) and
+        the scene's world2grid.txt with the (10,16,10) padding subtracted."""
+        cfg = self.cfg
+        root = os.path.join(cfg.BASE_IMAGE_PATH, self.scene_name(idx))
+        if self.mode == "chunk":
+            world2grid = np.linalg.inv(np.transpose(sf.world2chunk).astype(np.float32))
+            ids = [int(v) for v in sf.frame_ids]
+        else:
+            world2grid = frames.load_pose(os.path.join(root, "world2grid.txt"))
+            world2grid[0][3] -= 10
+            world2grid[1][3] -= 16
+            world2grid[2][3] -= 10
+            ids = [f.split(".")[0] for f in os.listdir(os.path.join(root, "depth"))]
+        relabel = bool(cfg.USE_IMAGES_GT and cfg.LABEL_MAP != "")
+        depths, images, poses, files = [], [], [], []
+        for fid in ids:
+            image_file = os.path.join(root, cfg.IMAGE_TYPE, str(fid) + cfg.IMAGE_EXT)
+            poses.append(frames.load_pose(os.path.join(root, "pose", str(fid) + ".txt")))
+            depths.append(frames.load_depth(os.path.join(root, "depth", str(fid) + ".png"), cfg.DEPTH_SHAPE))
+            im = frames.load_image(image_file, cfg.IMAGE_SHAPE, cfg.COLOR_MEAN, cfg.COLOR_STD)
+            if relabel:
+                im = frames.relabel(im, self.mapping, self.weights)
+            images.append(im)
+            files.append(image_file)
+        return {"depths": depths, "images": images, "poses": poses, "world2grid": world2grid, "frameids": ids}, files
 
 
-def collate_fn(batch):
-    """dataloader.py:8-49, geometry side (batch of dicts -> blobs for Network.forward)"""
+def collate_images(batch, cfg):
+    """dataloader.py:16-40: per sample the (V,...) stacks of images / depths / poses and world2grid expanded to V views;
+    in train mode the view list is cut to NUM_IMAGES (or a random count in [1, NUM_IMAGES] with RANDOM_NUM_IMAGES)"""
+    depths, poses, world2grid = [], [], []
+    for b in batch:
+        x = b["nearest_images"]
+        n = len(x["depths"])
+        cap = cfg.NUM_IMAGES if not cfg.get("RANDOM_NUM_IMAGES", False) else np.random.randint(low=1, high=cfg.NUM_IMAGES + 1)
+        if cap < n and cfg.get("MODE", "benchmark") == "train":
+            n = cap
+            x["images"], x["depths"], x["poses"] = x["images"][:n], x["depths"][:n], x["poses"][:n]
+        depths.append(torch.from_numpy(np.array(x["depths"])))
+        poses.append(torch.from_numpy(np.array(x["poses"])))
+        world2grid.append(torch.from_numpy(x["world2grid"]).expand(n, 4, 4))
+    images = [torch.from_numpy(np.stack([np.asarray(i) for i in b["nearest_images"]["images"]], 0).astype(np.float32)) for b in batch]
+    return {"images": images, "depths": depths, "poses": poses, "world2grid": world2grid}
+
+
+def collate_fn(batch, cfg=None):
+    """dataloader.py:8-49 (batch of dicts -> blobs for Network.forward).  The reference reads its module-global cfg; here
+    the colour side is collated when the samples carry frames (or `cfg.USE_IMAGES` is given)."""
     def tens(x):
         return x if torch.is_tensor(x) else torch.from_numpy(x)
+    with_images = bool(batch[0]["nearest_images"]) and "depths" in batch[0]["nearest_images"]
+    if cfg is None:
+        from ..config import cfg as cfg_default
+        cfg = cfg_default
+    nearest = collate_images(batch, cfg) if with_images else {}
     if len(batch) == 1 and torch.is_tensor(batch[0]["data"]):
         data = batch[0]["data"].unsqueeze(0)            # device-encoded sample: stays on the GPU, planar like the host path
     else:
@@ -123,9 +186,10 @@ def collate_fn(batch):
             "data": data,
             "gt_box": [torch.from_numpy(x["gt_box"]) for x in batch if x["gt_box"].shape[0] != 0],
             "gt_mask": [[torch.from_numpy(y) for y in x["gt_mask"]] for x in batch if len(x["gt_mask"]) != 0],
-            "nearest_images": {}, "image_files": batch[0]["image_files"]}
+            "nearest_images": nearest, "image_files": batch[0]["image_files"]}
 
 
 def get_dataloader(dataset, batch_size=1, shuffle=False, num_workers=0):
-    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, collate_fn=collate_fn, shuffle=shuffle,
-                                       num_workers=num_workers)
+    import functools
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, collate_fn=functools.partial(collate_fn, cfg=dataset.cfg),
+                                       shuffle=shuffle, num_workers=num_workers)

@@ -47,6 +47,11 @@ def nms_raw(dets, thresh, max_keep=0):
     return keep, num
 
 
+def nms_set_path(path):
+    """0 = choose by size, 1 = one-workgroup sweep, 2 = sparse suppressor table + parallel resolve (same keep list)"""
+    check(lib().sis3d_nms_set_path(int(path)), "sis3d_nms_set_path")
+
+
 def nms(dets, thresh, max_keep=0):
     """lib/layer_utils/nms_wrapper.py:7-16 semantics: LongTensor (K,) of kept indices on dets' device.
     The result length is data dependent -> one 4-byte D2H read (the reference copies the whole

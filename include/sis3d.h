@@ -49,8 +49,14 @@ const char *sis3d_last_hip_error(void);
  * indices (entries >= *num_keep untouched), num_keep[0] = count.  The greedy
  * sweep runs ON THE DEVICE (the reference copies the mask to the host).
  * max_keep > 0 stops after that many survivors (== keep[:max_keep]).
- * workspace: sis3d_nms_workspace_bytes(n) bytes (bit matrix), any content. */
+ * workspace: sis3d_nms_workspace_bytes(n) bytes (bit matrix + the bitmap of its non-zero
+ * words), any content.  n whose matrix fits the sweep workgroup's LDS (n <~ 990) take the
+ * one-workgroup sweep; larger n (a whole scene's records) take a sparse suppressor table +
+ * parallel fixed-point resolve -- same keep list. */
 size_t sis3d_nms_workspace_bytes(int n);
+/* which of the two algorithms sis3d_nms uses: 0 = by size (default), 1 = one-workgroup sweep, 2 = parallel resolve
+ * (tuning / parity hook; both give the same keep list) */
+int sis3d_nms_set_path(int path);
 int sis3d_nms(const float *boxes, int n, float thresh, int max_keep, int64_t *keep, int32_t *num_keep,
               void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
 /* the IoU bit matrix alone: mask [n][ceil(n/64)] u64, bit j of word cb set iff

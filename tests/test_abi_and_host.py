@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert l.sis3d_strerror(-1).decode().startswith("invalid")
     # size helpers are host-only and safe without a GPU
     assert l.sis3d_conv_packed_floats(256, 128, 3) == 8 * 27 * 16 * 256
-    assert l.sis3d_nms_workspace_bytes(400) == 400 * 7 * 8 and l.sis3d_nms_workspace_bytes(6400) == 6400 * 100 * 8
+    assert l.sis3d_nms_workspace_bytes(400) == 400 * 7 * 8 + 400 * 8 and l.sis3d_nms_workspace_bytes(6400) == 6400 * 100 * 8 + 6400 * 2 * 8
 
 
 def test_ops_fail_loudly_on_cpu_tensors():
