@@ -73,6 +73,18 @@ def scannet_benchmark_cfg():
     c.MAX_IMAGE = 400
     c.TEST_SAVE_DIR = ""
     c.TRUNCATED = 3.0
+    # data side (lib/datasets): benchmark.yml:48-51,97-107, config.py:136-141,190
+    c.KEEP_THRESH = 1.0
+    c.LABEL_MAP = ""              # benchmark.yml points at datagen/fileLists/nyu40labels_scannet.csv (a reference-tree path)
+    c.FLIP_TSDF = False
+    c.LOG_TSDF = False
+    c.MODE = "benchmark"
+    c.RANDOM_NUM_IMAGES = False
+    c.BASE_IMAGE_PATH = "/mnt/local_datasets/ScanNet/frames_square"
+    c.IMAGE_TYPE = "color"
+    c.IMAGE_EXT = ".jpg"
+    c.COLOR_MEAN = [0.496342, 0.466664, 0.440796]
+    c.COLOR_STD = [0.277856, 0.28623, 0.291129]
     return c
 
 

@@ -346,6 +346,108 @@ def dataset_case(ns_unused):
     np.savez_compressed(os.path.join(OUT, "dataset_cases.npz"), **out)
 
 
+FRAMES_SCENE = "scene0000_00"
+
+
+def write_frames_fixture():
+    """tests/golden/frames_square/scene0000_00/{depth,color,label,pose}/<id>.* + world2grid.txt + the container
+    tests/golden/scene0000_00__0.chunk naming the three frames.  Small synthetic images (seeded), encoded with Pillow."""
+    from PIL import Image
+    from sis3d.datasets import scene_file
+    root = os.path.join(OUT, "frames_square", FRAMES_SCENE)
+    for d in ("depth", "color", "label", "pose"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    g = np.random.default_rng(11)
+    ids = [17, 420, 9000]
+    for k, fid in enumerate(ids):
+        yy, xx = np.mgrid[0:60, 0:80]
+        depth = (900 + 13 * xx + 7 * yy + 400 * k + g.integers(0, 50, (60, 80))).astype(np.uint16)     # millimetres
+        depth[g.random((60, 80)) < 0.05] = 0
+        Image.fromarray(depth).save(os.path.join(root, "depth", "%d.png" % fid))
+        col = np.stack([(3 * xx + 40 * k) % 256, (5 * yy + 2 * xx) % 256, (xx * yy // 7 + 90 * k) % 256], -1)
+        col = np.kron(col, np.ones((2, 2, 1))).astype(np.uint8)                                           # 120 x 160 blocks
+        col = (col + g.integers(0, 12, col.shape)).clip(0, 255).astype(np.uint8)
+        Image.fromarray(col).save(os.path.join(root, "color", "%d.jpg" % fid), quality=92)
+        lab = g.integers(0, 45, (60, 80)).astype(np.uint8)                                               # nyu40 ids incl. > 40
+        Image.fromarray(lab).save(os.path.join(root, "label", "%d.png" % fid))
+        a = 0.3 * (k + 1)
+        pose = np.array([[np.cos(a), 0, np.sin(a), 1.5 + k], [0, 1, 0, 0.25 * k], [-np.sin(a), 0, np.cos(a), -2.0], [0, 0, 0, 1]])
+        with open(os.path.join(root, "pose", "%d.txt" % fid), "w") as f:
+            for r in pose:
+                f.write(" ".join("%.6f" % v for v in r) + "\n")
+    w2g = np.array([[21.3333, 0, 0, 14.0], [0, 21.3333, 0, 19.5], [0, 0, 21.3333, 30.25], [0, 0, 0, 1]])
+    with open(os.path.join(root, "world2grid.txt"), "w") as f:
+        for r in w2g:
+            f.write(" ".join("%.6f" % v for v in r) + "\n")
+    dims = (12, 20, 10)
+    sdf = (g.standard_normal(dims) * 3).astype(np.float32)
+    boxes = np.array([[1.5, 2.2, 0.7, 9.1, 15.9, 7.5], [2.0, 2.0, 2.0, 5.0, 5.0, 5.0]], dtype=np.float32)
+    labels = [3, 38]
+    masks = [(lab, g.integers(0, 2, tuple(int(np.ceil(b[3 + k]) - np.floor(b[k])) for k in range(3))).astype(np.uint16))
+             for b, lab in zip(boxes, labels)]
+    w2c = np.eye(4, dtype=np.float32) * 21.333
+    w2c[:3, 3] = [3.0, -2.0, 8.5]
+    w2c[3, 3] = 1
+    path = os.path.join(OUT, FRAMES_SCENE + "__0.chunk")
+    scene_file.write_scene_file(path, sdf, boxes, labels, masks, [1.0, 1.0], w2c, ids)
+    with open(os.path.join(OUT, "frames_filelist.txt"), "w") as f:
+        f.write(FRAMES_SCENE + "__0.chunk\n")
+    return path
+
+
+def frames_case(ns_unused):
+    """The reference's Dataset.__getitem__ WITH frames (lib/datasets/dataset.py:136-190,230-267) and its collate_fn
+    (dataloader.py:8-49) on the fixture above: chunk mode with colour JPEGs at the benchmark shapes (328x256 / 41x32) and at
+    a second, non-trivially cropped shape; scene mode (depth-directory listing, world2grid.txt minus padding) with label
+    PNGs relabelled through the label map (USE_IMAGES_GT).  scipy.misc / torchvision are the Pillow restatements of
+    ref_harness.install_image_stubs."""
+    write_frames_fixture()
+    ns = rh.install(with_trainval=True)
+    rh.install_image_stubs()
+    from lib.datasets.dataset import Dataset as RefDataset
+    from lib.datasets.dataloader import collate_fn as ref_collate
+    cfg = ns.cfg
+    keys = ("LABEL_MAP", "USE_IMAGES", "USE_IMAGES_GT", "USE_MASK", "KEEP_THRESH", "BASE_IMAGE_PATH", "IMAGE_TYPE", "IMAGE_EXT",
+            "IMAGE_SHAPE", "DEPTH_SHAPE", "COLOR_MEAN", "COLOR_STD", "MODE", "NUM_IMAGES")
+    saved = {k: cfg[k] for k in keys}
+    out = {}
+    old = os.getcwd()
+    os.chdir(OUT)
+    try:
+        cfg.LABEL_MAP = os.path.join(OUT, "synthetic_labels.csv")
+        cfg.BASE_IMAGE_PATH = os.path.join(OUT, "frames_square")
+        cfg.USE_IMAGES, cfg.USE_MASK, cfg.KEEP_THRESH, cfg.MODE, cfg.NUM_IMAGES = True, True, 0.0, "benchmark", 5
+        for tag, mode, itype, ext, ishape, dshape, gt in (
+                ("chunk_color", "chunk", "color", ".jpg", [328, 256], [41, 32], False),
+                ("chunk_crop", "chunk", "color", ".jpg", [100, 90], [30, 30], False),
+                ("scene_label", "scene", "label", ".png", [41, 32], [41, 32], True)):
+            cfg.IMAGE_TYPE, cfg.IMAGE_EXT, cfg.IMAGE_SHAPE, cfg.DEPTH_SHAPE, cfg.USE_IMAGES_GT = itype, ext, ishape, dshape, gt
+            r = RefDataset("frames_filelist.txt", mode)[0]
+            ni = r["nearest_images"]
+            blobs = ref_collate([r])
+            fids = [int(v) for v in ni["frameids"]]
+            out[tag + "_frameids"] = np.array(fids)
+            out[tag + "_world2grid"] = np.asarray(ni["world2grid"])
+            out[tag + "_poses"] = np.stack(ni["poses"])
+            out[tag + "_depths"] = np.stack(ni["depths"])
+            imgs = np.stack([np.asarray(i) for i in ni["images"]]).astype(np.float32)
+            if imgs.size > 200000:
+                out[tag + "_images_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(imgs).tobytes()).digest(), dtype=np.uint8)
+                out[tag + "_images_sub"] = imgs[:, :, ::16, ::16]
+            else:
+                out[tag + "_images"] = imgs
+            out[tag + "_gt_box"] = r["gt_box"]
+            out[tag + "_image_files"] = np.array([os.path.relpath(p, OUT) for p in r["image_files"]])
+            out[tag + "_blob_world2grid"] = blobs["nearest_images"]["world2grid"][0].numpy()
+            out[tag + "_blob_images_shape"] = np.array(blobs["nearest_images"]["images"][0].shape)
+            print("frames", tag, fids, imgs.shape, imgs.dtype, ni["depths"][0].shape, ni["depths"][0].dtype)
+    finally:
+        os.chdir(old)
+        for k, v in saved.items():
+            cfg[k] = v
+    np.savez_compressed(os.path.join(OUT, "dataset_frames_cases.npz"), **out)
+
+
 def suncg_case():
     """second model family (SUNCG_Backbone, experiments/cfgs/SUNCG/rpn_class_mask_5.yml: colour + geometry, 3 / 6 anchors,
     its own label map).  Run in a SUBPROCESS: the reference's cfg is a process-wide singleton."""
@@ -366,6 +468,9 @@ def main():
     if "--mask-images" in sys.argv:              # round 2: the mask head's colour variants
         e2e(ns, "e2e_mask_use_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="use")
         e2e(ns, "e2e_mask_only_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="only")
+        return
+    if "--frames" in sys.argv:                   # round 2: per-frame image / depth / pose loading of the Dataset
+        frames_case(ns)
         return
     if "--enet" in sys.argv:                     # only the round-2 additions (2D encoder + RGB end-to-end)
         enet_case(ns)

@@ -207,6 +207,57 @@ def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=Fal
     return ns
 
 
+def install_image_stubs():
+    """Give the reference's frame loaders (lib/datasets/dataset.py:237-267) the three third-party calls they make, restated
+    over Pillow -- the library both absent packages delegate to.  Pinned versions (requirements.txt era): scipy 1.1
+    `scipy.misc.imread` (scipy/misc/pilutil.py: Image.open + fromimage: palette -> RGB(A), '1' -> 'L', else numpy.array)
+    and torchvision 0.2.1 transforms (functional.py: resize -> img.resize(size[::-1], interpolation); center_crop ->
+    i = int(round((h - th) / 2.)), j = int(round((w - tw) / 2.)), img.crop((j, i, j + tw, i + th));
+    normalize -> for t, m, s in zip(tensor, mean, std): t.sub_(m).div_(s)).  Test infrastructure."""
+    import numpy as np
+    from PIL import Image
+    import scipy
+
+    def imread(name, flatten=False, mode=None):
+        im = Image.open(name)
+        if im.mode == "P":
+            im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+        elif im.mode == "1":
+            im = im.convert("L")
+        return np.array(im)
+
+    class Resize(object):
+        def __init__(self, size, interpolation=Image.BILINEAR):
+            self.size, self.interpolation = size, interpolation
+
+        def __call__(self, img):
+            return img.resize(tuple(self.size[::-1]), self.interpolation)
+
+    class CenterCrop(object):
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, img):
+            w, h = img.size
+            th, tw = self.size
+            i = int(round((h - th) / 2.))
+            j = int(round((w - tw) / 2.))
+            return img.crop((j, i, j + tw, i + th))
+
+    class Normalize(object):
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, tensor):
+            for t, m, sd in zip(tensor, self.mean, self.std):
+                t.sub_(m).div_(sd)
+            return tensor
+
+    scipy.misc.imread = imread
+    tv = sys.modules["torchvision.transforms"]
+    tv.Resize, tv.CenterCrop, tv.Normalize = Resize, CenterCrop, Normalize
+
+
 def make_blobs(data, images=None, proj3d=None, proj2d=None, scene_id="syn0"):
     blobs = {"data": data, "id": [scene_id], "gt_box": [torch.zeros(0, 7)], "gt_mask": [[]]}
     if images is not None:
