@@ -218,22 +218,36 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restr
 //   W[i][jb]  word of suppressor candidates of box i inside block jb (bit j: box 64 jb + j, j < i, IoU > thresh); written
 //             only where non-zero
 //   nz[i][.]  bitmap of the non-zero words of row i (zeroed by the launcher)
+//   n_dev     when given, the box count is read on the device (<= n_cap, which fixes the table strides): the scene merge
+//             sorts and suppresses in one stream-ordered sequence without a host readback in between
 template <bool INDIRECT>
 __global__ __launch_bounds__(64 * MASK_WAVES) void nms_cand_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ order,
-                                                                   int n, float thresh, uint64_t *__restrict__ W,
+                                                                   int n_cap, const int32_t *__restrict__ n_dev, int bstride,
+                                                                   float thresh, uint64_t *__restrict__ W,
                                                                    unsigned long long *__restrict__ nz, int nzw)
 {
     const int jb = blockIdx.x, ib = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (jb > ib) return;
-    const int col_blocks = (n + 63) / 64;
+    const int n = n_dev ? min(n_dev[0], n_cap) : n_cap;
+    if (64 * ib >= n) return;
+    const int col_blocks = (n_cap + 63) / 64;
     constexpr int R = 64 / MASK_WAVES;
     __shared__ Box rows[64];
     const int ii = 64 * ib + lane;
-    if (wave == 0 && ii < n) rows[lane] = load_box<INDIRECT>(boxes, order, ii);
+    auto box_at = [&](int i) {
+        if (bstride == 6) return load_box<INDIRECT>(boxes, order, i);
+        const float *p = boxes + (size_t)bstride * i;
+        Box b;
+        b.x1 = p[0]; b.y1 = p[1]; b.z1 = p[2]; b.x2 = p[3]; b.y2 = p[4]; b.z2 = p[5];
+        b.area = (b.x2 - b.x1 + 1.0f) * (b.y2 - b.y1 + 1.0f) * (b.z2 - b.z1 + 1.0f);
+        b.pad = 0.0f;
+        return b;
+    };
+    if (wave == 0 && ii < n) rows[lane] = box_at(ii);
     __syncthreads();
     const int ji = 64 * jb + lane;
     Box col = {0, 0, 0, 0, 0, 0, 1, 0};
-    if (ji < n) col = load_box<INDIRECT>(boxes, order, ji);
+    if (ji < n) col = box_at(ji);
     uint64_t mine = 0;
     const int nrows = min(R * (wave + 1), n - 64 * ib);
 #pragma unroll 4
@@ -251,11 +265,12 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_cand_kernel(const float *
 }
 
 __global__ __launch_bounds__(1024) void nms_resolve_kernel(const uint64_t *__restrict__ W, const unsigned long long *__restrict__ nz,
-                                                           int nzw, int n, int max_keep, int64_t *__restrict__ keep,
-                                                           int32_t *__restrict__ num_keep)
+                                                           int nzw, int n_cap, const int32_t *__restrict__ n_dev, int max_keep,
+                                                           int64_t *__restrict__ keep, int32_t *__restrict__ num_keep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int cb = (n + 63) / 64;
+    const int n = n_dev ? min(n_dev[0], n_cap) : n_cap;
+    const int cb = (n_cap + 63) / 64;                  // table stride; words past ceil(n/64) stay zero
     unsigned long long *Kc = (unsigned long long *)smem, *Dc = Kc + cb, *Kn = Dc + cb, *Dn = Kn + cb;   // snapshot / next
     int *pref = (int *)(Dn + cb);
     __shared__ int s_changed;
@@ -316,6 +331,98 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const uint64_t *__res
     }
 }
 
+
+// ---------------------------------------------------------------- whole-scene merge (BASELINE config 5)
+// One stream-ordered sequence for what parallel.merge_scene does with ~10 torch kernels and two host readbacks: the
+// gathered per-chunk record blocks [n_chunks][1 + K * width] (slot 0 = valid row count) are flattened, the valid rows
+// ordered by score with the stable descending rule (ties: chunk id, then row), the rows gathered in that order, and the
+// whole-scene NMS run on them with the row count staying on the device.
+__device__ __forceinline__ uint32_t merge_order_key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;       // NaN first, as torch's descending sort
+    if (u == 0x80000000u) u = 0;                                      // -0.0 ties with +0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Order = RANK: the composite keys (score image << 32 | ~flat index) are unique, so the sorted position of a valid row is the
+// number of keys above it.  scene_keys_kernel compacts the valid rows' keys (row r of chunk c sits at prefix[c] + r: no scan
+// over rows is needed); scene_rank_kernel: one workgroup per 64 keys, all keys staged in its LDS, sixteen waves each scan a
+// sixteenth of them with broadcast reads, then the row is gathered to its rank.  (A one-workgroup bitonic network over 8192
+// slots took 115 us; torch.sort 31 us + gather 8 us.)
+__device__ __forceinline__ int block_count(const float *blocks, int c, int bf, int k_rows)
+{
+    const int cnt = (int)rintf(blocks[(size_t)c * bf]);
+    return cnt < 0 ? 0 : (cnt > k_rows ? k_rows : cnt);
+}
+
+__global__ __launch_bounds__(256) void scene_keys_kernel(const float *__restrict__ blocks, int n_chunks, int k_rows, int width,
+                                                         int score_col, uint64_t *__restrict__ keys, int32_t *__restrict__ total_out)
+{
+    extern __shared__ int s_pref[];                                   // [n_chunks + 1]
+    const int tid = threadIdx.x, bf = 1 + k_rows * width, T = n_chunks * k_rows;
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < n_chunks; ++c) { s_pref[c] = run; run += block_count(blocks, c, bf, k_rows); }
+        s_pref[n_chunks] = run;
+        if (blockIdx.x == 0) total_out[0] = run;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + tid;
+    if (i >= T) return;
+    const int c = i / k_rows, r = i - c * k_rows;
+    if (r < s_pref[c + 1] - s_pref[c])
+        keys[s_pref[c] + r] = ((uint64_t)merge_order_key(blocks[(size_t)c * bf + 1 + (size_t)r * width + score_col]) << 32) |
+                              (0xffffffffu - (uint32_t)i);
+}
+
+__global__ __launch_bounds__(1024) void scene_rank_kernel(const float *__restrict__ blocks, const uint64_t *__restrict__ keysg,
+                                                          const int32_t *__restrict__ total_dev, int k_rows, int width,
+                                                          float *__restrict__ recs, int32_t *__restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *keys = (uint64_t *)smem;                                // [total rounded up to 256], tail = 0
+    __shared__ int s_rank[64];
+    const int total = total_dev[0];
+    if (blockIdx.x * 64 >= total) return;
+    const int tid = threadIdx.x, bf = 1 + k_rows * width, Tp = (total + 255) & ~255;
+    for (int j = 2 * tid; j < Tp; j += 2 * blockDim.x) {              // 16 B per lane, tail zeroed
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (j + 1 < total) v = *reinterpret_cast<const uint4 *>(keysg + j);
+        else if (j < total) { const uint64_t k = keysg[j]; v.x = (uint32_t)k; v.y = (uint32_t)(k >> 32); }
+        *reinterpret_cast<uint4 *>(keys + j) = v;
+    }
+    if (tid < 64) s_rank[tid] = 0;
+    __syncthreads();
+    const int e = tid & 63, part = tid >> 6;
+    const int i = blockIdx.x * 64 + e;
+    const uint64_t my = i < total ? keys[i] : 0ULL;
+    const int q = Tp / 16;                                            // a multiple of 16 keys
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + part * q);
+    int above = 0;
+    for (int j = 0; j < q / 2; j += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k4[j + u];                 // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            above += (((uint64_t)v[u].y << 32) | v[u].x) > my ? 1 : 0;
+            above += (((uint64_t)v[u].w << 32) | v[u].z) > my ? 1 : 0;
+        }
+    }
+    if (my != 0 && above) atomicAdd(&s_rank[e], above);
+    __syncthreads();
+    if (my != 0 && part < 4) {
+        const int rk = s_rank[e];
+        const int flat = (int)(0xffffffffu - (uint32_t)my);
+        const int c = flat / k_rows, r = flat - c * k_rows;
+        const float *src = blocks + (size_t)c * bf + 1 + (size_t)r * width;
+        float *dst = recs + (size_t)rk * width;
+        for (int f = part; f < width; f += 4) dst[f] = src[f];
+        if (part == 0) order[rk] = flat;
+    }
+}
+
 template <bool INDIRECT, bool SELECT>
 int launch_nms(const float *boxes, const int64_t *order, const float *level_all, const float *scores_sorted, int n,
                float thresh, int max_keep, int64_t *keep, int32_t *num_keep, float *rois, float *roi_scores,
@@ -336,12 +443,12 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
         if (lds > 160 * 1024 - 64) return SIS3D_EUNSUPPORTED;
         unsigned long long *nz = (unsigned long long *)((char *)ws + mask_bytes);
         if (hipMemsetAsync(nz, 0, nz_bytes, st) != hipSuccess) return SIS3D_ELAUNCH;
-        hipLaunchKernelGGL((nms_cand_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, thresh, mask, nz, nzw);
+        hipLaunchKernelGGL((nms_cand_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, nullptr, 6, thresh, mask, nz, nzw);
         int rc = sis3d_check_launch();
         if (rc) return rc;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), lds, st, mask, nz, nzw, n, max_keep, keep, num_keep);
+        hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), lds, st, mask, nz, nzw, n, nullptr, max_keep, keep, num_keep);
         return sis3d_check_launch();
     }
     if (n > 0) {
@@ -407,4 +514,46 @@ extern "C" int sis3d_nms_select(const float *boxes_all, const float *level_all, 
     if (!boxes_all || !level_all || !scores_sorted || !order || !rois || !roi_scores || !roi_levels) return SIS3D_EINVAL;
     return launch_nms<true, true>(boxes_all, order, level_all, scores_sorted, n, thresh, max_keep, keep, num_keep, rois,
                                   roi_scores, roi_levels, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" size_t sis3d_scene_merge_workspace_bytes(int n_chunks, int k_rows)
+{
+    const int64_t T = (int64_t)n_chunks * k_rows;
+    return (n_chunks > 0 && k_rows > 0 && T <= 0x7fffffff) ? sis3d_nms_workspace_bytes((int)T) : 0;
+}
+
+extern "C" int sis3d_scene_merge(const float *blocks, int n_chunks, int k_rows, int width, int score_col, int box_col, float thresh,
+                                 int max_keep, float *recs, int32_t *order, int64_t *keep, int32_t *counts, void *ws, size_t ws_bytes,
+                                 sis3d_stream_t stream)
+{
+    if (!blocks || !recs || !order || !keep || !counts || n_chunks <= 0 || k_rows <= 0 || width < 6) return SIS3D_EINVAL;
+    if (score_col < 0 || score_col >= width || box_col < 0 || box_col + 6 > width || max_keep < 0) return SIS3D_EINVAL;
+    const int64_t T64 = (int64_t)n_chunks * k_rows;
+    if (T64 > 8192) return SIS3D_EUNSUPPORTED;                     // the sort holds every candidate key in one workgroup's LDS
+    const int T = (int)T64;
+    const int cb = (T + 63) / 64, nzw = (cb + 63) / 64;
+    const size_t mask_bytes = (size_t)T * cb * 8, nz_bytes = (size_t)T * nzw * 8;
+    if (!ws || ws_bytes < mask_bytes + nz_bytes) return SIS3D_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    // the key list borrows the head of the bit-matrix area (>= T words): it is dead before the suppressor table is written
+    uint64_t *mask = (uint64_t *)ws;
+    hipLaunchKernelGGL(scene_keys_kernel, dim3((T + 255) / 256), dim3(256), (size_t)(n_chunks + 1) * sizeof(int), st, blocks, n_chunks,
+                       k_rows, width, score_col, mask, counts);
+    int rc = sis3d_check_launch();
+    if (rc) return rc;
+    const size_t sort_lds = (size_t)((T + 255) & ~255) * 8;
+    if (sort_lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)scene_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+    hipLaunchKernelGGL(scene_rank_kernel, dim3((T + 63) / 64), dim3(1024), sort_lds, st, blocks, mask, counts, k_rows, width, recs, order);
+    rc = sis3d_check_launch();
+    if (rc) return rc;
+    unsigned long long *nz = (unsigned long long *)((char *)ws + mask_bytes);
+    if (hipMemsetAsync(nz, 0, nz_bytes, st) != hipSuccess) return SIS3D_ELAUNCH;
+    hipLaunchKernelGGL((nms_cand_kernel<false>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, recs + box_col, nullptr, T, counts, width,
+                       thresh, mask, nz, nzw);
+    rc = sis3d_check_launch();
+    if (rc) return rc;
+    const size_t lds = (size_t)cb * (4 * 8 + 4) + 16;
+    hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), lds, st, mask, nz, nzw, T, counts, max_keep, keep, counts + 1);
+    return sis3d_check_launch();
 }

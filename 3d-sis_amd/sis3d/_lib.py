@@ -15,6 +15,8 @@ SIGNATURES = {
     "sis3d_nms_workspace_bytes": (c_sz, [c_int]),
     "sis3d_nms_set_path": (c_int, [c_int]),
     "sis3d_nms": (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sis3d_scene_merge_workspace_bytes": (c_sz, [c_int, c_int]),
+    "sis3d_scene_merge": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_nms_mask": (c_int, [c_vp, c_int, c_f32, c_vp, c_vp]),
     "sis3d_nms_select": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_roi_pool_forward": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int,

@@ -60,6 +60,36 @@ def nms(dets, thresh, max_keep=0):
     return keep[:int(num.item())].contiguous()
 
 
+def scene_merge_raw(blocks, k_rows, thresh, score_col=6, box_col=0, max_keep=0):
+    """sis3d_scene_merge on gathered record blocks (n_chunks, 1 + k_rows*W): -> (recs (T,W) padded, order int32 (T,),
+    keep int64 (T,), counts int32 [valid rows, kept]) on the device, no host sync."""
+    blocks = _dev(blocks, "blocks").contiguous()
+    n_chunks, bf = blocks.shape
+    width = (bf - 1) // int(k_rows)
+    if 1 + width * int(k_rows) != bf:
+        raise _lib.Sis3dError("blocks must be (n_chunks, 1 + k_rows*width)")
+    T = n_chunks * int(k_rows)
+    dev = blocks.device
+    recs = torch.empty(T, width, device=dev)
+    order = torch.empty(T, dtype=torch.int32, device=dev)
+    keep = torch.empty(T, dtype=torch.int64, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    wsb = lib().sis3d_scene_merge_workspace_bytes(n_chunks, int(k_rows))
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    check(lib().sis3d_scene_merge(_ptr(blocks), n_chunks, int(k_rows), width, int(score_col), int(box_col), float(thresh),
+                                  int(max_keep), _ptr(recs), _ptr(order), _ptr(keep), _ptr(counts), _ptr(ws), wsb, _stream()),
+          "sis3d_scene_merge")
+    return recs, order, keep, counts
+
+
+def scene_merge(blocks, k_rows, thresh, score_col=6, box_col=0, max_keep=0):
+    """parallel.merge_scene as one device sequence: -> (records sorted by score (N,W), keep LongTensor, chunk id of every
+    sorted record).  One 8-byte readback for the two data-dependent lengths."""
+    recs, order, keep, counts = scene_merge_raw(blocks, k_rows, thresh, score_col, box_col, max_keep)
+    total, kept = counts.tolist()
+    return recs[:total], keep[:kept], (order[:total] // int(k_rows)).long()
+
+
 def nms_mask(dets, thresh):
     dets = _dev(dets, "dets").contiguous()
     n = dets.shape[0]

@@ -69,11 +69,24 @@ def gather_blocks(local_blocks, n_chunks, k_rows, group=None, solo=False):
         dist.all_gather(parts, send, group=group)
         recv = torch.stack(parts, 0)
     # (rank r, slot i) holds chunk r + i*world: chunk c sits at flat row (c % world) * per_rank + c // world
-    idx = torch.tensor([(c % world) * per_rank + c // world for c in range(n_chunks)], device=device)
-    return recv.view(world * per_rank, bf).index_select(0, idx)
+    return recv.view(world * per_rank, bf).index_select(0, _chunk_rows(n_chunks, world, per_rank, device))
 
 
-def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_chunk_ids=False, box_cols=(0, 6)):
+_CHUNK_ROWS = {}
+
+
+def _chunk_rows(n_chunks, world, per_rank, device):
+    """row of every chunk in the gathered table, built once per (scene size, world, device): a per-scene torch.tensor(...)
+    from a Python list is a pageable H2D copy, i.e. a host stall in the middle of the merge"""
+    key = (n_chunks, world, per_rank, str(device))
+    t = _CHUNK_ROWS.get(key)
+    if t is None:
+        t = torch.tensor([(c % world) * per_rank + c // world for c in range(n_chunks)], device=device)
+        _CHUNK_ROWS[key] = t
+    return t
+
+
+def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_chunk_ids=False, box_cols=(0, 6), merge_fn=None):
     """Whole-scene NMS over the gathered blocks.  Valid rows are taken in (chunk id, row) order and sorted by
     score with a STABLE descending sort, so ties break by (chunk, row) -- deterministic and rank-independent.
     Returns (records_sorted (N,W), keep LongTensor) with keep indexing records_sorted
@@ -82,7 +95,15 @@ def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_ch
     Which boxes: the north star asks for an all-gather of per-chunk PROPOSALS before the whole-scene NMS, so by default
     the suppression runs on the proposal box (columns 0:6) ordered by the RPN objectness (column 6) -- the same quantities
     the per-chunk NMS used, which makes the merged list exactly what a single NMS over all chunks' proposals would keep.
-    Callers that want duplicates judged on the class-refined detections pass box_cols=(10, 16), score_col=9."""
+    Callers that want duplicates judged on the class-refined detections pass box_cols=(10, 16), score_col=9.
+
+    merge_fn(blocks, k_rows, thresh, score_col, box_col, max_keep) -> (records, keep, chunk ids): a fused implementation of
+    everything below (ops.scene_merge on the GPU: one launch sequence, one readback); it must refuse (return None) tables it
+    does not take, and the torch code here is then used -- the two are interchangeable bit for bit (tests/test_gpu_scene.py)."""
+    if merge_fn is not None:
+        out = merge_fn(blocks, k_rows, thresh, score_col, box_cols[0], max_keep)
+        if out is not None:
+            return out if with_chunk_ids else out[:2]
     n_chunks = blocks.shape[0]
     dev = blocks.device
     counts = blocks[:, 0].round().long().clamp(0, k_rows)

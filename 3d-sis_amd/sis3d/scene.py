@@ -10,6 +10,13 @@ from . import ops, parallel
 from .engine import PipelinedEngines
 
 
+def fused_merge(blocks, k_rows, thresh, score_col, box_col, max_keep):
+    """parallel.merge_scene's merge_fn on the GPU: sis3d_scene_merge for tables its sort takes (<= 8192 rows), else None"""
+    if not blocks.is_cuda or blocks.shape[0] * int(k_rows) > 8192:
+        return None
+    return ops.scene_merge(blocks, k_rows, thresh, score_col, box_col, max_keep)
+
+
 class SceneRunner:
     def __init__(self, net, dims, use_graph=True, inflight=3, solo=False):
         """solo: behave as a world of one even when a process group exists (the 1-GPU reference point bench.py takes on
@@ -79,8 +86,9 @@ class SceneRunner:
             local = self.run_chunks(chunks, group)
             blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group, solo=self.solo)
             if not with_masks:
-                return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep)
-            recs, keep, cids = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, with_chunk_ids=True)
+                return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, merge_fn=fused_merge)
+            recs, keep, cids = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, with_chunk_ids=True,
+                                                    merge_fn=fused_merge)
             masks = parallel.scene_masks(recs, keep, cids, chunks, self.mask_fn, float(self.net.cfg.CLASS_THRESH), group,
                                          solo=self.solo)
             return recs, keep, masks

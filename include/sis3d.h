@@ -416,6 +416,19 @@ int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *ou
 int sis3d_planar_to_cl(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
 int sis3d_cl_to_planar(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
 
+/* ---------------------------------------------------------------- whole-scene merge --
+ * New (the reference never chunks a scene; BASELINE config 5 / SURVEY 8e): what follows the all-gather of the per-chunk
+ * record blocks.  blocks [n_chunks][1 + k_rows*width] fp32, slot 0 of a block = its valid row count.  The valid rows are
+ * ordered by column score_col, descending and STABLE (ties: chunk id, then row -- torch.sort(stable=True) on the
+ * flattened table), gathered into recs [<= n_chunks*k_rows][width], and the 3D NMS of sis3d_nms runs on columns
+ * box_col..box_col+5 of the sorted rows.  order[j] = flat index (chunk*k_rows + row) of sorted row j; keep = ascending
+ * kept positions in recs; counts[0] = number of valid rows, counts[1] = number kept (max_keep > 0 cuts the list).
+ * One stream-ordered launch sequence, no host readback.  n_chunks*k_rows <= 8192, else SIS3D_EUNSUPPORTED. */
+size_t sis3d_scene_merge_workspace_bytes(int n_chunks, int k_rows);
+int sis3d_scene_merge(const float *blocks, int n_chunks, int k_rows, int width, int score_col, int box_col, float thresh,
+                      int max_keep, float *recs, int32_t *order, int64_t *keep, int32_t *counts, void *workspace,
+                      size_t workspace_bytes, sis3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

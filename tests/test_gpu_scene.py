@@ -205,3 +205,48 @@ def test_config5_scene_32_chunks_vs_oracle(oracle):
         assert float((r[:, 9] - w[:, 9]).abs().max()) <= 1e-4 and float((r[:, 10:16] - w[:, 10:16]).abs().max()) <= 5e-3
         s_ = recs[:, 6]
         assert bool((s_[:-1] >= s_[1:]).all())
+
+
+@pytest.mark.parametrize("n_chunks,k_rows", [(1, 200), (4, 200), (32, 200), (40, 200), (7, 33)])
+def test_fused_scene_merge_equals_torch_path(oracle, n_chunks, k_rows):
+    """sis3d_scene_merge (sort + gather + whole-scene NMS, one launch sequence) against parallel.merge_scene's torch code on
+    random record tables: ragged counts incl. empty and full chunks, tied scores across chunks, boxes that overlap across
+    chunk borders; both box / score column choices; keep list also against the CPU oracle's NMS."""
+    from sis3d import ops, parallel
+    from sis3d.engine import RECORD_WIDTH as W
+    g = torch.Generator().manual_seed(1000 * n_chunks + k_rows)
+    bf = 1 + k_rows * W
+    blocks = torch.zeros(n_chunks, bf)
+    counts = torch.randint(0, k_rows + 1, (n_chunks,), generator=g)
+    counts[0] = k_rows
+    if n_chunks > 2:
+        counts[1] = 0
+    for c in range(n_chunks):
+        n = int(counts[c])
+        rows = torch.zeros(k_rows, W)
+        lo = torch.rand(n, 3, generator=g) * torch.tensor([96.0, 40.0, 96.0]) + torch.tensor([90.0 * (c % 4), 0.0, 90.0 * (c // 4)])
+        rows[:n, 0:3] = lo
+        rows[:n, 3:6] = lo + torch.rand(n, 3, generator=g) * 30 + 1
+        rows[:n, 6] = (torch.rand(n, generator=g) * 50).round() / 50            # many exact ties, within and across chunks
+        rows[:n, 9] = torch.rand(n, generator=g)
+        rows[:n, 10:16] = rows[:n, 0:6] + torch.rand(n, 6, generator=g)
+        rows[:n, 8] = torch.randint(1, 19, (n,), generator=g).float()
+        rows[n:, 6] = 7.0                                                        # garbage past the count must be ignored
+        blocks[c, 0] = n
+        blocks[c, 1:] = rows.reshape(-1)
+    dev = blocks.cuda()
+    for score_col, box_cols in ((6, (0, 6)), (9, (10, 16))):
+        for th, mk in ((0.1, 0), (0.3, 17)):
+            want = parallel.merge_scene(dev, k_rows, ops.nms, th, score_col=score_col, max_keep=mk, with_chunk_ids=True, box_cols=box_cols)
+            if n_chunks * k_rows > 8192:
+                from sis3d.scene import fused_merge
+                assert fused_merge(dev, k_rows, th, score_col, box_cols[0], mk) is None
+                continue
+            got = ops.scene_merge(dev, k_rows, th, score_col, box_cols[0], mk)
+            for a, b in zip(got, want):
+                assert a.dtype == b.dtype and torch.equal(a, b)
+            okeep = oracle.nms(want[0][:, box_cols[0]:box_cols[1]].cpu().contiguous(), th)
+            assert torch.equal(got[1].cpu(), okeep[:mk] if mk else okeep)
+    empty = torch.zeros(3, bf).cuda()
+    r, k, c = ops.scene_merge(empty, k_rows, 0.1)
+    assert r.shape == (0, W) and k.numel() == 0 and c.numel() == 0

@@ -64,6 +64,11 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e6
     print("merge_scene (host wall, synced each call): %.1f us" % host_timed(lambda: parallel.merge_scene(blocks, runner.k_rows, ops.nms, 0.1)))
+    a = ops.scene_merge(blocks, runner.k_rows, 0.1)
+    b = parallel.merge_scene(blocks, runner.k_rows, ops.nms, 0.1, with_chunk_ids=True)
+    print("fused == torch path:", all(torch.equal(x, y) for x, y in zip(a, b)))
+    print("fused scene_merge (host wall, synced each call): %.1f us" % host_timed(lambda: ops.scene_merge(blocks, runner.k_rows, 0.1)))
+    print("fused scene_merge device time: %.1f us" % ev_time(lambda: ops.scene_merge_raw(blocks, runner.k_rows, 0.1)))
     k_rows = runner.k_rows
     counts = blocks[:, 0].round().long().clamp(0, k_rows)
     rows = blocks[:, 1:].reshape(n * k_rows, -1)
