@@ -74,9 +74,15 @@ struct T16Args {
     // to back; descriptor layout shared with conv3d.hip's ragged launch
     const T16Ragged *rag;
     int nrag;
+    // tools/t16_trace.py: per-workgroup {start, end (wall_clock64 ticks), HW_ID} of wave 0, or NULL
+    long long *dbg;
+    int dbg_cap;
 };
 
-template <int BX, int BY, int BZ, int G, int RB>
+// CLIP (the ragged mask-head launches): a brick that sticks out of its crop enumerates only the voxels inside -- its tiles
+// are cx*cy*cz / 16, not BX*BY*BZ / 16 -- and the MFMAs of the tiles it does not have are skipped by wave-uniform branches.
+// Crops are 9-20 voxels across, so with fixed 108-voxel bricks 30 % of all tile slots were padding (mask head 76 TF).
+template <int BX, int BY, int BZ, int G, int RB, bool CLIP = false>
 __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
@@ -90,6 +96,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
+    const int flat_block = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    if (a.dbg && tid == 0 && flat_block < a.dbg_cap) {
+        a.dbg[3 * (size_t)flat_block] = (long long)wall_clock64();
+        a.dbg[3 * (size_t)flat_block + 2] = (long long)__builtin_amdgcn_s_getreg((15 << 11) | 4);      // HW_REG_HW_ID[15:0]
+    }
     // block -> (brick, cout tile): work list is brick-major / tile-minor and every XCD (block b runs on XCD b % 8, private
     // 4 MiB L2) takes one contiguous range of it: the workgroups that share a halo brick share an L2
     int wid;
@@ -119,6 +130,29 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     int brick = wid / a.ntiles;
     const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
     const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
+    // clipped brick extents (CLIP): voxel m of the brick is (m / (cy cz), (m / cz) % cy, m % cz); small divisions by
+    // multiply-shift (exact for m < 512, divisor <= 144)
+    int cy = BY, cz = BZ, m_act = M, mt_act = MT;
+    uint32_t inv_yz = 0, inv_z = 0;
+    if constexpr (CLIP) {
+        const int cx = min(BX, gX - ox0);
+        cy = min(BY, gY - oy0);
+        cz = min(BZ, gZ - oz0);
+        m_act = cx * cy * cz;
+        mt_act = __builtin_amdgcn_readfirstlane((m_act + 15) >> 4);
+        inv_yz = (65536u + (uint32_t)(cy * cz) - 1u) / (uint32_t)(cy * cz);
+        inv_z = (65536u + (uint32_t)cz - 1u) / (uint32_t)cz;
+    }
+    auto voxel_of = [&](int m, int &lx, int &ly, int &lz) {
+        if constexpr (CLIP) {
+            lx = (int)(((uint32_t)m * inv_yz) >> 16);
+            const int rem = m - lx * cy * cz;
+            ly = (int)(((uint32_t)rem * inv_z) >> 16);
+            lz = rem - ly * cz;
+        } else {
+            lx = m / (BY * BZ); ly = (m / BZ) % BY; lz = m % BZ;
+        }
+    };
 
     // halo staging: item = (row, 16 B piece); global element offset (-1: outside the grid -> zero).  Rows advance by 32 per
     // item: (hx, hy, hz) is carried incrementally instead of re-dividing (this address math sits in front of the very first
@@ -178,8 +212,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         int m = 16 * t + li;
-        m = m < M ? m : M - 1;                             // surplus rows of the last tile recompute a valid voxel, never stored
-        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        m = m < m_act ? m : m_act - 1;                     // surplus rows of the last tile recompute a valid voxel, never stored
+        int lx, ly, lz;
+        voxel_of(m, lx, ly, lz);
         abase[t] = (((lx * IBY + ly) * IBZ + lz) * RS + 8 * wave + 2 * kq) * 4;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -187,44 +222,58 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     __syncthreads();
 
     const int nq = a.nq;
+    const int nga = CLIP ? (mt_act + G - 1) / G : NG;          // tile groups with at least one voxel tile (uniform)
     for (int q = 0; q < nq; ++q) {
         const bool more = q + 1 < nq;
         if (more) stage_load(q + 1);                       // in flight while this chunk is multiplied
-        f32x2 ar[2][G];
-        auto read_group = [&](auto BUF, auto STEP) {
-            constexpr int buf = decltype(BUF)::value, step = decltype(STEP)::value;
-            constexpr int tap = step / NG, g = step % NG;
-            constexpr int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
-            constexpr int toff = ((dx * IBY + dy) * IBZ + dz) * RS * 4;
-            static_for<0, G>([&](auto J) {
-                constexpr int j = decltype(J)::value, t = g * G + j;
-                if constexpr (t < MT)
-                    ar[buf][j] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(lds) + abase[t] + toff);
+        // one chunk = TAPS x NGA steps; NGA = tile groups this brick really has (NG unless CLIP): the body is instantiated
+        // per NGA and picked by ONE uniform branch per chunk (a branch per step cost more than the skipped MFMAs saved)
+        auto run_chunk = [&](auto NGA_) {
+            constexpr int NGA = decltype(NGA_)::value;
+            constexpr int NSTEPA = TAPS * NGA;
+            f32x2 ar[2][G];
+            auto read_group = [&](auto BUF, auto STEP) {
+                constexpr int buf = decltype(BUF)::value, step = decltype(STEP)::value;
+                constexpr int tap = step / NGA, g = step % NGA;
+                constexpr int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+                constexpr int toff = ((dx * IBY + dy) * IBZ + dz) * RS * 4;
+                static_for<0, G>([&](auto J) {
+                    constexpr int j = decltype(J)::value, t = g * G + j;
+                    if constexpr (t < MT)
+                        ar[buf][j] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(lds) + abase[t] + toff);
+                });
+            };
+            read_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            static_for<0, NSTEPA>([&](auto STEP) {
+                constexpr int step = decltype(STEP)::value;
+                constexpr int tap = step / NGA, g = step % NGA;
+                if constexpr (g == 0) {
+                    // fetch the fragment RB-1 taps ahead (wraps into the next chunk's first taps)
+                    constexpr int tn = tap + RB - 1;
+                    if constexpr (tn < TAPS) bq[tn % RB] = load_b(q, tn);
+                    else if (more) bq[tn % RB] = load_b(q + 1, tn - TAPS);
+                }
+                if constexpr (step + 1 < NSTEPA) read_group(std::integral_constant<int, (step + 1) & 1>{}, std::integral_constant<int, step + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                const float2 b = bq[tap % RB];
+                static_for<0, G>([&](auto J) {
+                    constexpr int j = decltype(J)::value, t = g * G + j;
+                    if constexpr (t < MT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].x, b.x, acc[t], 0, 0, 0);
+                });
+                static_for<0, G>([&](auto J) {
+                    constexpr int j = decltype(J)::value, t = g * G + j;
+                    if constexpr (t < MT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].y, b.y, acc[t], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
             });
         };
-        read_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        static_for<0, NSTEP>([&](auto STEP) {
-            constexpr int step = decltype(STEP)::value;
-            constexpr int tap = step / NG, g = step % NG;
-            if constexpr (g == 0) {
-                // fetch the fragment RB-1 taps ahead (wraps into the next chunk's first taps)
-                constexpr int tn = tap + RB - 1;
-                if constexpr (tn < TAPS) bq[tn % RB] = load_b(q, tn);
-                else if (more) bq[tn % RB] = load_b(q + 1, tn - TAPS);
-            }
-            if constexpr (step + 1 < NSTEP) read_group(std::integral_constant<int, (step + 1) & 1>{}, std::integral_constant<int, step + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            const float2 b = bq[tap % RB];
-            static_for<0, G>([&](auto J) {
-                constexpr int j = decltype(J)::value, t = g * G + j;
-                if constexpr (t < MT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].x, b.x, acc[t], 0, 0, 0);
+        if constexpr (CLIP) {
+            static_for<1, NG + 1>([&](auto NGA_) {
+                if (nga == decltype(NGA_)::value) run_chunk(NGA_);
             });
-            static_for<0, G>([&](auto J) {
-                constexpr int j = decltype(J)::value, t = g * G + j;
-                if constexpr (t < MT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[step & 1][j].y, b.y, acc[t], 0, 0, 0);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        } else {
+            run_chunk(std::integral_constant<int, NG>{});
+        }
         __syncthreads();                                   // every wave is done with chunk q's image
         if (more) {
             stage_store();
@@ -245,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias[prob] && co < a.cout) bv = *reinterpret_cast<const float4 *>(a.bias[prob] + co);
     float *__restrict__ p_out = a.out[prob] + out_off;
-    for (int t = wave; t < MT; t += 4) {
+    for (int t = wave; t < mt_act; t += 4) {
         const float4 *src = reinterpret_cast<const float4 *>(lds + t * 256 + row * 16 + c4 * 4);
         const float4 s0 = src[0], s1 = src[MT * 64], s2 = src[2 * MT * 64], s3 = src[3 * MT * 64];
         float4 v;
@@ -255,11 +304,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
         v.w = (s0.w + s1.w) + (s2.w + s3.w) + bv.w;
         if (a.flags & SIS3D_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const int m = 16 * t + row;
-        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        int lx, ly, lz;
+        voxel_of(m < m_act ? m : 0, lx, ly, lz);
         const int ox = ox0 + lx, oy = oy0 + ly, oz = oz0 + lz;
-        if (m < M && ox < gX && oy < gY && oz < gZ && co < a.cout)
+        if (m < m_act && ox < gX && oy < gY && oz < gZ && co < a.cout)
             *reinterpret_cast<float4 *>(p_out + ((size_t)(ox * gY + oy) * gZ + oz) * a.out_stride + a.out_coff + co) = v;
     }
+    if (a.dbg && tid == 0 && flat_block < a.dbg_cap) a.dbg[3 * (size_t)flat_block + 1] = (long long)wall_clock64();
 }
 
 // (Cout,Cin,3,3,3) -> [cout/16][cin/32][wave 4][tap 27][lane 64][2]: lane (j = lane & 15, k = lane >> 4) holds
@@ -282,7 +333,10 @@ __global__ __launch_bounds__(256) void pack_weight_t16_kernel(const float *__res
     }
 }
 
-template <int BX, int BY, int BZ>
+std::atomic<long long *> g_dbg{nullptr};   // sis3d_conv3d_k3t16_set_trace
+std::atomic<int> g_dbg_cap{0};
+
+template <int BX, int BY, int BZ, bool CLIP = false>
 int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
@@ -293,7 +347,9 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     constexpr size_t lds = img > red ? img : red;
     static_assert(lds <= 160 * 1024, "LDS brick too large");
     a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
-    auto kern = conv3d_k3t16_kernel<BX, BY, BZ, G, RB>;
+    a.dbg = g_dbg.load(std::memory_order_relaxed);
+    a.dbg_cap = g_dbg_cap.load(std::memory_order_relaxed);
+    auto kern = conv3d_k3t16_kernel<BX, BY, BZ, G, RB, CLIP>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t nwg = ragged_blocks > 0 ? ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * a.ntiles;
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
@@ -301,7 +357,8 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     return sis3d_check_launch();
 }
 
-std::atomic<int> g_brick_cap{0};          // sis3d_conv3d_k3t16_set_brick_cap
+std::atomic<int> g_brick_cap{0};
+          // sis3d_conv3d_k3t16_set_brick_cap
 
 struct Brick { int bx, by, bz; };
 constexpr Brick BRICKS[] = {{6, 6, 12}, {6, 6, 6}, {3, 6, 6}, {3, 3, 6}, {4, 4, 4}, {4, 4, 8}, {4, 8, 8}};
@@ -336,6 +393,13 @@ extern "C" int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, f
     hipLaunchKernelGGL(pack_weight_t16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), w, cout, cin,
                        ntiles, nq, packed);
     return sis3d_check_launch();
+}
+
+extern "C" int sis3d_conv3d_k3t16_set_trace(void *buf, int capacity_blocks)
+{
+    g_dbg.store((long long *)buf, std::memory_order_relaxed);
+    g_dbg_cap.store(buf ? capacity_blocks : 0, std::memory_order_relaxed);
+    return SIS3D_OK;
 }
 
 extern "C" int sis3d_conv3d_k3t16_set_brick_cap(int max_voxels)
@@ -421,11 +485,22 @@ extern "C" int sis3d_conv3d_k3t16_ragged(const float *in, int cin, int cin_strid
     a.flags = flags; a.out_stride = out_stride; a.out_coff = 0;
     a.rag = (const T16Ragged *)desc_dev; a.nrag = ndesc;
     hipStream_t st = as_stream(stream);
+    static const bool noclip = [] { const char *e = getenv("SIS3D_T16_NOCLIP"); return e && atoi(e) != 0; }();   // A/B hook
+    if (noclip) {
+        switch (brick) {
+        case 2: return launch_t16<3, 6, 6>(a, 1, st, total_blocks);
+        case 3: return launch_t16<3, 3, 6>(a, 1, st, total_blocks);
+        case 4: return launch_t16<4, 4, 4>(a, 1, st, total_blocks);
+        case 5: return launch_t16<4, 4, 8>(a, 1, st, total_blocks);
+        default: return SIS3D_EUNSUPPORTED;
+        }
+    }
     switch (brick) {
-    case 2: return launch_t16<3, 6, 6>(a, 1, st, total_blocks);
-    case 3: return launch_t16<3, 3, 6>(a, 1, st, total_blocks);
-    case 4: return launch_t16<4, 4, 4>(a, 1, st, total_blocks);
-    case 5: return launch_t16<4, 4, 8>(a, 1, st, total_blocks);
+    case 2: return launch_t16<3, 6, 6, true>(a, 1, st, total_blocks);
+    case 3: return launch_t16<3, 3, 6, true>(a, 1, st, total_blocks);
+    case 4: return launch_t16<4, 4, 4, true>(a, 1, st, total_blocks);
+    case 5: return launch_t16<4, 4, 8, true>(a, 1, st, total_blocks);
+    case 1: return launch_t16<6, 6, 6, true>(a, 1, st, total_blocks);
     default: return SIS3D_EUNSUPPORTED;
     }
 }

@@ -963,16 +963,26 @@ class MaskPlan:
         if not K3_LEGACY:
             best = None
             forced = int(_os.environ.get("SIS3D_MASK_BRICK", "-1"))        # tuning hook
-            for brick in ((forced,) if forced >= 0 else (2, 4, 5, 3)):   # 3x6x6, 4x4x4, 4x4x8, 3x3x6: least estimated SIMD time wins
+            # 3x6x6, 4x4x4, 4x4x8, 3x3x6: least estimated SIMD time wins (6x6x6 = brick 1 exists but measured slower on 9-20 voxel crops:
+            # 0.58 vs 0.48 ms for the 16-box batch, tools/mask_time.py)
+            for brick in ((forced,) if forced >= 0 else (2, 4, 5, 3)):
                 tb = [ctypes.c_int() for _ in range(5)]
                 if lib().sis3d_ragged_tiling_k3t16(C, C, brick, *[ctypes.byref(v) for v in tb]) != 0:
                     continue
                 tbx, tby, tbz, tng, tmt = (v.value for v in tb)
-                nbt = -(-ext // np.array([tbx, tby, tbz]))
-                # per workgroup: MFMA issue of its tile slots (padded or not) + a fixed prologue / epilogue share
-                slots = int(nbt.prod(1).sum()) * (tmt * 27 * (C // 16) * 32 + 3000)
-                if best is None or slots < best[0]:
-                    best = (slots, brick, nbt, tng)
+                bdim = np.array([tbx, tby, tbz])
+                nbt = -(-ext // bdim)
+                # a brick that sticks out of its crop runs only the tile groups it has voxels for (CLIP kernels, conv3d_t16.hip):
+                # per workgroup MFMA issue of ceil(ceil(v / 16) / G) * G tiles + a fixed prologue / epilogue share
+                grp = 3 if tmt % 3 == 0 else (4 if tmt >= 4 else tmt)
+                cost = 0
+                for e in ext:
+                    per_axis = [np.minimum(bdim[k], e[k] - bdim[k] * np.arange(-(-e[k] // bdim[k]))) for k in range(3)]
+                    vox = per_axis[0][:, None, None] * per_axis[1][None, :, None] * per_axis[2][None, None, :]
+                    tiles = np.minimum(tmt, -(-(-(-vox // 16)) // grp) * grp)
+                    cost += int((tiles * (27 * (C // 16) * 32) + 3000).sum())
+                if best is None or cost < best[0]:
+                    best = (cost, brick, nbt, tng)
             if best is not None:
                 _, brick, nbt, tng = best
                 blt = np.concatenate([[0], np.cumsum(nbt.prod(1) * tng)])
@@ -989,6 +999,7 @@ class MaskPlan:
         dp["out_off"] = voffs[:-1] * C
         self.voxels, self.blocks, self.items = int(voffs[-1]), int(blks[-1]), int(voffs[-1]) * (C // 4)
         self.dims = [tuple(int(v) for v in e) for e in ext]
+        self.windows = [tuple(int(v) for v in r) for r in w]
         # ONE upload for the three descriptor tables (each is a blocking pageable copy)
         parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1),
                  d3t.view(np.uint8).reshape(-1)]

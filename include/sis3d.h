@@ -343,6 +343,9 @@ int sis3d_rpn_heads(const float *in1, const float *packed_w1, const float *bias1
  * largest brick (one workgroup per CU); with several chunks in flight on separate streams bricks of <= 108 voxels (46 KB of
  * LDS, 3 workgroups per CU) let the streams' kernels share the CUs (+3-4 % throughput, profiles/README.md). */
 int sis3d_conv3d_k3t16_set_brick_cap(int max_voxels);
+/* profiling hook (tools/t16_trace.py): every later k3t16 launch writes {start, end (100 MHz wall clock ticks), HW_ID} of each of its
+ * first capacity_blocks workgroups into buf (3 x int64 per workgroup, device memory); NULL switches it off */
+int sis3d_conv3d_k3t16_set_trace(void *buf, int capacity_blocks);
 size_t sis3d_conv_k3t16_packed_floats(int cout, int cin);
 int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
 int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob);
