@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The dominant kernel's launches inside a rocprofv3 kernel trace of `bench.py`: bench.py times the rpn_net k3 128->256 conv with 100
-warm + 50 timed launches BEFORE anything else of that template runs, so the first 150 dispatches of conv3d_k3t16_kernel<6, 6, 12, ...>
-with a 256 x 1 grid (start-time order) are exactly those; the last 50 of them are the timed ones.  The kernel_stats row of the
+warm + 5 x 50 timed launches (median batch reported) BEFORE anything else of that template runs, so the first 350 dispatches of
+conv3d_k3t16_kernel<6, 6, 12, ...> with a 256 x 1 grid (start-time order) are exactly those; the last 250 of them are the timed ones.  The kernel_stats row of the
 template averages every layer that uses the instantiation (the 48x24x48 Bottleneck convs share its grid).
 Usage: python tools/dominant_from_trace.py <kernel_trace.csv> [bench.json]  -> JSON on stdout"""
 import csv
@@ -15,14 +15,15 @@ def main():
         if "conv3d_k3t16_kernel<6, 6, 12" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 256 * 256 and int(r.get("Grid_Size_Y", 1)) == 1:
             rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     rows.sort()
-    first = [d for _, d in rows[:150]]
-    timed = first[100:150]
+    first = [d for _, d in rows[:350]]
+    timed = first[100:350]
     out = {"kernel": "conv3d_k3t16_kernel<6,6,12,3,3> (rpn_net 128->256 on 24x12x24, 256 workgroups x 256 threads)",
            "launches_of_this_grid_in_trace": len(rows), "bench_timing_launches": len(first),
-           "timed_50_mean_us": sum(timed) / max(1, len(timed)), "timed_50_min_us": min(timed) if timed else None,
-           "timed_50_max_us": max(timed) if timed else None, "warm_100_mean_us": sum(first[:100]) / max(1, len(first[:100])),
+           "timed_250_mean_us": sum(timed) / max(1, len(timed)), "timed_250_min_us": min(timed) if timed else None,
+           "timed_250_max_us": max(timed) if timed else None,
+           "batch_means_us": [sum(timed[i:i + 50]) / 50 for i in range(0, len(timed) - 49, 50)], "warm_100_mean_us": sum(first[:100]) / max(1, len(first[:100])),
            "flop_per_launch": 2.0 * 6912 * 256 * 128 * 27}
-    out["tflops"] = out["flop_per_launch"] / out["timed_50_mean_us"] / 1e6 if timed else None
+    out["tflops"] = out["flop_per_launch"] / out["timed_250_mean_us"] / 1e6 if timed else None
     out["frac_of_157.3TF"] = out["tflops"] / 157.3 if timed else None
     if len(sys.argv) > 2:
         try:
