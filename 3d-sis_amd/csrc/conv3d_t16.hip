@@ -77,6 +77,7 @@ struct T16Args {
     // tools/t16_trace.py: per-workgroup {start, end (wall_clock64 ticks), HW_ID} of wave 0, or NULL
     long long *dbg;
     int dbg_cap;
+    int xcd_tg, xcd_bpb;       // work-list order per XCD range: xcd_bpb bricks x xcd_tg cout tiles (0: tile-fastest order)
 };
 
 // CLIP (the ragged mask-head launches): a brick that sticks out of its crop enumerates only the voxels inside -- its tiles
@@ -126,8 +127,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3t16_kernel(const T16Args a)
         p_in += d.in_off;
         out_off = d.out_off;
     }
-    const int nt = wid % a.ntiles;
-    int brick = wid / a.ntiles;
+    // (brick, cout tile) of work item wid.  Default: tile fastest.  With xcd_tg > 0 (launch_t16: full-grid launches whose
+    // workgroup count splits evenly over the 8 XCDs) an XCD's range is xcd_bpb bricks x xcd_tg tiles instead of few bricks x all
+    // tiles: its L2 then holds 1/ (ntiles / xcd_tg) of the weights (rpn_net: 1.75 MB weights + 1.65 MB halo bricks per 4 MB
+    // L2 instead of 3.5 + 0.8 MB)
+    int nt, brick;
+    if (a.xcd_tg > 0) {
+        const int L = a.xcd_tg * a.xcd_bpb, r = wid / L, within = wid - r * L, ngroups = a.ntiles / a.xcd_tg;
+        const int bb = r / ngroups, tgp = r - bb * ngroups;
+        brick = bb * a.xcd_bpb + within / a.xcd_tg;
+        nt = tgp * a.xcd_tg + within % a.xcd_tg;
+    } else {
+        nt = wid % a.ntiles;
+        brick = wid / a.ntiles;
+    }
     const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
     const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
     // clipped brick extents (CLIP): voxel m of the brick is (m / (cy cz), (m / cz) % cy, m % cz); small divisions by
@@ -347,6 +360,24 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     constexpr size_t lds = img > red ? img : red;
     static_assert(lds <= 160 * 1024, "LDS brick too large");
     a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
+    a.xcd_tg = a.xcd_bpb = 0;
+    if (ragged_blocks == 0) {
+        // split of an XCD's range (nwg / 8 work items) into bricks x tiles that keeps the least data in its L2
+        static const int tg_mode = [] { const char *e = getenv("SIS3D_T16_XCD_TG"); return e ? atoi(e) : -1; }();   // 0: off, >0: forced
+        const int64_t nbr = (int64_t)a.nbx * a.nby * a.nbz, nwg_ = nbr * a.ntiles;
+        if (tg_mode != 0 && nwg_ % 8 == 0) {
+            const int L = (int)(nwg_ / 8);
+            const double wbytes = (double)a.ntiles * 16 * a.nq * CK * TAPS * 4, bbytes = (double)ROWS * a.nq * CK * 4;
+            double best = -1;
+            for (int tg = 1; tg <= a.ntiles; ++tg) {
+                if (a.ntiles % tg || L % tg || nbr % (L / tg) || 8 % (a.ntiles / tg)) continue;   // 8 ranges = brick blocks x tile groups
+                if (tg_mode > 0 && tg != tg_mode) continue;
+                const double cost = wbytes * tg / a.ntiles + bbytes * (L / tg);
+                if (best < 0 || cost < best) { best = cost; a.xcd_tg = tg; a.xcd_bpb = L / tg; }
+            }
+            if (a.xcd_tg == a.ntiles) a.xcd_tg = a.xcd_bpb = 0;          // the default order already
+        }
+    }
     a.dbg = g_dbg.load(std::memory_order_relaxed);
     a.dbg_cap = g_dbg_cap.load(std::memory_order_relaxed);
     auto kern = conv3d_k3t16_kernel<BX, BY, BZ, G, RB, CLIP>;
