@@ -1,0 +1,377 @@
+// k3 / pad-1 3D convolution on the bf16 matrix pipe with SPLIT operands ("bf16x3"): an OPTIONAL, separately reported variant
+// of conv3d_k3t16_kernel for the rpn_net layers (lib/nets/network.py:40,45: nn.Conv3d(128, 256, 3, padding=1) + ReLU).
+//
+// gfx950 has no xf32 / TF32 mode and its fp32 MFMA runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s), so the exact-fp32 conv
+// stack is bound by the fp32 matrix pipe.  Here every fp32 operand x is split into two bf16 numbers
+//     x = hi + lo (+ r),  hi = bf16(x),  lo = bf16(x - hi),  |r| <= 2^-17 |x|
+// and a product a * b is taken as  ah*bh + ah*bl + al*bh  on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: three matrix
+// instructions of 16 cycles replace eight fp32 instructions of 32 cycles for the same 32 input channels.  The dropped term
+// al*bl and the split remainders bound the relative error of a product by ~2^-16 (1.5e-5); results are NOT bit-compatible with
+// the fp32 path and the variant is therefore off by default (tests/test_gpu_conv_b16.py states the measured error; the headline
+// bench line stays on the fp32 kernels).
+//
+// Structure (as conv3d_t16.hip unless noted): workgroup = 4 waves = a BX x BY x BZ brick x one 16-wide cout tile; the halo brick
+// of one 32-channel chunk is staged in LDS as rows of [32 hi | 32 lo] bf16 (128 B + 16 B pad, the footprint of the fp32 image),
+// converted on the way from the fp32 activations (v_cvt_pk_bf16_f32); a matrix instruction consumes all 32 channels of a chunk,
+// so the four waves split the 27 TAPS (7 / 7 / 7 / 6, the short share rotating with the chunk) instead of the channels, and
+// their partial tiles are summed through LDS at the end.  A tap is an immediate offset of two ds_read_b128 (hi, lo) that feed
+// three MFMAs; weights are pre-split into fragment order ([tile][chunk][tap][hi|lo][lane][8]) and a chunk's seven taps are
+// requested one chunk ahead.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int B16_MAXP = 4;
+constexpr int CK = 32;                  // channels per chunk = K of one matrix instruction
+constexpr int RSB = 2 * CK * 2 + 32;    // LDS row stride in BYTES: 64 B hi + 64 B lo + 32 B pad (160: ds_read_b128 of a tile's 16 rows takes
+                                        // 8 LDS cycles on the real halo-brick rows; 144 would take 11.7, tools note in profiles/)
+constexpr int TAPS = 27;
+constexpr int TPW = 7;                  // taps per wave and chunk (the wave of rank 3 takes 6)
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct B16Args {
+    const float *in[B16_MAXP];
+    const uint4 *wp[B16_MAXP];          // packed split weights
+    const float *bias[B16_MAXP];
+    float *out[B16_MAXP];
+    int X, Y, Z;
+    int cin_stride;
+    int cout, ntiles, nq, flags;
+    int out_stride, out_coff;
+    int nbx, nby, nbz;
+};
+
+// fp32 pair -> packed bf16 pair (round to nearest even) and the bf16 pair of the remainders
+__device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = *reinterpret_cast<const uint32_t *>(&h);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)ra, (__bf16)rb};
+    lo = *reinterpret_cast<const uint32_t *>(&l);
+}
+
+// NTC = cout tiles per workgroup: with 2, an A fragment read from LDS feeds six matrix instructions instead of three -- the
+// kernel with one tile per workgroup is bound by its LDS reads (two ds_read_b128 per three 16-cycle MFMAs on four waves)
+template <int BX, int BY, int BZ, int NTC>
+__global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
+{
+    constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
+    constexpr int IBY = BY + 2, IBZ = BZ + 2, IBX = BX + 2, ROWS = IBX * IBY * IBZ;
+    constexpr int ITEMS = ROWS * (CK / 4), NIT = (ITEMS + 255) / 256;
+    constexpr int G = (MT % 3 == 0) ? 3 : (MT >= 4 ? 4 : MT);
+    constexpr int NG = (MT + G - 1) / G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];   // [ROWS][RSB]; reused as float [4 waves][MT][16][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    int wid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int prob = blockIdx.y;
+    const float *__restrict__ p_in = a.in[prob];
+    const int gX = a.X, gY = a.Y, gZ = a.Z, nby = a.nby, nbz = a.nbz;
+    const int ngrp = (a.ntiles + NTC - 1) / NTC;            // workgroups per brick
+    const int nt = (wid % ngrp) * NTC;                      // first cout tile of this workgroup
+    const int brick = wid / ngrp;
+    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+    const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
+
+    // halo staging table (element offsets, -1 = outside the grid), as conv3d_k3t16_kernel
+    int goff[NIT];
+    {
+        const int row0 = tid >> 3, c4 = tid & 7;
+        int hz = row0 % IBZ, hy = (row0 / IBZ) % IBY, hx = row0 / (IBZ * IBY);
+        constexpr int DZ = 32 % IBZ, DY = (32 / IBZ) % IBY, DX = 32 / (IBZ * IBY);
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
+            const bool ok = (tid + it * 256 < ITEMS) && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
+            goff[it] = ok ? ((gx * gY + gy) * gZ + gz) * a.cin_stride + c4 * 4 : -1;
+            hz += DZ;
+            const int cz = hz >= IBZ;
+            hz -= cz * IBZ;
+            hy += DY + cz;
+            const int cy = hy >= IBY;
+            hy -= cy * IBY;
+            hx += DX + cy;
+        });
+    }
+    float4 sv[NIT];
+    auto stage_load = [&](int q) {
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int o = goff[it];
+            const float4 v = *reinterpret_cast<const float4 *>(p_in + (size_t)(o < 0 ? 0 : o) + q * CK);
+            sv[it] = o < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : v;
+        });
+    };
+    // item = (row, 4 channels): 4 hi bf16 (8 B) into the hi half of the row, 4 lo bf16 into the lo half
+    auto stage_store = [&]() {
+        static_for<0, NIT>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            const int idx = tid + it * 256;
+            if (idx < ITEMS) {
+                uint2 h, l;
+                split2(sv[it].x, sv[it].y, h.x, l.x);
+                split2(sv[it].z, sv[it].w, h.y, l.y);
+                unsigned char *row = ldsb + (idx >> 3) * RSB + (idx & 7) * 8;
+                *reinterpret_cast<uint2 *>(row) = h;
+                *reinterpret_cast<uint2 *>(row + 2 * CK) = l;
+            }
+        });
+    };
+
+    // B operand of this wave for chunk q: taps [TPW r, TPW r + n), r = (wave + q) & 3 (the 6-tap share rotates), hi and lo
+    // fragment of every (tap, cout tile) = 16 B per lane each: packed [ntile][chunk][tap][2][64] uint4.  All of a chunk's
+    // slots sit in registers; slot ts is refilled for the NEXT chunk as soon as its last matrix instruction has been issued.
+    const uint4 *bp = a.wp[prob] + lane;
+    constexpr int TS = 2 * 64, QS = TAPS * TS;              // uint4 strides of a tap / a chunk
+    const size_t tile_stride = (size_t)a.nq * QS;
+    uint4 bw[TPW][NTC][2];
+    auto load_slot = [&](int q, auto T) {
+        constexpr int t = decltype(T)::value;
+        const int r = (wave + q) & 3;
+        // the share of rank 3 has TAPS - 3 TPW = 6 taps: its 7th slot re-reads tap 26 and is never used
+        const int tap = (TPW * r + t < TAPS) ? TPW * r + t : TAPS - 1;
+        static_for<0, NTC>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            const int tile = (nt + n < a.ntiles) ? nt + n : a.ntiles - 1;      // a surplus tile recomputes the last one, never stored
+            const uint4 *src = bp + (size_t)tile * tile_stride + (size_t)q * QS + (size_t)tap * TS;
+            bw[t][n][0] = src[0];
+            bw[t][n][1] = src[64];
+        });
+    };
+
+    f32x4 acc[MT][NTC];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    static_for<0, TPW>([&](auto T) { load_slot(0, T); });
+    stage_load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    int abase[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = 16 * t + li;
+        m = m < M ? m : M - 1;
+        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        abase[t] = ((lx * IBY + ly) * IBZ + lz) * RSB + kq * 16;          // bytes: channels 8 kq .. 8 kq + 7 of the hi half
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_store();
+    __syncthreads();
+
+    const int nq = a.nq;
+    for (int q = 0; q < nq; ++q) {
+        const bool more = q + 1 < nq;
+        if (more) stage_load(q + 1);
+        const int r = (wave + q) & 3;
+        // taps [TPW R, TPW R + NTAP) x NG groups of G tiles; per group 2 G reads (hi, lo) and 3 G NTC matrix instructions
+        auto run_taps = [&](auto R_) {
+            constexpr int R = decltype(R_)::value;
+            constexpr int T0 = TPW * R, NTAP = (T0 + TPW <= TAPS) ? TPW : TAPS - T0;
+            constexpr int NSTEP = NTAP * NG;
+            bf16x8 ah[2][G], al[2][G];
+            auto read_group = [&](auto BUF, auto STEP) {
+                constexpr int buf = decltype(BUF)::value, step = decltype(STEP)::value;
+                constexpr int tap = T0 + step / NG, g = step % NG;
+                constexpr int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+                constexpr int toff = ((dx * IBY + dy) * IBZ + dz) * RSB;
+                static_for<0, G>([&](auto J) {
+                    constexpr int j = decltype(J)::value, t = g * G + j;
+                    if constexpr (t < MT) {
+                        ah[buf][j] = *reinterpret_cast<const bf16x8 *>(ldsb + abase[t] + toff);
+                        al[buf][j] = *reinterpret_cast<const bf16x8 *>(ldsb + abase[t] + toff + 2 * CK);
+                    }
+                });
+            };
+            read_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            static_for<0, NSTEP>([&](auto STEP) {
+                constexpr int step = decltype(STEP)::value;
+                constexpr int ts = step / NG, g = step % NG;
+                if constexpr (step + 1 < NSTEP) read_group(std::integral_constant<int, (step + 1) & 1>{}, std::integral_constant<int, step + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                // small terms first, the hi * hi product last; the instructions of one accumulator are G NTC instructions apart
+                static_for<0, 3>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    static_for<0, G>([&](auto J) {
+                        constexpr int j = decltype(J)::value, t = g * G + j;
+                        if constexpr (t < MT)
+                            static_for<0, NTC>([&](auto N) {
+                                constexpr int n = decltype(N)::value;
+                                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(p == 0 ? &al[step & 1][j] : &ah[step & 1][j]);
+                                const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(&bw[ts][n][p == 1 ? 1 : 0]);
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[t][n], 0, 0, 0);
+                            });
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (g == NG - 1)
+                    if (more) load_slot(q + 1, std::integral_constant<int, ts>{});      // this slot's last use is behind us
+            });
+            if constexpr (NTAP < TPW)
+                if (more) load_slot(q + 1, std::integral_constant<int, TPW - 1>{});
+        };
+        static_for<0, 4>([&](auto R_) {
+            if (r == decltype(R_)::value) run_taps(R_);
+        });
+        __syncthreads();                                   // every wave is done with chunk q's image
+        if (more) {
+            stage_store();
+            __syncthreads();
+        }
+    }
+
+    // ---- cross-wave reduction + epilogue, as conv3d_k3t16_kernel: tile (t, n) of wave w at [w][t][n][16 voxels][16 couts]
+    float *lds = reinterpret_cast<float *>(ldsb);
+    constexpr int SLAB = MT * NTC * 256;
+    float *red = lds + (size_t)wave * SLAB;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NTC; ++n)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[(t * NTC + n) * 256 + (4 * kq + rr) * 16 + li] = acc[t][n][rr];
+    __syncthreads();
+    const int row = lane >> 2, c4 = lane & 3;
+    float *__restrict__ p_out = a.out[prob];
+    for (int t = wave; t < MT; t += 4) {
+        const int m = 16 * t + row;
+        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        const int ox = ox0 + lx, oy = oy0 + ly, oz = oz0 + lz;
+        const bool inside = m < M && ox < gX && oy < gY && oz < gZ;
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) {
+            const int co = 16 * (nt + n) + 4 * c4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias[prob] && co < a.cout) bv = *reinterpret_cast<const float4 *>(a.bias[prob] + co);
+            const float4 *src = reinterpret_cast<const float4 *>(lds + (t * NTC + n) * 256 + row * 16 + c4 * 4);
+            const float4 s0 = src[0], s1 = src[SLAB / 4], s2 = src[2 * (SLAB / 4)], s3 = src[3 * (SLAB / 4)];
+            float4 v;
+            v.x = (s0.x + s1.x) + (s2.x + s3.x) + bv.x;
+            v.y = (s0.y + s1.y) + (s2.y + s3.y) + bv.y;
+            v.z = (s0.z + s1.z) + (s2.z + s3.z) + bv.z;
+            v.w = (s0.w + s1.w) + (s2.w + s3.w) + bv.w;
+            if (a.flags & SIS3D_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (inside && nt + n < a.ntiles && co < a.cout)
+                *reinterpret_cast<float4 *>(p_out + ((size_t)(ox * gY + oy) * gZ + oz) * a.out_stride + a.out_coff + co) = v;
+        }
+    }
+}
+
+// (Cout,Cin,3,3,3) fp32 -> [cout/16][cin/32][tap 27][hi|lo][lane 64][8] bf16: lane (j = lane & 15, kb = lane >> 4), element e
+// holds the split of W[16 tile + j][32 q + 8 kb + e][tap]
+__global__ __launch_bounds__(256) void pack_weight_b16_kernel(const float *__restrict__ w, int cout, int cin, int ntiles, int nq,
+                                                              uint16_t *__restrict__ packed)
+{
+    const int64_t total = (int64_t)ntiles * nq * TAPS * 64 * 8;           // (tile, q, tap, lane, e)
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        int64_t rest = idx >> 9;
+        const int tap = (int)(rest % TAPS);
+        rest /= TAPS;
+        const int q = (int)(rest % nq), tile = (int)(rest / nq);
+        const int co = tile * 16 + (lane & 15), ci = q * CK + 8 * (lane >> 4) + e;
+        const float v = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * TAPS + tap] : 0.0f;
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        const int64_t base = (((int64_t)(tile * nq + q) * TAPS + tap) * 2) * 512 + lane * 8 + e;
+        packed[base] = *reinterpret_cast<const uint16_t *>(&h);
+        packed[base + 512] = *reinterpret_cast<const uint16_t *>(&l);
+    }
+}
+
+template <int BX, int BY, int BZ, int NTC>
+int launch_b16(B16Args &a, int nprob, hipStream_t st)
+{
+    constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
+    constexpr int ROWS = (BX + 2) * (BY + 2) * (BZ + 2);
+    constexpr size_t img = (size_t)ROWS * RSB, red = (size_t)4 * MT * NTC * 256 * sizeof(float);
+    constexpr size_t lds = img > red ? img : red;
+    static_assert(lds <= 160 * 1024, "LDS brick too large");
+    a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
+    auto kern = conv3d_k3b16_kernel<BX, BY, BZ, NTC>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * ((a.ntiles + NTC - 1) / NTC);
+    if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(256), lds, st, a);
+    return sis3d_check_launch();
+}
+
+} // namespace
+
+extern "C" size_t sis3d_conv_k3b16_packed_floats(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0 || cin % CK) return 0;
+    // 2 bf16 per weight = one float's worth of bytes
+    return (size_t)((cout + 15) / 16) * (cin / CK) * TAPS * 64 * 8;
+}
+
+extern "C" int sis3d_conv_k3b16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream)
+{
+    if (!w || !packed || cout <= 0 || cin <= 0 || cin % CK) return SIS3D_EINVAL;
+    const int ntiles = (cout + 15) / 16, nq = cin / CK;
+    const int64_t total = (int64_t)ntiles * nq * TAPS * 512;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_weight_b16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), w, cout, cin,
+                       ntiles, nq, (uint16_t *)packed);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_conv3d_k3b16(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                  const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                                  int out_stride, int out_coff, int brick, sis3d_stream_t stream)
+{
+    if (nprob < 1 || nprob > B16_MAXP || !ins || !packed_ws || !outs) return SIS3D_EINVAL;
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || cin_stride < cin || (cin_stride % 4)) return SIS3D_EINVAL;
+    if ((cin % CK) || (cout % 4) || (out_stride % 4) || (out_coff % 4) || out_stride < out_coff + cout) return SIS3D_EUNSUPPORTED;
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    if ((int64_t)X * Y * Z * cin_stride > 0x7fffffffLL) return SIS3D_EUNSUPPORTED;
+    B16Args a;
+    for (int p = 0; p < B16_MAXP; ++p) {
+        const int s = p < nprob ? p : 0;
+        if (!ins[s] || !packed_ws[s] || !outs[s]) return SIS3D_EINVAL;
+        a.in[p] = ins[s]; a.wp[p] = (const uint4 *)packed_ws[s]; a.bias[p] = biases ? biases[s] : nullptr; a.out[p] = outs[s];
+    }
+    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
+    hipStream_t st = as_stream(stream);
+    if (brick < 0) {
+        // two cout tiles per workgroup (an A fragment feeds six instructions) whenever that still fills the chip, on the
+        // larger brick first; else one tile per workgroup (measured on the four layer shapes of a 96x48x96 chunk, tools/b16_time.py)
+        const int64_t b666 = (int64_t)cdiv(X, 6) * cdiv(Y, 6) * cdiv(Z, 6), b366 = (int64_t)cdiv(X, 3) * cdiv(Y, 6) * cdiv(Z, 6);
+        const int64_t pairs = (a.ntiles + 1) / 2;
+        if (b666 * pairs * nprob >= 224) brick = 3;
+        else if (b366 * pairs * nprob >= 224) brick = 4;
+        else if (b666 * a.ntiles * nprob >= 224) brick = 1;
+        else brick = 2;
+    }
+    switch (brick) {
+    case 1: return launch_b16<6, 6, 6, 1>(a, nprob, st);
+    case 2: return launch_b16<3, 6, 6, 1>(a, nprob, st);
+    case 3: return launch_b16<6, 6, 6, 2>(a, nprob, st);
+    case 4: return launch_b16<3, 6, 6, 2>(a, nprob, st);
+    default: return SIS3D_EINVAL;
+    }
+}

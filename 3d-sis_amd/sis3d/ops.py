@@ -478,6 +478,8 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     _, cin_t, X, Y, Z = x0.shape
     if cin_t != p0.cin:
         raise _lib.Sis3dError("conv3d_k3t16: activation has %d channels, packed weight expects %d" % (cin_t, p0.cin))
+    if SPLIT_BF16 and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs):
+        return conv3d_k3b16(xs, pcs, None, relu=relu, outs=outs, out_coff=out_coff)
     if outs is None:
         outs, out_coff = [new_act(p0.cout, (X, Y, Z), x0.device) for _ in range(n)], 0
     for o in outs:
@@ -496,6 +498,54 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     return outs
 
 
+# set_split_bf16() / SIS3D_SPLIT_BF16=1: route the balanced k3 convs (conv3d_k3t16 calls) through the split-bf16 kernel
+SPLIT_BF16 = bool(int(_os.environ.get("SIS3D_SPLIT_BF16", "0") or 0))
+
+
+def set_split_bf16(on):
+    """OPT-IN numerics switch (default off = exact fp32): the k3 convs that run on conv3d_k3t16 -- rpn_net_level*, geometry2[0],
+    Bottleneck.conv2 of the unfused blocks -- take csrc/conv3d_b16.hip instead (bf16 matrix pipe, operands split hi + lo, three
+    products, fp32 accumulate: ~5e-6 of the output scale per layer, tests/test_gpu_conv_b16.py).  Read at launch / capture time."""
+    global SPLIT_BF16
+    SPLIT_BF16 = bool(on)
+
+
+def packed_b16(pc, weight=None):
+    """split-bf16 fragment pack of a k3 PackedConv's weight (sis3d_conv_k3b16_pack_weight), built on first use"""
+    if getattr(pc, "_packed_b16", None) is None:
+        weight = pc._w if weight is None else weight
+        w = _dev(weight.detach(), "weight").contiguous()
+        if w.shape[1] != pc.cin:
+            raise _lib.Sis3dError("split-bf16 conv: cin must be a multiple of 32")
+        n = lib().sis3d_conv_k3b16_packed_floats(pc.cout, pc.cin)
+        if n == 0:
+            raise Sis3dUnsupported("split-bf16 conv: cin % 32 != 0")
+        pc._packed_b16 = torch.empty(n, device=w.device)
+        check(lib().sis3d_conv_k3b16_pack_weight(_ptr(w), pc.cout, pc.cin, _ptr(pc._packed_b16), _stream()), "sis3d_conv_k3b16_pack_weight")
+    return pc._packed_b16
+
+
+def conv3d_k3b16(xs, pcs, weights=None, relu=True, outs=None, out_coff=0, brick=-1):
+    """OPTIONAL split-bf16 variant of conv3d_k3t16 (csrc/conv3d_b16.hip): same shapes and layouts, ~2^-16 relative error per
+    product instead of exact fp32.  weights: the fp32 nn.Conv3d weights the PackedConvs were made from."""
+    n = len(xs)
+    x0, p0 = xs[0], pcs[0]
+    _, cin_t, X, Y, Z = x0.shape
+    if outs is None:
+        outs, out_coff = [new_act(p0.cout, (X, Y, Z), x0.device) for _ in range(n)], 0
+    arr = ctypes.c_void_p * n
+    ins = arr(*[x.data_ptr() for x in xs])
+    wps = arr(*[packed_b16(pc, w).data_ptr() for pc, w in zip(pcs, weights or [None] * n)])
+    bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
+    os_ = arr(*[o.data_ptr() for o in outs])
+    rc = lib().sis3d_conv3d_k3b16(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, EPI_RELU if relu else 0, os_, outs[0].shape[1],
+                                  int(out_coff), int(brick), _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("conv3d_k3b16: unsupported shape")
+    check(rc, "sis3d_conv3d_k3b16")
+    return outs
+
+
 BNECK_SPLIT = bool(_os.environ.get("SIS3D_BNECK_SPLIT"))  # A/B switch: Bottleneck body as k3t16 + pointwise launches
 
 
@@ -508,6 +558,10 @@ def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick
         raise Sis3dUnsupported("no fused Bottleneck pack")
     if not is_cl(y1) or not is_cl(residual):
         raise _lib.Sis3dError("bottleneck16 expects channels-last activations")
+    if SPLIT_BF16 and y1.shape[2] * y1.shape[3] * y1.shape[4] >= 32768:
+        # split-bf16 mode: on the 48x24x48 maps conv2 on the bf16 pipe + the pointwise launch (15.6 + 9 us) beat the fused fp32
+        # body (31-34 us); the small-grid blocks stay on the fused kernel
+        raise Sis3dUnsupported("split-bf16 mode: two-launch Bottleneck body")
     _, pl, X, Y, Z = y1.shape
     od = (X, Y, Z)
     if (pc2.cin, pc2.cout, pc2.k, pc3.cin, pc3.k) != (pl, pl, 3, pl, 1) or tuple(residual.shape[2:]) != od or residual.shape[1] != pc3.cout:
@@ -694,6 +748,7 @@ class PackedConv:
                   "sis3d_conv_pw16_pack_weight")
         # second pack for the balanced k3 kernel (csrc/conv3d_t16.hip): [cout/16][cin/32][4][27][64][2]
         self.packed_t16 = None
+        self._w = w if (k == 3 and self.cin % 32 == 0) else None       # kept for the optional split-bf16 pack (packed_b16)
         if k == 3 and self.cin % 32 == 0 and self.cout % 4 == 0 and not K3_LEGACY:
             nt = lib().sis3d_conv_k3t16_packed_floats(self.cout, self.cin)
             self.packed_t16 = torch.empty(nt, device=w.device)
