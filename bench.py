@@ -556,8 +556,11 @@ def main(argv=None):
             # SEPARATELY REPORTED (never the headline): the same workload with the balanced k3 convs on the bf16 matrix
             # pipe, operands split hi + lo (csrc/conv3d_b16.hip); `value` above stays on the exact-fp32 kernels
             ops.set_split_bf16(True)
+            st2 = None
             try:
                 r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False)
+                if stages is not None:
+                    st2 = time_stages(net)
             finally:
                 ops.set_split_bf16(False)
             diffs = {}
@@ -569,6 +572,8 @@ def main(argv=None):
                 "value": r2["vox_per_step"] * args.steps / r2["dt"], "unit": "voxels/s", "ms_per_step": r2["dt"] / args.steps * 1e3,
                 "single_chunk_latency_ms": r2["single_ms"], "speedup_vs_value": (r2["vox_per_step"] / r2["dt"]) / (res["vox_per_step"] / res["dt"]),
                 "max_abs_diff_vs_fp32_path": diffs,
+                **({"stages": {k: (v if not isinstance(v, dict) else {"ms": v["ms"], "hbm_frac": v["hbm_frac"], "voxels_per_s": v["voxels_per_s"]})
+                               for k, v in st2.items() if k != "how"}} if st2 else {}),
                 "arithmetic": "k3 convs that run on conv3d_k3t16 (rpn_net x2, geometry2[0], Bottleneck conv2 of the unfused blocks): "
                               "v_mfma_f32_16x16x32_bf16 on operands split x = hi + lo, products ah*bh + ah*bl + al*bh, fp32 accumulate; "
                               "everything else exact fp32",
