@@ -548,6 +548,19 @@ def main(argv=None):
             sv = solo["vox_per_step"] * solo["steps"] / solo["dt"]
             side["scene_single_gpu"] = {"value": sv, "unit": "voxels/s", "ms_per_scene": solo["dt"] / solo["steps"] * 1e3,
                                         "steps": solo["steps"], "how": "rank 0 alone, same scene, same process, no collective"}
+        if not args.masks and not args.no_split_line and not args.no_graph:
+            # SEPARATELY REPORTED, as at N = 1: the same scene on every rank with the balanced k3 convs on the split-bf16 kernel
+            # (every rank takes part: the gather is a collective)
+            ops.set_split_bf16(True)
+            try:
+                r2 = run_scene(net, args, rank, world, args.scene_chunks, barrier, steps=max(3, args.steps // 4))
+            finally:
+                ops.set_split_bf16(False)
+            dt2 = max_over_ranks(r2["dt"])
+            side["split_bf16"] = {"value": r2["vox_per_step"] * r2["steps"] / dt2, "unit": "voxels/s", "ms_per_step": dt2 / r2["steps"] * 1e3,
+                                  "steps": r2["steps"], "records_gathered": r2["extra"]["records_gathered"],
+                                  "kept_after_scene_nms": r2["extra"]["kept_after_scene_nms"],
+                                  "status": "opt-in (ops.set_split_bf16), NOT the headline; see profiles/r02_split_bf16.md"}
     else:
         res = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
         dt = max_over_ranks(res["dt"])

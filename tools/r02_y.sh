@@ -1,11 +1,9 @@
 #!/bin/bash
-for wl in backbone_rpn detect; do
-timeout 300 python bench.py --no-cpu-baseline --workload $wl 2> /tmp/b.err | tail -1 > gpurun_out/bench_split_$wl.json; tail -2 /tmp/b.err
-python - $wl <<'PY'
-import json, sys
-d=json.load(open("gpurun_out/bench_split_%s.json" % sys.argv[1]))
-s=d.get("split_bf16") or {}
-print(sys.argv[1], "fp32 %.1f M (%.3f ms, single %.3f) | split %.1f M (%.3f ms, single %.3f) stages %s" % (d["value"]/1e6, d["ms_per_step"], d["config"]["single_chunk_latency_ms"], s.get("value",0)/1e6, s.get("ms_per_step",0), s.get("single_chunk_latency_ms",0), {k:round(v["ms"],4) for k,v in s.get("stages",{}).items()}))
+SIS3D_FORCE_DIST=1 timeout 300 python bench.py --workload scene --steps 20 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_scene_split.json
+SIS3D_FORCE_DIST=1 timeout 300 python bench.py --workload scene --scene-chunks 4 --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_scene4_split.json
+python - <<'PY'
+import json
+for n in ("scene","scene4"):
+    d=json.load(open("gpurun_out/bench_%s_split.json"%n)); s=d["split_bf16"]
+    print(n, "fp32 %.3f ms %.0f M | split %.3f ms %.0f M records %d kept %d (fp32 kept %d)" % (d["ms_per_step"], d["value"]/1e6, s["ms_per_step"], s["value"]/1e6, s["records_gathered"], s["kept_after_scene_nms"], d["config"]["kept_after_scene_nms"]))
 PY
-done
-timeout 300 python tools/b16_time.py 2>&1 | grep " us " > gpurun_out/b16_time.txt; cat gpurun_out/b16_time.txt | head -3
