@@ -43,6 +43,15 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// ragged batch descriptor (the mask head: all detected boxes' crops in one launch); layout shared with conv3d_t16.hip
+struct B16Ragged {
+    int X, Y, Z;
+    int nbx, nby, nbz;
+    int block0;
+    int pad;
+    int64_t in_off, out_off;
+};
+
 struct B16Args {
     const float *in[B16_MAXP];
     const uint4 *wp[B16_MAXP];          // packed split weights
@@ -53,6 +62,8 @@ struct B16Args {
     int cout, ntiles, nq, flags;
     int out_stride, out_coff;
     int nbx, nby, nbz;
+    const B16Ragged *rag;
+    int nrag;
 };
 
 // fp32 pair -> packed bf16 pair (round to nearest even) and the bf16 pair of the remainders
@@ -88,7 +99,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     }
     const int prob = blockIdx.y;
     const float *__restrict__ p_in = a.in[prob];
-    const int gX = a.X, gY = a.Y, gZ = a.Z, nby = a.nby, nbz = a.nbz;
+    int gX = a.X, gY = a.Y, gZ = a.Z, nby = a.nby, nbz = a.nbz;
+    int64_t out_off = 0;
+    if (a.nrag > 0) {
+        int lo = 0, hi = a.nrag - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.rag[mid].block0 <= wid) lo = mid; else hi = mid - 1;
+        }
+        const B16Ragged d = a.rag[lo];
+        wid -= d.block0;
+        gX = d.X; gY = d.Y; gZ = d.Z; nby = d.nby; nbz = d.nbz;
+        p_in += d.in_off;
+        out_off = d.out_off;
+    }
     const int ngrp = (a.ntiles + NTC - 1) / NTC;            // workgroups per brick
     const int nt = (wid % ngrp) * NTC;                      // first cout tile of this workgroup
     const int brick = wid / ngrp;
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
             for (int rr = 0; rr < 4; ++rr) red[(t * NTC + n) * 256 + (4 * kq + rr) * 16 + li] = acc[t][n][rr];
     __syncthreads();
     const int row = lane >> 2, c4 = lane & 3;
-    float *__restrict__ p_out = a.out[prob];
+    float *__restrict__ p_out = a.out[prob] + out_off;
     for (int t = wave; t < MT; t += 4) {
         const int m = 16 * t + row;
         const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
@@ -303,7 +327,7 @@ __global__ __launch_bounds__(256) void pack_weight_b16_kernel(const float *__res
 }
 
 template <int BX, int BY, int BZ, int NTC>
-int launch_b16(B16Args &a, int nprob, hipStream_t st)
+int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
     constexpr int ROWS = (BX + 2) * (BY + 2) * (BZ + 2);
@@ -313,7 +337,7 @@ int launch_b16(B16Args &a, int nprob, hipStream_t st)
     a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
     auto kern = conv3d_k3b16_kernel<BX, BY, BZ, NTC>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * ((a.ntiles + NTC - 1) / NTC);
+    const int64_t nwg = ragged_blocks > 0 ? ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * ((a.ntiles + NTC - 1) / NTC);
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(256), lds, st, a);
     return sis3d_check_launch();
@@ -356,6 +380,7 @@ extern "C" int sis3d_conv3d_k3b16(int nprob, const float *const *ins, int X, int
     }
     a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
+    a.rag = nullptr; a.nrag = 0;
     hipStream_t st = as_stream(stream);
     if (brick < 0) {
         // two cout tiles per workgroup (an A fragment feeds six instructions) whenever that still fills the chip, on the
@@ -373,5 +398,37 @@ extern "C" int sis3d_conv3d_k3b16(int nprob, const float *const *ins, int X, int
     case 3: return launch_b16<6, 6, 6, 2>(a, nprob, st);
     case 4: return launch_b16<3, 6, 6, 2>(a, nprob, st);
     default: return SIS3D_EINVAL;
+    }
+}
+
+// ---- ragged batch (the mask head, lib/nets/network.py:303-317): the caller tiles every crop with the brick of `brick`
+// (2: 3x6x6 x 1 cout tile per workgroup, 4: 3x6x6 x 2 tiles) and numbers the workgroups crop by crop
+extern "C" int sis3d_ragged_tiling_k3b16(int cin, int cout, int brick, int *bx, int *by, int *bz, int *ngroups)
+{
+    if (!bx || !by || !bz || !ngroups) return SIS3D_EINVAL;
+    if ((cin % CK) || (cout % 4) || (brick != 2 && brick != 4)) return SIS3D_EUNSUPPORTED;
+    *bx = 3; *by = 6; *bz = 6;
+    const int ntiles = (cout + 15) / 16;
+    *ngroups = brick == 4 ? (ntiles + 1) / 2 : ntiles;
+    return SIS3D_OK;
+}
+
+extern "C" int sis3d_conv3d_k3b16_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                                         int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks,
+                                         int brick, sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || !desc_dev || ndesc <= 0 || total_blocks <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
+    if ((cin % CK) || (cout % 4) || (cin_stride % 4) || cin_stride < cin || (out_stride % 4) || out_stride < cout) return SIS3D_EUNSUPPORTED;
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    B16Args a;
+    for (int p = 0; p < B16_MAXP; ++p) { a.in[p] = in; a.wp[p] = (const uint4 *)packed_w; a.bias[p] = bias; a.out[p] = out; }
+    a.X = a.Y = a.Z = 1; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = 0;
+    a.rag = (const B16Ragged *)desc_dev; a.nrag = ndesc;
+    hipStream_t st = as_stream(stream);
+    switch (brick) {
+    case 2: return launch_b16<3, 6, 6, 1>(a, 1, st, total_blocks);
+    case 4: return launch_b16<3, 6, 6, 2>(a, 1, st, total_blocks);
+    default: return SIS3D_EUNSUPPORTED;
     }
 }

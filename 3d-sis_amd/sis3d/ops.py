@@ -1048,6 +1048,21 @@ class MaskPlan:
                 d3t["in_off"] = voffs[:-1] * C
                 d3t["out_off"] = voffs[:-1] * C
                 self.t16, self.brick_t16, self.blocks_t16 = True, brick, int(blt[-1])
+        # the same layers on the opt-in split-bf16 kernel (csrc/conv3d_b16.hip): 3x6x6 bricks, two cout tiles per workgroup
+        self.b16, self.brick_b16, self.blocks_b16 = False, 4, 0
+        d3b = np.zeros(0, dtype=rdt)
+        tb = [ctypes.c_int() for _ in range(4)]
+        if C % 32 == 0 and lib().sis3d_ragged_tiling_k3b16(C, C, self.brick_b16, *[ctypes.byref(v) for v in tb]) == 0:
+            bbx, bby, bbz, bng = (v.value for v in tb)
+            nbb = -(-ext // np.array([bbx, bby, bbz]))
+            blb = np.concatenate([[0], np.cumsum(nbb.prod(1) * bng)])
+            d3b = np.zeros(n, dtype=rdt)
+            d3b["X"], d3b["Y"], d3b["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
+            d3b["nbx"], d3b["nby"], d3b["nbz"] = nbb[:, 0], nbb[:, 1], nbb[:, 2]
+            d3b["block0"] = blb[:-1]
+            d3b["in_off"] = voffs[:-1] * C
+            d3b["out_off"] = voffs[:-1] * C
+            self.b16, self.blocks_b16 = True, int(blb[-1])
         dp["x0"], dp["y0"], dp["z0"] = w[:, 0], w[:, 1], w[:, 2]
         dp["dx"], dp["dy"], dp["dz"] = ext[:, 0], ext[:, 1], ext[:, 2]
         dp["t0"] = voffs[:-1] * (C // 4)
@@ -1057,14 +1072,16 @@ class MaskPlan:
         self.windows = [tuple(int(v) for v in r) for r in w]
         # ONE upload for the three descriptor tables (each is a blocking pageable copy)
         parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1),
-                 d3t.view(np.uint8).reshape(-1)]
+                 d3t.view(np.uint8).reshape(-1), d3b.view(np.uint8).reshape(-1)]
         pad = [(-p.size) % 16 for p in parts]
         host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
         self.devbuf = torch.from_numpy(host).to(device)
         o1 = parts[0].size + pad[0]
         o2 = o1 + parts[1].size + pad[1]
         o3 = o2 + parts[2].size + pad[2]
-        self.g3, self.g1, self.gp, self.g3t = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:o3], self.devbuf[o3:]
+        o4 = o3 + parts[3].size + pad[3]
+        self.g3, self.g1, self.gp = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:o3]
+        self.g3t, self.g3b = self.devbuf[o3:o4], self.devbuf[o4:]
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
         self.out = torch.empty(self.voxels, NC, device=device)
@@ -1092,7 +1109,10 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
           "sis3d_conv3d_planar2_ragged")
     src, dst = plan.a, plan.b
     for pc in pcs:
-        if plan.t16 and pc.packed_t16 is not None:
+        if SPLIT_BF16 and plan.b16 and getattr(pc, "_w", None) is not None:
+            check(lib().sis3d_conv3d_k3b16_ragged(_ptr(src), C, C, _ptr(packed_b16(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
+                                                  _ptr(plan.g3b), n, plan.blocks_b16, plan.brick_b16, _stream()), "sis3d_conv3d_k3b16_ragged")
+        elif plan.t16 and pc.packed_t16 is not None:
             check(lib().sis3d_conv3d_k3t16_ragged(_ptr(src), C, C, _ptr(pc.packed_t16), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                   _ptr(plan.g3t), n, plan.blocks_t16, plan.brick_t16, _stream()), "sis3d_conv3d_k3t16_ragged")
         else:

@@ -564,14 +564,14 @@ def main(argv=None):
     else:
         res = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
         dt = max_over_ranks(res["dt"])
-        if rank == 0 and world == 1 and workload in ("backbone_rpn", "detect") and not args.masks and not args.no_split_line \
+        if rank == 0 and world == 1 and workload in ("backbone_rpn", "detect", "images") and not args.no_split_line \
                 and not args.no_graph:
             # SEPARATELY REPORTED (never the headline): the same workload with the balanced k3 convs on the bf16 matrix
             # pipe, operands split hi + lo (csrc/conv3d_b16.hip); `value` above stays on the exact-fp32 kernels
             ops.set_split_bf16(True)
             st2 = None
             try:
-                r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False)
+                r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
                 if stages is not None:
                     st2 = time_stages(net)
             finally:

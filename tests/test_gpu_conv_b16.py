@@ -65,3 +65,37 @@ def test_network_parity_holds_in_split_bf16_mode(oracle):
                                   label="split-bf16 mode")
     if near == 0:
         assert float((p["cls_score"].cpu() - o["cls_score"]).abs().max()) <= 1e-4
+
+
+def test_mask_head_in_split_bf16_mode(oracle):
+    """the ragged mask-head batch with its four 64->64 k3 layers on the split-bf16 kernel (sis3d_conv3d_k3b16_ragged) against the
+    oracle's MaskBackbone on the same crops, at the tolerance of tests/test_gpu_network.py's mask test"""
+    from sis3d import config, ops, synthetic
+    from sis3d.nets import backbones
+    cfg = config.scannet_benchmark_cfg()
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    data = synthetic.synth_chunk(2)
+    windows = [(3, 2, 5, 16, 20, 17), (40, 10, 50, 49, 19, 59), (0, 0, 0, 13, 18, 12), (80, 30, 70, 96, 48, 96), (20, 5, 30, 27, 9, 33)]
+    scene = data.cuda().float()
+    with torch.no_grad():
+        exact = [t.clone() for t in net.mask_backbone.forward_batched(scene, windows)]
+        ops.set_split_bf16(True)
+        try:
+            got = [t.clone() for t in net.mask_backbone.forward_batched(scene, windows)]
+        finally:
+            ops.set_split_bf16(False)
+    on = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
+    worst = 0.0
+    for w, g, e in zip(windows, got, exact):
+        crop = data[:, :, w[0]:w[3], w[1]:w[4], w[2]:w[5]]
+        want = on.mask_backbone(crop)
+        assert g.shape == e.shape == want.shape
+        worst = max(worst, float((g - e).abs().max()))
+        assert float((g.cpu() - want).abs().max()) <= 1e-4
+    print("[split-bf16] mask head, 5 crops: max |split - exact fp32| on the sigmoid outputs = %.2e" % worst)
+    assert worst <= 1e-5

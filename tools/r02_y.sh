@@ -1,9 +1,6 @@
 #!/bin/bash
-SIS3D_FORCE_DIST=1 timeout 300 python bench.py --workload scene --steps 20 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_scene_split.json
-SIS3D_FORCE_DIST=1 timeout 300 python bench.py --workload scene --scene-chunks 4 --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_scene4_split.json
-python - <<'PY'
-import json
-for n in ("scene","scene4"):
-    d=json.load(open("gpurun_out/bench_%s_split.json"%n)); s=d["split_bf16"]
-    print(n, "fp32 %.3f ms %.0f M | split %.3f ms %.0f M records %d kept %d (fp32 kept %d)" % (d["ms_per_step"], d["value"]/1e6, s["ms_per_step"], s["value"]/1e6, s["records_gathered"], s["kept_after_scene_nms"], d["config"]["kept_after_scene_nms"]))
-PY
+timeout 600 python -m pytest tests/test_gpu_conv_b16.py -x -q -s 2>&1 | grep -E "mask head|passed|failed|Error|error|assert" | head -10
+timeout 300 python bench.py --no-cpu-baseline --workload detect --masks 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); s=d.get('split_bf16',{}); print('detect+masks fp32 %.1f M (%.3f ms) | split %.1f M (%.3f ms) single %.3f' % (d['value']/1e6, d['ms_per_step'], s.get('value',0)/1e6, s.get('ms_per_step',0), s.get('single_chunk_latency_ms') or 0))"
+timeout 300 python bench.py --no-cpu-baseline --workload images 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); s=d.get('split_bf16',{}); print('images fp32 %.1f M (%.3f ms) | split %.1f M (%.3f ms) single %.3f' % (d['value']/1e6, d['ms_per_step'], s.get('value',0)/1e6, s.get('ms_per_step',0), s.get('single_chunk_latency_ms') or 0))"
