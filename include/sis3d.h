@@ -425,7 +425,7 @@ int sis3d_cl_to_planar(const float *in, int C, int64_t nvox, float *out, sis3d_s
  * the exact-fp32 arithmetic of the default kernels -- callers opt in per layer (Network.rpn_split_bf16; bench.py --split-bf16
  * reports it as a separate line).  fp32 activations in and out; weights pre-split by sis3d_conv_k3b16_pack_weight (buffer of
  * sis3d_conv_k3b16_packed_floats floats).  cin % 32 == 0.  brick: -1 = chosen by size; 1 = 6x6x6, 2 = 3x6x6 (one 16-cout tile per
- * workgroup); 3 = 6x6x6, 4 = 3x6x6 with two cout tiles per workgroup. */
+ * workgroup); 3 = 6x6x6, 4 = 3x6x6 with two cout tiles per workgroup; 5 = 3x6x6 with four. */
 size_t sis3d_conv_k3b16_packed_floats(int cout, int cin);
 int sis3d_conv_k3b16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
 int sis3d_conv3d_k3b16(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,

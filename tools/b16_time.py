@@ -42,6 +42,6 @@ for cin, cout, dims, name in ((128, 256, (24, 12, 24), "rpn_net 128->256"), (128
     flop = 2.0 * dims[0] * dims[1] * dims[2] * cin * cout * 27
     t = timed(lambda: ops.conv3d_k3t16([x], [pc], relu=True, outs=[y]))
     print("%-24s fp32 t16            %7.1f us  %6.1f TF" % (name, t, flop / t / 1e6))
-    for brick in (1, 2, 3, 4):
+    for brick in (1, 2, 3, 4, 5):
         t = timed(lambda: ops.conv3d_k3b16([x], [pc], [w], relu=True, outs=[y], brick=brick))
         print("%-24s split-bf16 brick %d  %7.1f us  %6.1f TF-equivalent" % (name, brick, t, flop / t / 1e6))
