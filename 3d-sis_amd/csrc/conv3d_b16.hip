@@ -13,12 +13,13 @@
 // Structure (as conv3d_t16.hip unless noted): workgroup = 4 waves = a BX x BY x BZ brick x one 16-wide cout tile; the halo brick
 // of one 32-channel chunk is staged in LDS as rows of [32 hi | 32 lo] bf16 (128 B + 16 B pad, the footprint of the fp32 image),
 // converted on the way from the fp32 activations (v_cvt_pk_bf16_f32); a matrix instruction consumes all 32 channels of a chunk,
-// so the four waves split the 27 TAPS (7 / 7 / 7 / 6, the short share rotating with the chunk) instead of the channels, and
+// so the four waves split the 27 TAPS (7 / 7 / 7 / 6) instead of the channels, and
 // their partial tiles are summed through LDS at the end.  A tap is an immediate offset of two ds_read_b128 (hi, lo) that feed
 // three MFMAs; weights are pre-split into fragment order ([tile][chunk][tap][hi|lo][lane][8]) and a chunk's seven taps are
 // requested one chunk ahead.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -64,6 +65,7 @@ struct B16Args {
     int nbx, nby, nbz;
     const B16Ragged *rag;
     int nrag;
+    long long *dbg;                     // tools/b16_phases.py: wall_clock64() of every wave at 16 phase boundaries, or NULL
 };
 
 // fp32 pair -> packed bf16 pair (round to nearest even) and the bf16 pair of the remainders
@@ -92,6 +94,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
+    auto stamp = [&](int k) {
+        if (a.dbg && lane == 0) a.dbg[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + wave) * 16 + k] = (long long)wall_clock64();
+    };
+    stamp(0);
     int wid;
     {
         const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
@@ -164,22 +170,27 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
         });
     };
 
-    // B operand of this wave for chunk q: taps [TPW r, TPW r + n), r = (wave + q) & 3 (the 6-tap share rotates), hi and lo
-    // fragment of every (tap, cout tile) = 16 B per lane each: packed [ntile][chunk][tap][2][64] uint4.  All of a chunk's
-    // slots sit in registers; slot ts is refilled for the NEXT chunk as soon as its last matrix instruction has been issued.
-    const uint4 *bp = a.wp[prob] + lane;
+    // B operand: wave w owns taps [TPW w, TPW w + 7) (wave 3: six taps -- a fixed 27/28 balance; rotating the short share with
+    // the chunk made every refill address a run-time select and the compiler serialised those loads, see profiles/r02_split_bf16.md).
+    // hi and lo fragment of every (tap, cout tile) = 16 B per lane each, packed [ntile][chunk][tap][2][64] uint4.  All of a chunk's
+    // slots sit in registers; slot ts is refilled for the NEXT chunk right after its last matrix instruction (the last chunk
+    // re-requests its own fragments: no branch around the loads).
     constexpr int TS = 2 * 64, QS = TAPS * TS;              // uint4 strides of a tap / a chunk
-    const size_t tile_stride = (size_t)a.nq * QS;
+    const uint4 *bsrc[NTC];
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) {
+        const int tile = (nt + n < a.ntiles) ? nt + n : a.ntiles - 1;          // a surplus tile recomputes the last one, never stored
+        const int tap0 = TPW * wave;
+        bsrc[n] = a.wp[prob] + lane + (size_t)tile * a.nq * QS + (size_t)tap0 * TS;
+    }
     uint4 bw[TPW][NTC][2];
     auto load_slot = [&](int q, auto T) {
         constexpr int t = decltype(T)::value;
-        const int r = (wave + q) & 3;
-        // the share of rank 3 has TAPS - 3 TPW = 6 taps: its 7th slot re-reads tap 26 and is never used
-        const int tap = (TPW * r + t < TAPS) ? TPW * r + t : TAPS - 1;
+        // wave 3's seventh slot (tap 27 does not exist) re-reads its sixth and is never used
+        const int tt = (wave == 3 && t == TPW - 1) ? t - 1 : t;
         static_for<0, NTC>([&](auto N) {
             constexpr int n = decltype(N)::value;
-            const int tile = (nt + n < a.ntiles) ? nt + n : a.ntiles - 1;      // a surplus tile recomputes the last one, never stored
-            const uint4 *src = bp + (size_t)tile * tile_stride + (size_t)q * QS + (size_t)tap * TS;
+            const uint4 *src = bsrc[n] + (size_t)q * QS + (size_t)tt * TS;
             bw[t][n][0] = src[0];
             bw[t][n][1] = src[64];
         });
@@ -191,8 +202,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
 #pragma unroll
         for (int n = 0; n < NTC; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    static_for<0, TPW>([&](auto T) { load_slot(0, T); });
-    stage_load(0);
+    stage_load(0);                                          // first: the LDS stores below wait for these only,
+    static_for<0, TPW>([&](auto T) { load_slot(0, T); });   // the weight fragments keep arriving under the first taps
     __builtin_amdgcn_sched_barrier(0);
     int abase[MT];
 #pragma unroll
@@ -204,13 +215,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     }
     __builtin_amdgcn_sched_barrier(0);
     stage_store();
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     const int nq = a.nq;
     for (int q = 0; q < nq; ++q) {
         const bool more = q + 1 < nq;
         if (more) stage_load(q + 1);
-        const int r = (wave + q) & 3;
+        const int r = wave;
+        const int qn = more ? q + 1 : q;                   // chunk whose fragments the slots are refilled with
         // taps [TPW R, TPW R + NTAP) x NG groups of G tiles; per group 2 G reads (hi, lo) and 3 G NTC matrix instructions
         auto run_taps = [&](auto R_) {
             constexpr int R = decltype(R_)::value;
@@ -251,20 +265,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
                     });
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (g == NG - 1)
-                    if (more) load_slot(q + 1, std::integral_constant<int, ts>{});      // this slot's last use is behind us
+                if constexpr (g == NG - 1) load_slot(qn, std::integral_constant<int, ts>{});      // this slot's last use is behind us
             });
-            if constexpr (NTAP < TPW)
-                if (more) load_slot(q + 1, std::integral_constant<int, TPW - 1>{});
         };
         static_for<0, 4>([&](auto R_) {
             if (r == decltype(R_)::value) run_taps(R_);
         });
+        if (q < 4) stamp(3 + 3 * q);                       // matrix loop of chunk q done
         __syncthreads();                                   // every wave is done with chunk q's image
+        if (q < 4) stamp(4 + 3 * q);
         if (more) {
             stage_store();
             __syncthreads();
         }
+        if (q < 4) stamp(5 + 3 * q);
     }
 
     // ---- cross-wave reduction + epilogue, as conv3d_k3t16_kernel: tile (t, n) of wave w at [w][t][n][16 voxels][16 couts]
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
                 *reinterpret_cast<float4 *>(p_out + ((size_t)(ox * gY + oy) * gZ + oz) * a.out_stride + a.out_coff + co) = v;
         }
     }
+    stamp(15);
 }
 
 // (Cout,Cin,3,3,3) fp32 -> [cout/16][cin/32][tap 27][hi|lo][lane 64][8] bf16: lane (j = lane & 15, kb = lane >> 4), element e
@@ -326,9 +341,12 @@ __global__ __launch_bounds__(256) void pack_weight_b16_kernel(const float *__res
     }
 }
 
+std::atomic<long long *> g_b16_dbg{nullptr};   // sis3d_conv3d_k3b16_set_trace
+
 template <int BX, int BY, int BZ, int NTC>
 int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 {
+    a.dbg = g_b16_dbg.load(std::memory_order_relaxed);
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
     constexpr int ROWS = (BX + 2) * (BY + 2) * (BZ + 2);
     constexpr size_t img = (size_t)ROWS * RSB, red = (size_t)4 * MT * NTC * 256 * sizeof(float);
@@ -344,6 +362,12 @@ int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 }
 
 } // namespace
+
+extern "C" int sis3d_conv3d_k3b16_set_trace(void *buf)
+{
+    g_b16_dbg.store((long long *)buf, std::memory_order_relaxed);
+    return SIS3D_OK;
+}
 
 extern "C" size_t sis3d_conv_k3b16_packed_floats(int cout, int cin)
 {
