@@ -66,6 +66,7 @@ struct B16Args {
     const B16Ragged *rag;
     int nrag;
     long long *dbg;                     // tools/b16_phases.py: wall_clock64() of every wave at 16 phase boundaries, or NULL
+    int dbg_cap;                        // workgroups the buffer holds
 };
 
 // fp32 pair -> packed bf16 pair (round to nearest even) and the bf16 pair of the remainders
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     const int li = lane & 15, kq = lane >> 4;
 
     auto stamp = [&](int k) {
-        if (a.dbg && lane == 0) a.dbg[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + wave) * 16 + k] = (long long)wall_clock64();
+        const int fb = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+        if (a.dbg && lane == 0 && fb < a.dbg_cap) a.dbg[((size_t)fb * 4 + wave) * 16 + k] = (long long)wall_clock64();
     };
     stamp(0);
     int wid;
@@ -342,11 +344,13 @@ __global__ __launch_bounds__(256) void pack_weight_b16_kernel(const float *__res
 }
 
 std::atomic<long long *> g_b16_dbg{nullptr};   // sis3d_conv3d_k3b16_set_trace
+std::atomic<int> g_b16_dbg_cap{0};
 
 template <int BX, int BY, int BZ, int NTC>
 int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 {
     a.dbg = g_b16_dbg.load(std::memory_order_relaxed);
+    a.dbg_cap = g_b16_dbg_cap.load(std::memory_order_relaxed);
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
     constexpr int ROWS = (BX + 2) * (BY + 2) * (BZ + 2);
     constexpr size_t img = (size_t)ROWS * RSB, red = (size_t)4 * MT * NTC * 256 * sizeof(float);
@@ -363,8 +367,10 @@ int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 
 } // namespace
 
-extern "C" int sis3d_conv3d_k3b16_set_trace(void *buf)
+extern "C" int sis3d_conv3d_k3b16_set_trace(void *buf, int capacity_blocks)
 {
+    if (buf && capacity_blocks <= 0) return SIS3D_EINVAL;
+    g_b16_dbg_cap.store(buf ? capacity_blocks : 0, std::memory_order_relaxed);
     g_b16_dbg.store((long long *)buf, std::memory_order_relaxed);
     return SIS3D_OK;
 }

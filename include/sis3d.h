@@ -433,9 +433,9 @@ int sis3d_conv3d_k3b16(int nprob, const float *const *ins, int X, int Y, int Z, 
                        int out_stride, int out_coff, int brick, sis3d_stream_t stream);
 /* ragged batch of crops (the mask head), as sis3d_conv3d_k3t16_ragged: descriptors {X,Y,Z,nbx,nby,nbz,block0,pad,in_off,out_off};
  * brick 2 = 3x6x6 with one cout tile per workgroup, 4 = 3x6x6 with two (sis3d_ragged_tiling_k3b16 gives workgroups per brick) */
-/* profiling hook (tools/b16_phases.py): later launches write wall_clock64() of every wave at 16 phase boundaries into buf
- * ([workgroup][4 waves][16] int64, device memory); NULL switches it off */
-int sis3d_conv3d_k3b16_set_trace(void *buf);
+/* profiling hook (tools/b16_phases.py): later launches write wall_clock64() of every wave of their first capacity_blocks
+ * workgroups at 16 phase boundaries into buf ([workgroup][4 waves][16] int64, device memory); NULL switches it off */
+int sis3d_conv3d_k3b16_set_trace(void *buf, int capacity_blocks);
 int sis3d_ragged_tiling_k3b16(int cin, int cout, int brick, int *bx, int *by, int *bz, int *ngroups);
 int sis3d_conv3d_k3b16_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
                               int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks,

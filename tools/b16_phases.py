@@ -24,10 +24,10 @@ for _ in range(10):
 torch.cuda.synchronize()
 nwg = 2048
 buf = torch.zeros(nwg, 4, 16, dtype=torch.int64, device="cuda")
-lib.sis3d_conv3d_k3b16_set_trace(ops._ptr(buf))
+lib.sis3d_conv3d_k3b16_set_trace(ops._ptr(buf), nwg)
 run()
 torch.cuda.synchronize()
-lib.sis3d_conv3d_k3b16_set_trace(None)
+lib.sis3d_conv3d_k3b16_set_trace(None, 0)
 t = buf.cpu().numpy()
 used = t[:, 0, 0] > 0
 t = t[used].astype(np.float64)
