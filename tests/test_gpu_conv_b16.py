@@ -99,3 +99,21 @@ def test_mask_head_in_split_bf16_mode(oracle):
         assert float((g.cpu() - want).abs().max()) <= 1e-4
     print("[split-bf16] mask head, 5 crops: max |split - exact fp32| on the sigmoid outputs = %.2e" % worst)
     assert worst <= 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,dims,brick", [(128, 256, (24, 12, 24), -1), (64, 64, (13, 9, 11), 2), (32, 48, (7, 9, 13), 3), (96, 80, (6, 12, 18), 4)])
+def test_split_bf16_kernel_vs_its_own_restatement(oracle, cin, cout, dims, brick):
+    """the kernel against oracle.conv3d_split_bf16 (same split, same three products, float64 sums): agreement to fp32 summation noise
+    -- i.e. the kernel computes exactly the arithmetic it claims -- and an edge-padded odd grid"""
+    from sis3d import ops
+    g = torch.Generator().manual_seed(7 * cin + cout)
+    x = torch.randn(1, cin, *dims, generator=g).clamp_(min=0)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    want = oracle.conv3d_split_bf16(x, w, b, relu=True)
+    pc = ops.PackedConv(w.cuda(), b.cuda())
+    got = ops.conv3d_k3b16([ops.to_cl(x.cuda())], [pc], relu=True, brick=brick)[0].cpu()
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max()) / scale
+    print("[split-bf16] kernel vs its restatement %d->%d %s: %.2e of max|y|" % (cin, cout, dims, err))
+    assert err <= 1e-6
