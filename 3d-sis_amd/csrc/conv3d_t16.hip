@@ -388,8 +388,7 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     return sis3d_check_launch();
 }
 
-std::atomic<int> g_brick_cap{0};
-          // sis3d_conv3d_k3t16_set_brick_cap
+std::atomic<int> g_brick_cap{0};          // sis3d_conv3d_k3t16_set_brick_cap
 
 struct Brick { int bx, by, bz; };
 constexpr Brick BRICKS[] = {{6, 6, 12}, {6, 6, 6}, {3, 6, 6}, {3, 3, 6}, {4, 4, 4}, {4, 4, 8}, {4, 8, 8}};
