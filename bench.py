@@ -85,6 +85,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--no-split-line", action="store_true", help="skip the separately reported split-bf16 measurement")
+    ap.add_argument("--split-line-multi", action="store_true", help="N > 1: also time the scene in split-bf16 mode (collective on every rank)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # launch / rendezvous logic under gloo, no GPU
     return ap.parse_args(argv)
@@ -548,9 +549,10 @@ def main(argv=None):
             sv = solo["vox_per_step"] * solo["steps"] / solo["dt"]
             side["scene_single_gpu"] = {"value": sv, "unit": "voxels/s", "ms_per_scene": solo["dt"] / solo["steps"] * 1e3,
                                         "steps": solo["steps"], "how": "rank 0 alone, same scene, same process, no collective"}
-        if not args.masks and not args.no_split_line and not args.no_graph:
+        if not args.masks and not args.no_split_line and not args.no_graph and (world == 1 or args.split_line_multi):
             # SEPARATELY REPORTED, as at N = 1: the same scene on every rank with the balanced k3 convs on the split-bf16 kernel
-            # (every rank takes part: the gather is a collective)
+            # (every rank takes part: the gather is a collective -- which is why at N > 1 it runs only on request: an error on one
+            # rank inside an optional side measurement must not be able to hang the scaling run)
             ops.set_split_bf16(True)
             try:
                 r2 = run_scene(net, args, rank, world, args.scene_chunks, barrier, steps=max(3, args.steps // 4))
@@ -568,30 +570,34 @@ def main(argv=None):
                 and not args.no_graph:
             # SEPARATELY REPORTED (never the headline): the same workload with the balanced k3 convs on the bf16 matrix
             # pipe, operands split hi + lo (csrc/conv3d_b16.hip); `value` above stays on the exact-fp32 kernels
-            ops.set_split_bf16(True)
-            st2 = None
             try:
-                r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
-                if stages is not None:
-                    st2 = time_stages(net)
-            finally:
+                ops.set_split_bf16(True)
+                st2 = None
+                try:
+                    r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
+                    if stages is not None:
+                        st2 = time_stages(net)
+                finally:
+                    ops.set_split_bf16(False)
+                diffs = {}
+                if res.get("snap") and r2.get("snap"):
+                    for k in sorted(res["snap"]):
+                        if k in r2["snap"] and res["snap"][k].shape == r2["snap"][k].shape:
+                            diffs[k] = float((res["snap"][k] - r2["snap"][k]).abs().max())
+                side["split_bf16"] = {
+                    "value": r2["vox_per_step"] * args.steps / r2["dt"], "unit": "voxels/s", "ms_per_step": r2["dt"] / args.steps * 1e3,
+                    "single_chunk_latency_ms": r2["single_ms"], "speedup_vs_value": (r2["vox_per_step"] / r2["dt"]) / (res["vox_per_step"] / res["dt"]),
+                    "max_abs_diff_vs_fp32_path": diffs,
+                    **({"stages": {k: (v if not isinstance(v, dict) else {"ms": v["ms"], "hbm_frac": v["hbm_frac"], "voxels_per_s": v["voxels_per_s"]})
+                                   for k, v in st2.items() if k != "how"}} if st2 else {}),
+                    "arithmetic": "k3 convs that run on conv3d_k3t16 (rpn_net x2, geometry2[0], Bottleneck conv2 of the unfused blocks): "
+                                  "v_mfma_f32_16x16x32_bf16 on operands split x = hi + lo, products ah*bh + ah*bl + al*bh, fp32 accumulate; "
+                                  "everything else exact fp32",
+                    "status": "opt-in (ops.set_split_bf16), NOT the headline: not the reference's fp32 arithmetic; parity tests at the "
+                              "unchanged 1e-4 tolerances pass in this mode (tests/test_gpu_conv_b16.py)"}
+            except Exception as e:                       # the separately reported line must never take the headline down
                 ops.set_split_bf16(False)
-            diffs = {}
-            if res.get("snap") and r2.get("snap"):
-                for k in sorted(res["snap"]):
-                    if k in r2["snap"] and res["snap"][k].shape == r2["snap"][k].shape:
-                        diffs[k] = float((res["snap"][k] - r2["snap"][k]).abs().max())
-            side["split_bf16"] = {
-                "value": r2["vox_per_step"] * args.steps / r2["dt"], "unit": "voxels/s", "ms_per_step": r2["dt"] / args.steps * 1e3,
-                "single_chunk_latency_ms": r2["single_ms"], "speedup_vs_value": (r2["vox_per_step"] / r2["dt"]) / (res["vox_per_step"] / res["dt"]),
-                "max_abs_diff_vs_fp32_path": diffs,
-                **({"stages": {k: (v if not isinstance(v, dict) else {"ms": v["ms"], "hbm_frac": v["hbm_frac"], "voxels_per_s": v["voxels_per_s"]})
-                               for k, v in st2.items() if k != "how"}} if st2 else {}),
-                "arithmetic": "k3 convs that run on conv3d_k3t16 (rpn_net x2, geometry2[0], Bottleneck conv2 of the unfused blocks): "
-                              "v_mfma_f32_16x16x32_bf16 on operands split x = hi + lo, products ah*bh + ah*bl + al*bh, fp32 accumulate; "
-                              "everything else exact fp32",
-                "status": "opt-in (ops.set_split_bf16), NOT the headline: not the reference's fp32 arithmetic; parity tests at the "
-                          "unchanged 1e-4 tolerances pass in this mode (tests/test_gpu_conv_b16.py)"}
+                side["split_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     ms = dt / args.steps * 1e3
     value = res["vox_per_step"] * args.steps / dt
 
