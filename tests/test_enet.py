@@ -184,3 +184,28 @@ def test_config4_forward_from_rgb(golden, oracle, dims, n_views, n_per_view, fix
         g = golden(fixture)
         s = int(g["sub"])
         assert float((l1.cpu()[0, :, ::s, ::s, ::s] - torch.from_numpy(g["level1_sub"])).abs().max()) <= 1e-4 * scale
+
+
+def test_folded_encoder_equals_module_tree_cpu():
+    """nets/enet_folded.py (BatchNorm + eval-dropout scale folded into the convolutions) against the module tree it reads, with
+    non-trivial BatchNorm statistics: equal to the rounding of the folded weights; re-folds when a parameter changes"""
+    from sis3d.nets.enet_folded import FoldedEncoder
+    torch.manual_seed(3)
+    m = enet.create_enet(41)
+    g = torch.Generator().manual_seed(4)
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean"):
+            v.copy_(torch.rand(v.shape, generator=g) - 0.5)
+        if k.endswith("running_var"):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    fixed, train, _ = enet.split_enet_for_3d(m)
+    fixed.eval()
+    train.eval()
+    x = torch.randn(2, 3, 64, 80, generator=g)
+    enc = FoldedEncoder(fixed, train)
+    with torch.no_grad():
+        want, got = train(fixed(x)), enc(x)
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+        fixed[2].weight.mul_(1.5)                                # a parameter update must invalidate the folded copy
+        want2, got2 = train(fixed(x)), enc(x)
+        assert float((want2 - want).abs().max()) > 1e-3 and float((got2 - want2).abs().max()) <= 1e-5 * max(1.0, float(want2.abs().max()))
