@@ -108,3 +108,33 @@ def test_pack_and_merge_rules(oracle):
     s = recs[:, 6]
     assert (s[:-1] >= s[1:]).all()
     assert torch.equal(keep, oracle.nms(recs[:, :6].contiguous(), 0.1))
+
+
+def test_merge_fn_contract():
+    """parallel.merge_scene(merge_fn=...): a fused implementation may take the table or refuse it (None -> the torch code runs);
+    either way the caller sees (records, keep[, chunk ids])"""
+    import sis3d_oracle as orc
+    from sis3d import parallel
+    from sis3d.engine import RECORD_WIDTH as W
+    g = torch.Generator().manual_seed(3)
+    k_rows, n_chunks = 5, 3
+    blocks = torch.zeros(n_chunks, 1 + k_rows * W)
+    for c, n in enumerate((5, 0, 3)):
+        rows = torch.zeros(k_rows, W)
+        lo = torch.rand(n, 3, generator=g) * 50 + 60 * c
+        rows[:n, 0:3], rows[:n, 3:6] = lo, lo + 10
+        rows[:n, 6] = torch.rand(n, generator=g)
+        blocks[c, 0], blocks[c, 1:] = n, rows.reshape(-1)
+    want = parallel.merge_scene(blocks, k_rows, orc.nms, 0.1, with_chunk_ids=True)
+    calls = []
+
+    def refuse(b, k, t, sc, bc, mk):
+        calls.append((k, t, sc, bc, mk))
+        return None
+
+    got = parallel.merge_scene(blocks, k_rows, orc.nms, 0.1, with_chunk_ids=True, merge_fn=refuse)
+    assert calls == [(k_rows, 0.1, 6, 0, 0)] and all(torch.equal(a, b) for a, b in zip(got, want))
+    marker = (torch.zeros(1, W), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long))
+    assert parallel.merge_scene(blocks, k_rows, orc.nms, 0.1, merge_fn=lambda *a: marker) == marker[:2]
+    assert parallel.merge_scene(blocks, k_rows, orc.nms, 0.1, with_chunk_ids=True, merge_fn=lambda *a: marker) == marker
+    assert want[0].shape[0] == 8 and want[2].tolist() == sorted(want[2].tolist(), key=lambda c: 0) and set(want[2].tolist()) == {0, 2}
