@@ -81,7 +81,9 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t 
 
 // NTC = cout tiles per workgroup: with 2, an A fragment read from LDS feeds six matrix instructions instead of three -- the
 // kernel with one tile per workgroup is bound by its LDS reads (two ds_read_b128 per three 16-cycle MFMAs on four waves)
-template <int BX, int BY, int BZ, int NTC>
+// CLIP (ragged mask-head launches, as conv3d_k3t16_kernel): a brick that sticks out of its crop enumerates only the voxels inside
+// and runs only the tile groups it has voxels for (one uniform branch per chunk picks the loop body).
+template <int BX, int BY, int BZ, int NTC, bool CLIP = false>
 __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
@@ -126,6 +128,27 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     const int brick = wid / ngrp;
     const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
     const int ox0 = bx * BX, oy0 = by * BY, oz0 = bz * BZ;
+    int cy = BY, cz = BZ, m_act = M, mt_act = MT;
+    uint32_t inv_yz = 0, inv_z = 0;
+    if constexpr (CLIP) {
+        const int cx = min(BX, gX - ox0);
+        cy = min(BY, gY - oy0);
+        cz = min(BZ, gZ - oz0);
+        m_act = cx * cy * cz;
+        mt_act = __builtin_amdgcn_readfirstlane((m_act + 15) >> 4);
+        inv_yz = (65536u + (uint32_t)(cy * cz) - 1u) / (uint32_t)(cy * cz);       // m / d by multiply-shift: exact for m < 512, d <= 144
+        inv_z = (65536u + (uint32_t)cz - 1u) / (uint32_t)cz;
+    }
+    auto voxel_of = [&](int m, int &lx, int &ly, int &lz) {
+        if constexpr (CLIP) {
+            lx = (int)(((uint32_t)m * inv_yz) >> 16);
+            const int rem = m - lx * cy * cz;
+            ly = (int)(((uint32_t)rem * inv_z) >> 16);
+            lz = rem - ly * cz;
+        } else {
+            lx = m / (BY * BZ); ly = (m / BZ) % BY; lz = m % BZ;
+        }
+    };
 
     // halo staging table (element offsets, -1 = outside the grid), as conv3d_k3t16_kernel
     int goff[NIT];
@@ -211,8 +234,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         int m = 16 * t + li;
-        m = m < M ? m : M - 1;
-        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        m = m < m_act ? m : m_act - 1;
+        int lx, ly, lz;
+        voxel_of(m, lx, ly, lz);
         abase[t] = ((lx * IBY + ly) * IBZ + lz) * RSB + kq * 16;          // bytes: channels 8 kq .. 8 kq + 7 of the hi half
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -222,20 +246,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     stamp(2);
 
     const int nq = a.nq;
+    const int nga = CLIP ? (mt_act + G - 1) / G : NG;
     for (int q = 0; q < nq; ++q) {
         const bool more = q + 1 < nq;
         if (more) stage_load(q + 1);
         const int r = wave;
         const int qn = more ? q + 1 : q;                   // chunk whose fragments the slots are refilled with
         // taps [TPW R, TPW R + NTAP) x NG groups of G tiles; per group 2 G reads (hi, lo) and 3 G NTC matrix instructions
-        auto run_taps = [&](auto R_) {
-            constexpr int R = decltype(R_)::value;
+        auto run_taps = [&](auto R_, auto NGA_) {
+            constexpr int R = decltype(R_)::value, NGA = decltype(NGA_)::value;      // NGA: tile groups this brick has (NG unless CLIP)
             constexpr int T0 = TPW * R, NTAP = (T0 + TPW <= TAPS) ? TPW : TAPS - T0;
-            constexpr int NSTEP = NTAP * NG;
+            constexpr int NSTEP = NTAP * NGA;
             bf16x8 ah[2][G], al[2][G];
             auto read_group = [&](auto BUF, auto STEP) {
                 constexpr int buf = decltype(BUF)::value, step = decltype(STEP)::value;
-                constexpr int tap = T0 + step / NG, g = step % NG;
+                constexpr int tap = T0 + step / NGA, g = step % NGA;
                 constexpr int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
                 constexpr int toff = ((dx * IBY + dy) * IBZ + dz) * RSB;
                 static_for<0, G>([&](auto J) {
@@ -249,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
             read_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
             static_for<0, NSTEP>([&](auto STEP) {
                 constexpr int step = decltype(STEP)::value;
-                constexpr int ts = step / NG, g = step % NG;
+                constexpr int ts = step / NGA, g = step % NGA;
                 if constexpr (step + 1 < NSTEP) read_group(std::integral_constant<int, (step + 1) & 1>{}, std::integral_constant<int, step + 1>{});
                 __builtin_amdgcn_sched_barrier(0);
                 // small terms first, the hi * hi product last; the instructions of one accumulator are G NTC instructions apart
@@ -267,11 +292,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
                     });
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (g == NG - 1) load_slot(qn, std::integral_constant<int, ts>{});      // this slot's last use is behind us
+                if constexpr (g == NGA - 1) load_slot(qn, std::integral_constant<int, ts>{});     // this slot's last use is behind us
             });
         };
         static_for<0, 4>([&](auto R_) {
-            if (r == decltype(R_)::value) run_taps(R_);
+            if (r == decltype(R_)::value) {
+                if constexpr (CLIP) {
+                    static_for<1, NG + 1>([&](auto NGA_) {
+                        if (nga == decltype(NGA_)::value) run_taps(R_, NGA_);
+                    });
+                } else {
+                    run_taps(R_, std::integral_constant<int, NG>{});
+                }
+            }
         });
         if (q < 4) stamp(3 + 3 * q);                       // matrix loop of chunk q done
         __syncthreads();                                   // every wave is done with chunk q's image
@@ -296,11 +329,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3b16_kernel(const B16Args a)
     __syncthreads();
     const int row = lane >> 2, c4 = lane & 3;
     float *__restrict__ p_out = a.out[prob] + out_off;
-    for (int t = wave; t < MT; t += 4) {
+    for (int t = wave; t < mt_act; t += 4) {
         const int m = 16 * t + row;
-        const int lx = m / (BY * BZ), ly = (m / BZ) % BY, lz = m % BZ;
+        int lx, ly, lz;
+        voxel_of(m < m_act ? m : 0, lx, ly, lz);
         const int ox = ox0 + lx, oy = oy0 + ly, oz = oz0 + lz;
-        const bool inside = m < M && ox < gX && oy < gY && oz < gZ;
+        const bool inside = m < m_act && ox < gX && oy < gY && oz < gZ;
 #pragma unroll
         for (int n = 0; n < NTC; ++n) {
             const int co = 16 * (nt + n) + 4 * c4;
@@ -346,7 +380,7 @@ __global__ __launch_bounds__(256) void pack_weight_b16_kernel(const float *__res
 std::atomic<long long *> g_b16_dbg{nullptr};   // sis3d_conv3d_k3b16_set_trace
 std::atomic<int> g_b16_dbg_cap{0};
 
-template <int BX, int BY, int BZ, int NTC>
+template <int BX, int BY, int BZ, int NTC, bool CLIP = false>
 int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
 {
     a.dbg = g_b16_dbg.load(std::memory_order_relaxed);
@@ -357,7 +391,7 @@ int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     constexpr size_t lds = img > red ? img : red;
     static_assert(lds <= 160 * 1024, "LDS brick too large");
     a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
-    auto kern = conv3d_k3b16_kernel<BX, BY, BZ, NTC>;
+    auto kern = conv3d_k3b16_kernel<BX, BY, BZ, NTC, CLIP>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t nwg = ragged_blocks > 0 ? ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * ((a.ntiles + NTC - 1) / NTC);
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
@@ -459,8 +493,8 @@ extern "C" int sis3d_conv3d_k3b16_ragged(const float *in, int cin, int cin_strid
     a.rag = (const B16Ragged *)desc_dev; a.nrag = ndesc;
     hipStream_t st = as_stream(stream);
     switch (brick) {
-    case 2: return launch_b16<3, 6, 6, 1>(a, 1, st, total_blocks);
-    case 4: return launch_b16<3, 6, 6, 2>(a, 1, st, total_blocks);
+    case 2: return launch_b16<3, 6, 6, 1, true>(a, 1, st, total_blocks);
+    case 4: return launch_b16<3, 6, 6, 2, true>(a, 1, st, total_blocks);
     default: return SIS3D_EUNSUPPORTED;
     }
 }
