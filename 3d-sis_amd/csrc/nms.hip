@@ -384,7 +384,7 @@ __global__ __launch_bounds__(1024) void scene_rank_kernel(const float *__restric
     uint64_t *keys = (uint64_t *)smem;                                // [total rounded up to 256], tail = 0
     __shared__ int s_rank[64];
     const int total = total_dev[0];
-    if (blockIdx.x * 64 >= total) return;
+    if ((int)(blockIdx.x * 64) >= total) return;
     const int tid = threadIdx.x, bf = 1 + k_rows * width, Tp = (total + 255) & ~255;
     for (int j = 2 * tid; j < Tp; j += 2 * blockDim.x) {              // 16 B per lane, tail zeroed
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
