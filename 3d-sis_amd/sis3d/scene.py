@@ -28,13 +28,16 @@ class SceneRunner:
         self._origins = {}
         self._send = None
 
-    def mask_fn(self, payload, windows, classes):
+    def mask_fn(self, payload, windows, classes, values=False):
         """mask head of one chunk's surviving detections: one ragged launch per layer for all its boxes, then the predicted
-        class's channel thresholded at MASK_THRESH (lib/model/trainval.py:736-759) -> list of {0,1} float32 GPU tensors"""
+        class's channel thresholded at MASK_THRESH (lib/model/trainval.py:736-759) -> list of {0,1} float32 GPU tensors
+        (values=True: the channel's sigmoid outputs themselves, what the parity tests compare at 1e-4)"""
         data = payload[0] if isinstance(payload, (tuple, list)) else payload
         scene = data.cuda().float()
         with torch.no_grad():
             preds = self.net.mask_backbone.forward_batched(scene, windows)
+        if values:
+            return [p[0, k].clone() for p, k in zip(preds, classes)]
         t = float(self.net.cfg.MASK_THRESH)
         return [(p[0, k] >= t).float() for p, k in zip(preds, classes)]
 
@@ -76,7 +79,7 @@ class SceneRunner:
             self.pipes.join()
         return send[:len(mine)]
 
-    def infer(self, chunks, thresh=None, group=None, max_keep=0, with_masks=False):
+    def infer(self, chunks, thresh=None, group=None, max_keep=0, with_masks=False, mask_values=False):
         """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d) or None)] for the whole scene (entries of other
         ranks' chunks may carry None).  -> (records (N,16) sorted by score, keep LongTensor) on the GPU, identical on
         every rank; with_masks adds this rank's {position in keep: (scene window, mask)} (parallel.scene_masks)."""
@@ -89,6 +92,6 @@ class SceneRunner:
                 return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, merge_fn=fused_merge)
             recs, keep, cids = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, with_chunk_ids=True,
                                                     merge_fn=fused_merge)
-            masks = parallel.scene_masks(recs, keep, cids, chunks, self.mask_fn, float(self.net.cfg.CLASS_THRESH), group,
-                                         solo=self.solo)
+            fn = (lambda p, w, k: self.mask_fn(p, w, k, values=True)) if mask_values else self.mask_fn
+            masks = parallel.scene_masks(recs, keep, cids, chunks, fn, float(self.net.cfg.CLASS_THRESH), group, solo=self.solo)
             return recs, keep, masks

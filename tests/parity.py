@@ -1,8 +1,26 @@
 """End-to-end proposal parity, the protocol of SURVEY.md 8(c)(3): the device and oracle proposal lists are compared as
 SETS with exact (IoU = 1, coordinates within `tol`) one-to-one matching; a box left unmatched on either side FAILS unless
 its RPN score sits within `gap` of another candidate's score (a near-tie: the two fp32 pipelines differ by ~1e-6 in the
-logits, so the stable sort may order such a pair differently and NMS then keeps the other one) -- those are REPORTED."""
+logits, so the stable sort may order such a pair differently and NMS then keeps the other one) -- those are REPORTED.
+
+Contract of the committed seeds (round 3): every end-to-end test passes `max_near=0` (the default), i.e. a near-tie FAILS the
+test; the row-for-row comparisons that follow are therefore unconditional.  Should a box ever produce a near-tie on some host,
+the remedy is a different seed for that case, stated in the test -- not a silent skip.  Every `[parity]` line is also appended
+to the file named by $SIS3D_PARITY_LOG (profiles/r03_parity_log.txt is one such run on the MI355X box)."""
+import os
+
 import torch
+
+
+def report(line):
+    """print a `[parity]` line and append it to $SIS3D_PARITY_LOG when set (pytest -q swallows stdout)"""
+    line = "[parity] " + line
+    print(line)
+    path = os.environ.get("SIS3D_PARITY_LOG")
+    if path:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(line + "\n")
 
 
 def match_sets(got, want, tol=1e-3):
@@ -33,9 +51,9 @@ def nearest_score_gap(score, all_scores_sorted):
 
 
 def assert_proposals_match(got_rois, got_scores, want_rois, want_scores, all_scores_sorted, tol=1e-3, gap=1e-5, score_tol=1e-4,
-                           label=""):
-    """-> number of near-ties reported.  got_* device outputs (CPU tensors), want_* the oracle's, all_scores_sorted the
-    oracle's full candidate score list (OracleNet.forward()['_scores_sorted_all'])."""
+                           label="", max_near=0):
+    """-> number of near-ties (asserted <= max_near; 0 for every committed seed).  got_* device outputs (CPU tensors),
+    want_* the oracle's, all_scores_sorted the oracle's full candidate score list (OracleNet.forward()['_scores_sorted_all'])."""
     got_rois, want_rois = got_rois.float().cpu(), want_rois.float().cpu()
     gs, ws = got_scores.float().cpu().view(-1), want_scores.float().cpu().view(-1)
     pairs, un_w, un_g = match_sets(got_rois, want_rois, tol)
@@ -48,6 +66,7 @@ def assert_proposals_match(got_rois, got_scores, want_rois, want_scores, all_sco
             assert g_ <= gap + 2e-6, "%s %s box %d (score %.7f) has no near-tied rival: nearest other candidate score is %.3g away" % (
                 label, side, k, float(sc[k]), g_)
             near += 1
-    print("[parity] %s: %d oracle / %d device proposals, %d matched exactly, %d near-ties reported" % (
+    report("%s: %d oracle / %d device proposals, %d matched exactly, %d near-ties" % (
         label, len(want_rois), len(got_rois), len(pairs), near))
+    assert near <= max_near, "%s: %d near-tied proposals (allowed %d): pick a seed without near-ties for this case" % (label, near, max_near)
     return near

@@ -21,15 +21,41 @@ def _run(args, env_extra=None, timeout=300):
     return p.returncode, p.stdout, p.stderr
 
 
-def test_gpus_2_self_launches_two_ranks_gloo():
-    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--scene-chunks", "8", "--selftest-cpu"])
-    assert rc == 0, err[-2000:]
+SIDE_KEYS = {"chunk_pipeline": ("workload", "value", "unit", "scaling", "ms_per_step", "chunks_per_step_per_gpu"),
+             "scene": ("workload", "value", "unit", "scaling", "ms_per_scene", "steps", "scene_chunks", "scene_stride", "records_gathered",
+                       "kept_after_scene_nms")}
+
+
+def _check_line(out, n, steps):
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out                                  # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["selftest"] is True
-    assert d["config"]["records"] == sum(3 + c % 5 for c in range(8))     # every chunk of both ranks arrived
+    assert d["n_gpus"] == n and d["steps"] == steps and d["selftest"] is True
+    assert d["config"]["records"] == sum(3 + c % 5 for c in range(8))     # every chunk of every rank arrived
     assert out.strip().splitlines()[-1] == lines[0]              # ... and it is the last thing on stdout
+    # BOTH workloads on every line, at every N, under the same keys, so value(N) / value(1) compares like with like
+    for key, fields in SIDE_KEYS.items():
+        assert key in d, key
+        for f in fields:
+            assert f in d[key], (key, f)
+    assert d["chunk_pipeline"]["scaling"] == "weak" and d["scene"]["scaling"] == "strong"
+    assert d["scene"]["records_gathered"] == d["config"]["records"]
+    return d
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_default_line_carries_both_workloads_at_every_n(n):
+    rc, out, err = _run(["--gpus", str(n), "--steps", "3", "--warmup", "0", "--scene-chunks", "8", "--selftest-cpu"])
+    assert rc == 0, err[-2000:]
+    d = _check_line(out, n, 3)
+    assert d["value"] == d["chunk_pipeline"]["value"] and d["scaling"] == "weak"     # auto: the headline is config[1] at every N
+
+
+def test_gpus_2_scene_headline_gloo():
+    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--scene-chunks", "8", "--workload", "scene", "--selftest-cpu"])
+    assert rc == 0, err[-2000:]
+    d = _check_line(out, 2, 3)
+    assert d["value"] == d["scene"]["value"] and d["scaling"] == "strong"
 
 
 @pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has >= 2 GPUs")
@@ -53,6 +79,6 @@ def test_launch_command_is_one_rank_per_gpu_on_loopback():
     assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
-    # defaults: N = 1, backbone+RPN; N > 1 resolves to the scene workload (BASELINE config 5)
+    # defaults: N = 1, `auto` = config[1] as the headline at every N with the 32-chunk overlapping scene as a side key
     a = bench.parse([])
-    assert a.gpus == 1 and a.workload == "auto" and a.scene_chunks == 32
+    assert a.gpus == 1 and a.workload == "auto" and a.scene_chunks == 32 and a.scene_stride == 80.0

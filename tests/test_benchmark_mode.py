@@ -165,23 +165,32 @@ def test_benchmark_mode_end_to_end(golden, oracle, tmp_path, tag):
     assert np.array_equal(got["scene"], want["scene"]) and got["scene"].dtype == want["scene"].dtype
     for k in ("pred_class", "pred_conf", "pred_box"):
         assert got[k].dtype == want[k].dtype and got[k].ndim == want[k].ndim
-    # rows: same detections up to near-tie reordering of the proposal list (fp32 conv rounding)
-    dist = np.abs(got["pred_box"][None] - want["pred_box"][:, None]).max(-1)
-    match = dist.argmin(1)
-    ok = dist.min(1) <= 2e-3
-    assert ok.mean() >= 0.9, dist.min(1)
-    gi = {int(r): i for i, r in enumerate(np.flatnonzero(got["pred_mask_index"]))}
-    wi = {int(r): i for i, r in enumerate(np.flatnonzero(want["pred_mask_index"]))}
-    for w_row in np.flatnonzero(ok):
-        g_row = int(match[w_row])
-        assert got["pred_class"][g_row] == want["pred_class"][w_row]
-        assert abs(got["pred_conf"][g_row] - want["pred_conf"][w_row]) <= 1e-4
-        if abs(want["pred_conf"][w_row] - cfg.CLASS_THRESH) > 1e-3:
-            assert bool(got["pred_mask_index"][g_row]) == bool(want["pred_mask_index"][w_row])
-            if want["pred_mask_index"][w_row]:
-                a, b = got["pred_mask"][gi[g_row]], want["pred_mask"][wi[int(w_row)]]
-                if a.shape == b.shape:                      # a box edge within 2e-3 of x.5 may round to the other voxel
-                    assert (a != b).mean() <= 0.01
+    # proposals: one-to-one with the oracle's, 0 near-ties asserted (tests/parity.py) -> the files compare ROW FOR ROW
+    from parity import assert_proposals_match, report
+    p = net._predictions
+    assert_proposals_match(p["rois"][0].cpu(), p["roi_scores"][0].cpu(), o["rois"][0], o["roi_scores"][0], o["_scores_sorted_all"],
+                           label="benchmark mode %s" % tag)
+    assert got["pred_class"].shape == want["pred_class"].shape and np.array_equal(got["pred_class"], want["pred_class"])
+    assert np.abs(got["pred_conf"] - want["pred_conf"]).max() <= 1e-4
+    assert np.abs(got["pred_box"] - want["pred_box"]).max() <= 2e-3
+    # no confidence within 1e-3 of CLASS_THRESH and no box edge within 2e-3 of a rounding boundary for this seed: same keep list,
+    # same integer crop windows
+    assert np.abs(want["pred_conf"] - cfg.CLASS_THRESH).min() > 1e-3
+    assert [bool(v) for v in got["pred_mask_index"]] == [bool(v) for v in want["pred_mask_index"]]
+    assert len(got["pred_mask"]) == len(want["pred_mask"]) > 0
+    # mask VALUES: the sigmoid outputs behind the written files, every class channel, <= 1e-4; threshold flips counted
+    dev_masks, ora_masks = p["mask_pred"][0], o["mask_pred"][0]
+    assert len(dev_masks) == len(ora_masks) == len(want["pred_mask"])
+    flips = 0
+    kept_cls = [int(c) for c, s in zip(want["pred_class"], want["pred_mask_index"]) if s]
+    for dm, om, a, b, k in zip(dev_masks, ora_masks, got["pred_mask"], want["pred_mask"], kept_cls):
+        assert dm.shape == om.shape and a.shape == b.shape == tuple(om.shape[2:])
+        assert float((dm.cpu() - om).abs().max()) <= 1e-4
+        assert np.array_equal(a, (dm[0, k].cpu().numpy() >= cfg.MASK_THRESH).astype(np.float32))     # the file is that channel, thresholded
+        diff = a != b
+        flips += int(diff.sum())
+        assert np.all(np.abs(om[0, k].numpy()[diff] - cfg.MASK_THRESH) <= 1e-4)                      # a flip only where p is within 1e-4 of 0.5
+    report("benchmark mode %s: %d masks <= 1e-4 on the sigmoid outputs, %d voxels flip at MASK_THRESH" % (tag, len(dev_masks), flips))
     # resume rule: existing pred_box.npy -> detection is not recomputed, masks are rebuilt from the stored boxes
     t0 = os.path.getmtime(d + "/pred_box.npy")
     net.delete_intermediate_states()

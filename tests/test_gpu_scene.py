@@ -52,9 +52,8 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
     # the gathered record sets match one to one; an unmatched record must be a near-tie of the RPN scores
     from parity import assert_proposals_match
     allsc = torch.cat([on.forward(c[2])["_scores_sorted_all"] for c in chunks]).sort(descending=True).values
-    near = assert_proposals_match(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6], allsc, label="4-chunk scene records")
-    if near == 0:
-        assert recs.shape[0] == orecs.shape[0] and torch.equal(keep.cpu(), okeep)
+    assert_proposals_match(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6], allsc, label="4-chunk scene records")
+    assert recs.shape[0] == orecs.shape[0] and torch.equal(keep.cpu(), okeep)          # 0 near-ties asserted above
     got, want = recs[keep][:, :6].cpu(), orecs[okeep][:, :6]
     d = (got[None] - want[:, None]).abs().amax(-1)
     # boxes were shifted to scene coordinates
@@ -70,14 +69,26 @@ def test_scene_of_four_chunks_vs_oracle(oracle):
     assert torch.equal(recs3, recs) and torch.equal(keep3, keep)
     kept = recs[keep].cpu()
     assert 0 < len(masks) <= kept.shape[0]
+    # mask VALUES: the predicted class's sigmoid channel <= 1e-4 vs the oracle on the same crop; the binary mask is that channel
+    # thresholded; voxels that flip at MASK_THRESH are counted and must sit within 1e-4 of it
+    _, _, probs = runner.infer(chunks, with_masks=True, mask_values=True)
+    assert probs.keys() == masks.keys()
+    flips = 0
     for i, (w, mk) in masks.items():
         r = kept[i]
         assert r[9] > cfg.CLASS_THRESH and tuple(mk.shape) == (w[3] - w[0], w[4] - w[1], w[5] - w[2])
         c = [c for c in chunks if c[1][0] <= w[0] < c[1][0] + dims[0] and c[1][2] <= w[2] < c[1][2] + dims[2]][0]
         ox, oz = int(c[1][0]), int(c[1][2])
         crop = c[2][0:1, :, w[0] - ox:w[3] - ox, w[1]:w[4], w[2] - oz:w[5] - oz]
-        want_m = (on.mask_backbone(crop)[0, int(r[8])] >= cfg.MASK_THRESH).float()
-        assert float((mk.cpu() != want_m).float().mean()) <= 0.01
+        want_p = on.mask_backbone(crop)[0, int(r[8])]
+        pw, pr = probs[i]
+        assert pw == w and float((pr.cpu() - want_p).abs().max()) <= 1e-4
+        assert torch.equal(mk, (pr >= cfg.MASK_THRESH).float())
+        diff = mk.cpu() != (want_p >= cfg.MASK_THRESH).float()
+        flips += int(diff.sum())
+        assert bool(((want_p[diff] - cfg.MASK_THRESH).abs() <= 1e-4).all())
+    from parity import report
+    report("4-chunk scene masks: %d masks <= 1e-4 on the sigmoid outputs, %d voxels flip at MASK_THRESH" % (len(masks), flips))
 
 
 def test_engine_from_depth_maps_equals_loaded_lists(oracle):
@@ -151,10 +162,14 @@ def test_grouped_engine_equals_single_chunk_engines(stage):
             assert torch.equal(got[g][k], want[k]), (g, k)
 
 
-def test_config5_scene_32_chunks_vs_oracle(oracle):
-    """BASELINE config 5 at its real size: 32 chunks of 96x48x96 laid out 4 x 1 x 8 (what `bench.py --workload scene`
-    times), per-chunk captured graph -> record blocks -> gather -> whole-scene NMS, against the oracle running the same
-    chunks on the CPU + cpu_nms over the concatenation."""
+@pytest.mark.parametrize("stride", [96, 80])
+def test_config5_scene_32_chunks_vs_oracle(oracle, stride):
+    """BASELINE config 5 at its real size: 32 chunks of 96x48x96 laid out 4 x 1 x 8, per-chunk captured graph -> record
+    blocks -> gather -> whole-scene NMS, against the oracle running the same chunks on the CPU + cpu_nms over the
+    concatenation.  stride 96: tiles edge to edge (nothing crosses a border, the NMS keeps every
+    record).  stride 80: neighbouring chunks OVERLAP by 16 voxels in x and z (what `bench.py`'s scene workload times),
+    so detections of adjacent chunks do overlap and the whole-scene NMS -- the step the all-gather exists for --
+    really suppresses: kept < gathered, and the kept SET must be the oracle's."""
     from parity import assert_proposals_match
     from sis3d import parallel
     from sis3d.engine import RECORD_WIDTH
@@ -168,7 +183,7 @@ def test_config5_scene_32_chunks_vs_oracle(oracle):
     net.load_state_dict(sd)
     net.cuda().eval()
     dims = synthetic.CHUNK_DIMS
-    chunks = [(c, (96.0 * (c % 4), 0.0, 96.0 * (c // 4)), synthetic.synth_chunk(c)) for c in range(32)]
+    chunks = [(c, (float(stride) * (c % 4), 0.0, float(stride) * (c // 4)), synthetic.synth_chunk(c)) for c in range(32)]
     runner = SceneRunner(net, dims)
     recs, keep = runner.infer([(c, o, d.cuda()) for c, o, d in chunks])
     on = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
@@ -186,25 +201,53 @@ def test_config5_scene_32_chunks_vs_oracle(oracle):
         rec[:n, 10:16] = torch.from_numpy(oracle.class_boxes(o, data.shape[2:]))
         return rec, n
     orecs, okeep = parallel.infer_scene(chunks, odetect, oracle.nms, k, cfg.TEST.RPN_NMS_THRESH)
-    assert float(recs[:, 3].max()) > 3 * 96 and float(recs[:, 5].max()) > 7 * 96          # scene coordinates of the 4 x 1 x 8 grid
-    near = assert_proposals_match(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6],
-                                  torch.cat(allsc).sort(descending=True).values, label="config 5: 32-chunk scene records")
+    assert float(recs[:, 3].max()) > 3 * stride and float(recs[:, 5].max()) > 7 * stride   # scene coordinates of the 4 x 1 x 8 grid
+    assert_proposals_match(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6],
+                           torch.cat(allsc).sort(descending=True).values, label="config 5: 32-chunk scene records, stride %d" % stride)
     # the whole-scene NMS itself is integer-exact on the device's own records
     assert torch.equal(keep.cpu(), oracle.nms(recs[:, :6].cpu().contiguous(), cfg.TEST.RPN_NMS_THRESH))
-    if near == 0:
-        # same records (the score-sorted ORDER may swap rows whose scores differ by ~1e-7 between the two fp32 pipelines):
-        # level, class, class probability and the class-regressed final box of every matched record
-        from parity import match_sets
-        assert recs.shape[0] == orecs.shape[0] and keep.numel() == okeep.numel()
-        pairs, uw, ug = match_sets(recs[:, :6].cpu(), orecs[:, :6])
-        assert not uw and not ug
-        iw = torch.tensor([i for i, _ in pairs])
-        jg = torch.tensor([j for _, j in pairs])
-        r, w = recs.cpu()[jg], orecs[iw]
-        assert torch.equal(r[:, 7], w[:, 7]) and torch.equal(r[:, 8], w[:, 8])
-        assert float((r[:, 9] - w[:, 9]).abs().max()) <= 1e-4 and float((r[:, 10:16] - w[:, 10:16]).abs().max()) <= 5e-3
-        s_ = recs[:, 6]
-        assert bool((s_[:-1] >= s_[1:]).all())
+    # same records (the score-sorted ORDER may swap rows whose scores differ by ~1e-7 between the two fp32 pipelines):
+    # level, class, class probability and the class-regressed final box of every matched record
+    from parity import match_sets
+    assert recs.shape[0] == orecs.shape[0] and keep.numel() == okeep.numel()
+    pairs, uw, ug = match_sets(recs[:, :6].cpu(), orecs[:, :6])
+    assert not uw and not ug
+    iw = torch.tensor([i for i, _ in pairs])
+    jg = torch.tensor([j for _, j in pairs])
+    r, w = recs.cpu()[jg], orecs[iw]
+    assert torch.equal(r[:, 7], w[:, 7]) and torch.equal(r[:, 8], w[:, 8])
+    assert float((r[:, 9] - w[:, 9]).abs().max()) <= 1e-4 and float((r[:, 10:16] - w[:, 10:16]).abs().max()) <= 5e-3
+    s_ = recs[:, 6]
+    assert bool((s_[:-1] >= s_[1:]).all())
+    # the survivors of the whole-scene NMS are the oracle's survivors, one to one
+    kp, kuw, kug = match_sets(recs[keep][:, :6].cpu(), orecs[okeep][:, :6])
+    assert not kuw and not kug and len(kp) == keep.numel()
+    from parity import report
+    report("config 5 stride %d: %d records gathered, %d kept after the whole-scene NMS (oracle: %d / %d), kept sets equal" % (
+        stride, recs.shape[0], keep.numel(), orecs.shape[0], okeep.numel()))
+    if stride < 96:
+        assert keep.numel() < recs.shape[0]                   # suppression happened ...
+        # ... and it is CROSS-chunk: a chunk's own records already survived its per-chunk NMS at the same threshold, so every
+        # suppressed record must have a kept, higher-ranked suppressor (IoU > thresh) that another chunk produced
+        from sis3d import ops
+        from sis3d.scene import fused_merge
+        blocks = parallel.gather_blocks(runner.run_chunks([(c, o, d.cuda()) for c, o, d in chunks]), 32, k)
+        recs2, keep2, cids = parallel.merge_scene(blocks, k, ops.nms, cfg.TEST.RPN_NMS_THRESH, with_chunk_ids=True, merge_fn=fused_merge)
+        assert torch.equal(recs2, recs) and torch.equal(keep2, keep)
+        cids, kept = cids.cpu(), torch.zeros(recs.shape[0], dtype=torch.bool)
+        kept[keep.cpu()] = True
+        boxes = recs[:, :6].cpu()
+        x0, x1 = torch.maximum(boxes[:, None, :3], boxes[None, :, :3]), torch.minimum(boxes[:, None, 3:], boxes[None, :, 3:])
+        inter = (x1 - x0 + 1).clamp(min=0).prod(-1)
+        vol = (boxes[:, 3:] - boxes[:, :3] + 1).prod(-1)
+        over = inter / (vol[:, None] + vol[None, :] - inter) > cfg.TEST.RPN_NMS_THRESH          # (i, j): j overlaps i
+        n_cross = 0
+        for i in (~kept).nonzero().view(-1).tolist():
+            sup = (over[i, :i] & kept[:i]).nonzero().view(-1)
+            assert sup.numel() > 0 and bool((cids[sup] != cids[i]).all())
+            n_cross += 1
+        assert n_cross == recs.shape[0] - keep.numel() > 0
+        report("config 5 stride %d: %d suppressed records, each by a kept box of ANOTHER chunk" % (stride, n_cross))
 
 
 @pytest.mark.parametrize("n_chunks,k_rows", [(1, 200), (4, 200), (32, 200), (40, 200), (7, 33)])

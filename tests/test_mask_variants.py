@@ -64,24 +64,21 @@ def test_mask_head_with_colour_vs_oracle(golden, oracle, kind):
              "proj_ind_3d": [i3d], "proj_ind_2d": [i2d]}
     p = net.forward(blobs, "TEST", [])
     o = oracle.OracleNet(sd, c, config.anchor_sizes(c, 1), config.anchor_sizes(c, 2)).forward(data, feats, i3d, i2d)
-    near = assert_proposals_match(p["rois"][0].cpu(), p["roi_scores"][0].cpu(), o["rois"][0], o["roi_scores"][0],
-                                  o["_scores_sorted_all"], label="mask head, colour variant %s" % kind)
+    assert_proposals_match(p["rois"][0].cpu(), p["roi_scores"][0].cpu(), o["rois"][0], o["roi_scores"][0],
+                           o["_scores_sorted_all"], label="mask head, colour variant %s" % kind)     # asserts 0 near-ties
     _, _, pred_box, keep = final_detections(p, data.shape[2:], c)
     wins = mask_windows(pred_box, keep)
     masks = p["mask_pred"][0]
     owins = [tuple(b) for b in o["_mask_aux"]["crops"]]
     assert len(masks) == len(wins) > 0
-    if near == 0:
-        assert wins == owins
+    assert wins == owins
     by = dict(zip(owins, o["mask_pred"][0]))
     checked = 0
     for w, m in zip(wins, masks):
         assert tuple(m.shape) == (1, c.NUM_CLASSES, w[3] - w[0], w[4] - w[1], w[5] - w[2])
-        if w in by:
-            assert float((m.cpu() - by[w]).abs().max()) <= 1e-4, w
-            checked += 1
-    assert checked >= len(owins) - near and checked > 0
+        assert float((m.cpu() - by[w]).abs().max()) <= 1e-4, w
+        checked += 1
+    assert checked == len(owins) > 0
     # against the reference's own first masks
     for i in range(min(4, int(g["n_masks"]))):
-        if owins[i] in dict(zip(wins, masks)):
-            assert float((dict(zip(wins, masks))[owins[i]].cpu() - torch.from_numpy(g["mask_%d" % i])).abs().max()) <= 1e-4
+        assert float((dict(zip(wins, masks))[owins[i]].cpu() - torch.from_numpy(g["mask_%d" % i])).abs().max()) <= 1e-4
