@@ -495,7 +495,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         chunks.append((c, scene_origin(c, args.scene_stride), payload))
     torch.cuda.synchronize()
     steps = steps or args.steps
-    for _ in range(max(1, min(args.warmup, steps) // 5)):
+    for _ in range(max(3, min(args.warmup, 10))):              # the first replays of freshly captured graphs cost milliseconds each
         res = runner.infer(chunks, with_masks=args.masks)
     barrier()
     t0 = time.perf_counter()

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 rm -f "$OUT/parity_log.txt"
-SIS3D_PARITY_LOG="$OUT/parity_log.txt" timeout 900 python -m pytest tests -m gpu -q -x > "$OUT/pytest_gpu.log" 2>&1
+SIS3D_PARITY_LOG="$OUT/parity_log.txt" timeout 900 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc=$?"; tail -15 "$OUT/pytest_gpu.log"
 echo "---- parity log"; cat "$OUT/parity_log.txt"
 timeout 400 python bench.py --steps 20 --warmup 5 2> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_default.json"
