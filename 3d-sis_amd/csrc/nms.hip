@@ -434,10 +434,12 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     const size_t mask_bytes = (size_t)n * cb * 8;
     const int nzw = (cb + 63) / 64;
     const size_t nz_bytes = (size_t)n * nzw * 8;
-    if (n > 0 && (ws_bytes < mask_bytes + nz_bytes || !ws)) return SIS3D_EWORKSPACE;
+    if (n > 0 && (ws_bytes < mask_bytes || !ws)) return SIS3D_EWORKSPACE;          // n * ceil(n/64) * 8: what the sweep paths need
     uint64_t *mask = (uint64_t *)ws;
     const int path = g_nms_path.load(std::memory_order_relaxed);
     if (!SELECT && n > 0 && (path == 2 || (path == 0 && mask_bytes > SWEEP_LDS_MASK_MAX))) {
+        // only this path reads the non-zero-word bitmap behind the matrix: sis3d_nms_workspace_bytes(n) covers both
+        if (ws_bytes < mask_bytes + nz_bytes) return SIS3D_EWORKSPACE;
         // the matrix does not fit the sweep workgroup's LDS: sparse candidate table + parallel resolve
         const size_t lds = (size_t)cb * (4 * 8 + 4) + 16;
         if (lds > 160 * 1024 - 64) return SIS3D_EUNSUPPORTED;

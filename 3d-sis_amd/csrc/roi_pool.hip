@@ -247,9 +247,13 @@ extern "C" int sis3d_roi_pool_levels(const float *f1, const float *f2, int C, in
     if (!f1 || !f2 || !out || !levels || C <= 0 || W <= 0 || H <= 0 || L <= 0 || pooled <= 0 || R < 0) return SIS3D_EINVAL;
     if (R == 0) return SIS3D_OK;
     if (!rois) return SIS3D_EINVAL;
-    // channels-last maps and rows (the network's layout): the slab kernel
+    // channels-last maps and rows (the network's layout): the slab kernel.  It moves C/64 floats per lane with one vector
+    // access, so strides AND base pointers must be multiples of that vector (a channel-slice view need not be)
+    static const bool legacy = getenv("SIS3D_ROIPOOL_LEGACY") != nullptr;
+    const uintptr_t vec_bytes = (uintptr_t)(C / 64) * 4;
+    const bool aligned = (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) % (vec_bytes < 4 ? 4 : vec_bytes)) == 0;
     if (fs_c == 1 && os_c == 1 && (C == 64 || C == 128 || C == 256) && (fs_w % 4) == 0 && (fs_h % 4) == 0 && (fs_l % 4) == 0 &&
-        (os_n % 4) == 0 && (os_bin % 4) == 0 && !getenv("SIS3D_ROIPOOL_LEGACY")) {
+        (os_n % 4) == 0 && (os_bin % 4) == 0 && aligned && !legacy) {
         const dim3 grid(pooled, R), block(256);
         hipStream_t st = as_stream(stream);
         if (C == 64) hipLaunchKernelGGL((roi_pool_slab_kernel<1>), grid, block, 0, st, f1, f2, W, H, L, fs_w, fs_h, fs_l, rois, levels, pooled, pooled, pooled, scale, out, os_n, os_bin);

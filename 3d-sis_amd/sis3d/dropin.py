@@ -56,9 +56,11 @@ def roi_pooling_forward_cuda(pooled_width, pooled_height, pooled_length, spatial
 
 def roi_pooling_backward_cuda(pooled_width, pooled_height, pooled_length, spatial_scale, top_grad, rois, bottom_grad, argmax):
     """int roi_pooling_backward_cuda(int,int,int,float, THCudaTensor* top_grad, rois, bottom_grad, THCudaIntTensor* argmax)
-    (roi_pooling_cuda.h): accumulates into the caller's (zeroed) bottom_grad"""
+    (roi_pooling_cuda.h): OVERWRITES the caller's bottom_grad, as ROIPoolBackward does (`bottom_diff[index] = gradient`,
+    roi_pooling_kernel.cu:137-248) -- a reused, non-zeroed buffer gives the reference's result.  The sum over the RoIs that share
+    a voxel is a float atomicAdd here (order varies run to run: last-bit differences)."""
     g = ops.roi_pool_backward(top_grad, argmax, bottom_grad.shape, channels_last=ops.is_cl(bottom_grad))
-    bottom_grad.add_(g)
+    bottom_grad.copy_(g)
     return 1
 
 

@@ -147,7 +147,12 @@ class Network(nn.Module):
         return (lv, prob, bbox, anchors)
 
     def image_features(self, images):
-        """network.py:203-205: `image_enet_trainable(image_enet_fixed(images))`, eval mode, no grad"""
+        """network.py:203-205: `image_enet_trainable(image_enet_fixed(images))`, eval mode, no grad.
+        Inference only: the reference trains image_enet_trainable with gradients; this path (no_grad, BatchNorm folded into
+        detached weights) cannot, and says so instead of silently freezing that half."""
+        if self.training:
+            raise NotImplementedError("sis3d: the RGB image path is inference-only (mode 'TEST', net.eval()); training "
+                                      "image_enet_trainable is out of scope (SURVEY.md section 2)")
         with torch.no_grad():
             self.image_enet_fixed.eval()
             self.image_enet_trainable.eval()

@@ -109,9 +109,12 @@ def merge_scene(blocks, k_rows, nms_fn, thresh, score_col=6, max_keep=0, with_ch
     counts = blocks[:, 0].round().long().clamp(0, k_rows)
     rows = blocks[:, 1:].reshape(n_chunks * k_rows, RECORD_WIDTH)
     valid = (torch.arange(k_rows, device=dev).view(1, -1) < counts.view(-1, 1)).reshape(-1)
-    # invalid (padding) rows sort behind every real record; one stable sort of the fixed-size table, one count readback
-    key = torch.where(valid, rows[:, score_col], torch.full_like(rows[:, score_col], float("-inf")))
-    _, order = torch.sort(key, descending=True, stable=True)
+    # composite key (validity, then score): a stable descending sort on the score, then a stable sort that moves the padding
+    # rows behind every real record -- a real record whose score is -inf must not lose its place to a padding row (the fused
+    # kernel compacts by the per-chunk counts first; this is the same order).  One count readback.
+    _, by_score = torch.sort(rows[:, score_col], descending=True, stable=True)
+    _, front = torch.sort((~valid.index_select(0, by_score)).to(torch.uint8), stable=True)
+    order = by_score.index_select(0, front)
     total = int(counts.sum().item())
     order = order[:total]
     recs = rows.index_select(0, order)

@@ -138,3 +138,25 @@ def test_merge_fn_contract():
     assert parallel.merge_scene(blocks, k_rows, orc.nms, 0.1, merge_fn=lambda *a: marker) == marker[:2]
     assert parallel.merge_scene(blocks, k_rows, orc.nms, 0.1, with_chunk_ids=True, merge_fn=lambda *a: marker) == marker
     assert want[0].shape[0] == 8 and want[2].tolist() == sorted(want[2].tolist(), key=lambda c: 0) and set(want[2].tolist()) == {0, 2}
+
+
+def test_merge_scene_real_record_with_minus_inf_score_is_not_dropped():
+    """a valid record whose score is -inf used to tie with the padding rows (sort key -inf) and could lose its place
+    to a padding row with a smaller flat index; validity now ranks before the score, as in the fused kernel's compaction."""
+    import torch
+    from sis3d import parallel
+    W, k = parallel.RECORD_WIDTH, 4
+    blocks = torch.zeros(2, parallel.block_floats(k))
+    rows0 = torch.zeros(k, W)
+    rows0[0, :6] = torch.tensor([0., 0., 0., 4., 4., 4.])
+    rows0[0, 6] = 0.5
+    blocks[0, 0], blocks[0, 1:] = 1, rows0.reshape(-1)          # chunk 0: one record, three padding rows (flat 1..3)
+    rows1 = torch.zeros(k, W)
+    rows1[0, :6] = torch.tensor([50., 0., 0., 54., 4., 4.])
+    rows1[0, 6] = float("-inf")                                 # a real record with score -inf at flat index 4
+    rows1[1, :6] = torch.tensor([70., 0., 0., 74., 4., 4.])
+    rows1[1, 6] = 0.25
+    blocks[1, 0], blocks[1, 1:] = 2, rows1.reshape(-1)
+    recs, keep, cids = parallel.merge_scene(blocks, k, lambda b, th: torch.arange(b.shape[0]), 0.1, with_chunk_ids=True)
+    assert recs.shape[0] == 3 and cids.tolist() == [0, 1, 1]
+    assert recs[:, 0].tolist() == [0.0, 70.0, 50.0]             # 0.5, 0.25, then the -inf record -- not a zero padding row
