@@ -111,6 +111,26 @@ def projection_cases(ns):
     print("projection_cases")
 
 
+def projection_backward_case(ns):
+    """Projection.backward of the reference (projection.py:139-153) run in place under ref_harness.legacy_data_alias (torch-0.4
+    `.data` aliasing + `saved_variables`): volumes with >= 32*41 voxels (below that the reference's resize_ GROWS the clone's
+    storage and reads uninitialised memory -- undefined, not pinned), duplicate pixels (the last list entry wins), an empty list."""
+    out = {}
+    cases = (("a", (24, 12, 20), 900, 3, 7), ("b", (32, 16, 24), 3000, 6, 8), ("empty", (16, 10, 12), 0, 2, 9))
+    for name, dims, n, C, seed in cases:
+        feats, i3d, i2d = synthetic.synth_views(seed, n_views=1, n_per_view=n, channels=C, image_hw=(32, 41), dims=dims)
+        g = torch.randn(C, dims[2], dims[1], dims[0], generator=torch.Generator().manual_seed(seed))
+        fwd, gl = rh.ref_projection_backward(ns, feats[0], i3d[0], i2d[0], dims, g)
+        assert tuple(gl.shape) == (C, 32, 41)
+        pix = i2d[0, 1:1 + int(i3d[0, 0])]
+        out.update({name + "_dims": np.array(dims), name + "_label": feats[0].numpy(), name + "_i3d": i3d[0].numpy(),
+                    name + "_i2d": i2d[0].numpy(), name + "_grad_out": g.numpy(), name + "_grad_label": gl.numpy(),
+                    name + "_forward_sha": np.array(sha(fwd))})
+        print("projection_backward", name, dims, "entries", int(i3d[0, 0]), "distinct pixels", int(pix.unique().numel()))
+    out["names"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(OUT, "projection_backward_case.npz"), **out)
+
+
 def anchors_case(ns):
     with rh.in_reference_dir():
         a1, a2, _ = ns.generate_anchors.generate_anchors([3, 2, 4], [3, 2, 4], [], [4, 4, 4])
@@ -465,6 +485,9 @@ def main():
     if "--backward" in sys.argv:
         roi_backward_case(ns)
         return
+    if "--projection-backward" in sys.argv:      # round 3: pins the oracle's Projection.backward
+        projection_backward_case(ns)
+        return
     if "--mask-images" in sys.argv:              # round 2: the mask head's colour variants
         e2e(ns, "e2e_mask_use_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="use")
         e2e(ns, "e2e_mask_only_images_small", True, (64, 32, 48), 8, n_views=3, n_per_view=2500, sub=2, mask_images="only")
@@ -479,6 +502,7 @@ def main():
     nms_cases(ns)
     roi_cases(ns)
     projection_cases(ns)
+    projection_backward_case(ns)
     anchors_case(ns)
     compute_projection_cases(ns)
     benchmark_case(ns)

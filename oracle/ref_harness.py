@@ -310,6 +310,41 @@ def legacy_int_division():
         torch.Tensor.__truediv__ = orig
 
 
+@contextlib.contextmanager
+def legacy_data_alias():
+    """torch 0.4 semantics for `Tensor.data` and `ctx.saved_variables`, which the reference's `Projection.backward`
+    (lib/layer_utils/projection.py:139-153) relies on.  In torch 0.4.1 `x.data` wrapped the SAME underlying tensor, so
+    `grad_label.data.resize_(C, 32, 41)` resized `grad_label` itself (keeping the first C*32*41 elements of its storage) and
+    `grad_label.data.view(...).index_copy_(...)` wrote into it; since torch 1.2 `.data` is a shallow copy whose size changes no
+    longer reach the original, so the unmodified backward returns a volume-shaped gradient and autograd rejects it.  Inside a
+    backward (grad mode off, tensors that do not require grad) "the same underlying tensor" is the tensor itself: `.data` is
+    patched to return `self` and `saved_variables` (removed in torch 2.x) to alias `saved_tensors`, only while the reference
+    code runs -- the reference itself is unmodified (same approach as legacy_int_division)."""
+    from torch.autograd.function import FunctionCtx
+    had = "data" in torch.Tensor.__dict__
+    orig = torch.Tensor.__dict__.get("data")
+    torch.Tensor.data = property(lambda self: self)
+    FunctionCtx.saved_variables = property(lambda self: self.saved_tensors)
+    try:
+        yield
+    finally:
+        if had:
+            torch.Tensor.data = orig
+        else:
+            del torch.Tensor.data
+        del FunctionCtx.saved_variables
+
+
+def ref_projection_backward(ns, label, lin_indices_3d, lin_indices_2d, volume_dims, grad_output):
+    """d(Projection.apply(label, ...)) / d(label) applied to grad_output, through the reference's own forward + backward run in
+    place (CPU) under legacy_data_alias().  -> (output of the forward, grad_label)."""
+    lab = label.clone().requires_grad_(True)
+    out = ns.projection.Projection.apply(lab, lin_indices_3d, lin_indices_2d, volume_dims)
+    with legacy_data_alias():
+        out.backward(grad_output)
+    return out.detach(), lab.grad.detach().clone()
+
+
 def ref_compute_projection(ns, depth, camera_to_world, world_to_grid, volume_dims):
     """ProjectionHelper(...).compute_projection of the reference, run in place (CPU)."""
     cfg = ns.cfg

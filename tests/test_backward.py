@@ -1,5 +1,7 @@
 """Backward kernels (training only): RoI pooling (roi_pooling_kernel.cu:137-248, roi_pool.py:40-50) and
-Projection (projection.py:139-153).  Fixture roi_pool_backward_case.npz: the reference's own Python RoIPool forward + backward."""
+Projection (projection.py:139-153).  Fixtures: roi_pool_backward_case.npz = the reference's own Python RoIPool forward + backward;
+projection_backward_case.npz = the reference's own Projection.apply + backward run in place under ref_harness.legacy_data_alias
+(oracle/make_golden.py --projection-backward)."""
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,41 @@ def test_oracle_roi_pool_backward_matches_reference_fixture(golden, oracle):
     assert np.array_equal(out.numpy(), g["out"])
     gin = oracle.roi_pool_backward(torch.from_numpy(g["grad_out"]), arg, feat.shape)
     assert np.array_equal(gin.numpy(), g["grad_in"])         # same accumulation order as the reference's loop: bit-identical
+
+
+def _pb_cases(g):
+    for name in [str(n) for n in g["names"]]:
+        yield (name, tuple(int(v) for v in g[name + "_dims"]), torch.from_numpy(g[name + "_label"]), torch.from_numpy(g[name + "_i3d"]),
+               torch.from_numpy(g[name + "_i2d"]), torch.from_numpy(g[name + "_grad_out"]), torch.from_numpy(g[name + "_grad_label"]))
+
+
+def test_oracle_projection_backward_matches_reference_fixture(golden, oracle):
+    """pins the oracle: bit-identical to the reference's own backward (duplicate pixels: last entry wins; untouched pixels keep
+    the first C*h*w elements of the cloned volume gradient; empty list)"""
+    g = golden("projection_backward_case")
+    seen = 0
+    for name, dims, label, i3d, i2d, gout, want in _pb_cases(g):
+        got = oracle.projection_backward(gout, i3d, i2d)
+        assert got.shape == want.shape == label.shape and torch.equal(got, want), name
+        seen += 1
+    assert seen == 3
+
+
+def test_oracle_projection_backward_vs_live_reference(oracle):
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("reference tree not present on this machine")
+    ns = rh.install()
+    dims = (20, 16, 28)
+    feats, i3d, i2d = synthetic.synth_views(21, n_views=1, n_per_view=2000, channels=4, image_hw=(32, 41), dims=dims)
+    gout = torch.randn(4, dims[2], dims[1], dims[0], generator=torch.Generator().manual_seed(5))
+    fwd, gl = rh.ref_projection_backward(ns, feats[0], i3d[0], i2d[0], dims, gout)
+    assert torch.equal(fwd, oracle.projection(feats[0], i3d[0], i2d[0], dims))
+    assert torch.equal(gl, oracle.projection_backward(gout, i3d[0], i2d[0]))
+    # the shim is gone afterwards: `.data` is a shallow copy again
+    x = torch.zeros(3)
+    x.data.resize_(1)
+    assert x.shape == (3,)
 
 
 def test_oracle_projection_backward_semantics(oracle):
@@ -71,9 +108,15 @@ def test_roi_pool_backward_gpu(golden, oracle, layout):
 
 
 @pytest.mark.gpu
-def test_projection_backward_gpu_and_autograd(oracle):
+def test_projection_backward_gpu_and_autograd(oracle, golden):
     from sis3d import ops
     from sis3d.layer_utils.projection import Projection
+    # the reference's own backward (fixture): kernel and autograd.Function, bit for bit
+    for name, dims, label, i3d, i2d, gout, want in _pb_cases(golden("projection_backward_case")):
+        assert torch.equal(ops.projection_backward(gout.cuda(), i3d.cuda(), i2d.cuda()).cpu(), want), name
+        lab = label.cuda().requires_grad_(True)
+        Projection.apply(lab, i3d.cuda(), i2d.cuda(), dims).backward(gout.cuda())
+        assert torch.equal(lab.grad.cpu(), want), name
     for dims, n in (((12, 6, 10), 150), ((96, 48, 96), 3000)):
         feats, i3d, i2d = synthetic.synth_views(5, n_views=1, n_per_view=n, channels=7, image_hw=(32, 41), dims=dims)
         g = torch.randn(7, dims[2], dims[1], dims[0], generator=torch.Generator().manual_seed(2))
