@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "sis3d", "libsis3d_hip.so")
 OBJ = os.path.join(HERE, "build")
 
 EXACT = ["nms.hip", "roi_pool.hip", "projection.hip", "frustum.hip", "proposal.hip", "pool_misc.hip", "api.hip", "topk.hip"]
-FAST = ["conv3d.hip", "conv3d_t16.hip", "conv3d_b16.hip", "bottleneck.hip", "pointwise.hip", "mlp.hip", "mlp16.hip"]
+FAST = ["conv3d.hip", "conv3d_wino.hip", "conv3d_t16.hip", "conv3d_b16.hip", "bottleneck.hip", "pointwise.hip", "mlp.hip", "mlp16.hip"]
 
 
 def _newer(src, dst):
@@ -37,7 +37,7 @@ def build(force=False, verbose=True):
             continue
         obj = os.path.join(OBJ, name.replace(".hip", ".o"))
         if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
-            jobs.append(base + (["-ffp-contract=off"] if name in EXACT else []) + ["-c", src, "-o", obj])
+            jobs.append(base + (["-ffp-contract=off"] if name in EXACT else []) + (["-fno-slp-vectorize"] if name == "conv3d_wino.hip" else []) + ["-c", src, "-o", obj])
         objs.append(obj)
     width = max(1, min(len(jobs), int(os.environ.get("SIS3D_BUILD_JOBS", os.cpu_count() or 1))))
     running = []

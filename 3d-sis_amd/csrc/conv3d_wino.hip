@@ -1,0 +1,523 @@
+// k3 / pad-1 3D convolution by the Winograd minimal-filtering algorithm F(2x2x2, 3x3x3) in EXACT fp32, fused in one kernel
+// for gfx950 (CDNA4).
+//
+// Replaces the same cuDNN calls as conv3d_t16.hip -- nn.Conv3d(C, C', 3, padding=1) + bias + ReLU of
+// lib/nets/backbones.py:20-22,188-231 (Bottleneck.conv2, geometry2[0]) and lib/nets/network.py:40 (rpn_net_level*) -- with
+// 3.375x fewer multiplications: a 2x2x2 block of outputs costs 64 products per (cin, cout) pair instead of 8 * 27 = 216.
+// Every operation is an IEEE binary32 add or an fp32 MFMA (an fmaf chain); the transform matrices hold only 0, +-1, +-1/2, so
+// the result differs from a direct fp32 convolution by summation order / association only (measured on the rpn_net layer:
+// 2.7e-6 max abs error against a float64 convolution, the direct oneDNN fp32 convolution 2.0e-6; tolerance of the path: 1e-4).
+// This is the algorithm class cuDNN -- the library under the reference's nn.Conv3d on a GPU -- picks for 3x3 filters itself.
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      (nested over x, y, z)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// In the transformed domain the layer is 64 independent GEMMs  M_xi[tile][cout] = V_xi[tile][cin] * U_xi[cin][cout]
+// (xi = the 4x4x4 positions of a transformed input tile, tile = a 2x2x2 output block).  Mapping on the chip:
+//   * v_mfma_f32_16x16x4_f32: A = V_xi (16 tiles x 4 channels), B = U_xi (4 channels x 16 couts), one accumulator tile per xi.
+//     All xi of a (tile, cout) pair must stay live over the whole channel loop: 64 x 4 registers -- so a wave takes HALF of
+//     them (xi_x in {2h, 2h+1}: 128 accumulator registers) and two waves per SIMD are resident (<= 256 registers each), which
+//     also gives the hardware a second instruction stream: the input transform is ~3 VALU operations per MFMA and a single
+//     in-order wave cannot issue that many beside its MFMAs.
+//   * workgroup = 8 waves (h, g, c) = a block of 4 x 2 x 4 Winograd tiles (8 x 4 x 8 output voxels; g = which 16 tiles)
+//     x 2 cout tiles (c) x the two xi halves (h).  rpn_net 128 -> 256 on 24 x 12 x 24: 27 blocks x 8 cout pairs = 216
+//     workgroups, one per CU.
+//   * V is never materialised: the raw halo brick (10 x 6 x 10 voxels) of the 4 channels of a K-step is staged in LDS in a
+//     planar layout [channel][x][y][z] whose strides (16, 100, 1040 floats) put the 32 lanes of a ds_read_b64 group on 32
+//     distinct bank pairs; a lane (tile, channel) reads the 3 x-planes its xi half needs (24 x 8 B) and transforms them in
+//     registers (96 adds) into the A operands of its 32 MFMAs.
+//   * U (the transformed weights, packed once: [cout tile][K-step][xi / 4][lane][4]) streams through a double-buffered
+//     32 KB LDS stage filled by LDS-DMA (global_load_lds_dwordx4: no staging registers); a lane's B operands of a K-step are
+//     8 x ds_read_b128.
+//   * the two waves of a SIMD run half a step apart: class-1 waves transform the NEXT step's input behind their MFMAs,
+//     before the barrier, class-0 waves after it -- so one wave of each SIMD multiplies while the other transforms.
+//   * epilogue: output transform in registers (per lane: 32 xi -> 8 partial outputs per tile), the two xi halves are added
+//     through LDS, + bias, ReLU, store.
+// The weight transform (G g G^T per axis) runs once at pack time in fp32.
+#include "common.h"
+#include "mfma16.h"
+#include <stdlib.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// timing experiments (tools/wino_bench.cpp builds variants; results are WRONG with any bit set): 1 = no U fill, 2 = no raw staging,
+// 4 = no barrier in the loop, 16 = no input transform, 32 = no output stores, 64 = no epilogue at all, 128 = no prologue staging
+#ifndef WN_EXP
+#define WN_EXP 0
+#endif
+
+namespace {
+
+constexpr int WN_MAXP = 4;
+constexpr int TXB = 4, TYB = 2, TZB = 4;                        // Winograd tiles per workgroup block
+constexpr int VX = 2 * TXB, VY = 2 * TYB, VZ = 2 * TZB;         // output voxels per block: 8 x 4 x 8
+constexpr int HX = VX + 2, HY = VY + 2, HZ = VZ + 2;            // halo brick 10 x 6 x 10
+constexpr int HZS = 16;                                         // LDS row stride (floats)
+constexpr int PS = 100;                                         // x-plane stride: >= HY * HZS, == 4 (mod 32)
+constexpr int CHS = 1040;                                       // channel stride: >= HX * PS, == 16 (mod 64)
+constexpr int RAW_STAGE = 4 * CHS;                              // floats of one K-step's raw brick (4 channels)
+constexpr int NRAW = 3;                                         // raw ring depth (class-1 waves read one step ahead)
+constexpr int B_TILE = 64 * 64;                                 // floats of one (cout tile, K-step) block of U: [16][64][4]
+constexpr int B_STAGE = 2 * B_TILE;
+constexpr int NBST = 3;                                         // U ring depth: LDS-DMA lands ~1 us after issue -> two steps ahead
+constexpr int LDS_FLOATS = NRAW * RAW_STAGE + NBST * B_STAGE;   // 37,056 floats = 148,224 B
+constexpr int NVOX = HX * HY * HZ;                              // 600 staging items (voxel x 4 channels)
+constexpr int NTHR = 256;                                        // 4 waves, one per SIMD
+constexpr int NIT = (NVOX + NTHR - 1) / NTHR;
+
+struct WinoArgs {
+    const float *in[WN_MAXP];
+    const float *wp[WN_MAXP];
+    const float *bias[WN_MAXP];
+    float *out[WN_MAXP];
+    int X, Y, Z;
+    int cin_stride;
+    int cout, npairs;          // npairs = ceil(ceil(cout/16) / 2)
+    int nk;                    // cin / 4
+    int flags;
+    int out_stride, out_coff;
+    int nbx, nby, nbz;
+};
+
+__device__ __forceinline__ void glds16(const float *gsrc, float *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gsrc,
+                                     (void __attribute__((address_space(3))) *)lds_dst, 16, 0, 0);
+}
+
+// raw-stage loads and their counted waits as inline asm (see wino_wave): free functions, because clang rejects asm operands that
+// name captured variables inside a generic lambda
+__device__ __forceinline__ void load16_asm(f32x4 &dst, int byte_off, const float *base)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+
+// 1-D input transform B^T over 4 values, in place
+#define WN_BT_INPLACE(v0, v1, v2, v3) \
+    do { const float t0_ = (v0) - (v2), t1_ = (v1) + (v2), t2_ = (v2) - (v1), t3_ = (v1) - (v3); \
+         v0 = t0_; v1 = t1_; v2 = t2_; v3 = t3_; } while (0)
+
+// hipcc sinks pure arithmetic to its first use, i.e. below the MFMAs it is meant to hide behind (and a sched_barrier only pins
+// the machine scheduler, not IR-level code motion): an empty volatile asm that "modifies" a unit's results keeps the unit
+// where it is written
+#define WN_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+// The input transform of the NEXT K-step as 28 units, issued behind MFMAs of the current step.  fp32 MFMA and fp32 VALU share
+// the SIMD's fp32 lanes on gfx950 (their cycles ADD: measured, tools/wino_bench.cpp), so the transform is not hidden -- it is
+// kept small instead: a wave transforms HALF of the xi (xi_x in {2H, 2H + 1}: 96 adds + 24 LDS reads) and uses every transformed
+// value for TWO cout tiles, i.e. 1.5 adds per MFMA.
+//   read unit (4):  raw row dy of the three x-planes this half needs: 6 x ds_read_b64, two rows in flight at most
+//   x unit    (8):  (dy, dz pair) over x            4 adds
+//   y unit    (8):  line (i, dz) over y              4 adds, in place
+//   z unit    (8):  line (i, xi_y) over z            4 adds, in place  -> T[i][xi_y][xi_z] = the A operands of the next step
+template <int H>
+struct NextV {
+    float T[2][4][4];
+    f32x2 d[2][3][2];                                           // [dy & 1][plane][lo / hi]
+
+    template <int DY>
+    __device__ __forceinline__ void read_row(const float *__restrict__ r)
+    {
+        static_for<0, 3>([&](auto P) {
+            constexpr int p = decltype(P)::value, dx = p + H;
+            d[DY & 1][p][0] = *reinterpret_cast<const f32x2 *>(r + dx * PS + DY * HZS);
+            d[DY & 1][p][1] = *reinterpret_cast<const f32x2 *>(r + dx * PS + DY * HZS + 2);
+        });
+    }
+    template <int DY, int ZP>
+    __device__ __forceinline__ void x_pair()
+    {
+        static_for<0, 2>([&](auto E) {
+            constexpr int dz = 2 * ZP + decltype(E)::value;
+            const float p0 = dz & 1 ? d[DY & 1][0][dz >> 1].y : d[DY & 1][0][dz >> 1].x;
+            const float p1 = dz & 1 ? d[DY & 1][1][dz >> 1].y : d[DY & 1][1][dz >> 1].x;
+            const float p2 = dz & 1 ? d[DY & 1][2][dz >> 1].y : d[DY & 1][2][dz >> 1].x;
+            if constexpr (H == 0) {
+                T[0][DY][dz] = p0 - p2;                              // xi_x = 0: d0 - d2
+                T[1][DY][dz] = p1 + p2;                              // xi_x = 1: d1 + d2
+            } else {
+                T[0][DY][dz] = p1 - p0;                              // xi_x = 2: d2 - d1   (planes held: 1, 2, 3)
+                T[1][DY][dz] = p0 - p2;                              // xi_x = 3: d1 - d3
+            }
+        });
+        WN_PIN4(T[0][DY][2 * ZP], T[0][DY][2 * ZP + 1], T[1][DY][2 * ZP], T[1][DY][2 * ZP + 1]);
+    }
+    // unit M rides behind MFMA M (0..63) of the current step
+    template <int M>
+    __device__ __forceinline__ void unit(const float *__restrict__ r)
+    {
+        if constexpr (M == 0) read_row<0>(r);
+        else if constexpr (M == 2) read_row<1>(r);
+        else if constexpr (M == 8 || M == 10) x_pair<0, (M - 8) / 2>();
+        else if constexpr (M == 12) read_row<2>(r);
+        else if constexpr (M == 14 || M == 16) x_pair<1, (M - 14) / 2>();
+        else if constexpr (M == 18) read_row<3>(r);
+        else if constexpr (M == 24 || M == 26) x_pair<2, (M - 24) / 2>();
+        else if constexpr (M == 28 || M == 30) x_pair<3, (M - 28) / 2>();
+        else if constexpr (M >= 32 && M < 48 && (M & 1) == 0) {
+            constexpr int u = (M - 32) / 2, i = u >> 2, dz = u & 3;
+            WN_BT_INPLACE(T[i][0][dz], T[i][1][dz], T[i][2][dz], T[i][3][dz]);
+            WN_PIN4(T[i][0][dz], T[i][1][dz], T[i][2][dz], T[i][3][dz]);
+        } else if constexpr (M >= 48 && (M & 1) == 0) {
+            constexpr int u = (M - 48) / 2, i = u >> 2, y = u & 3;
+            WN_BT_INPLACE(T[i][y][0], T[i][y][1], T[i][y][2], T[i][y][3]);
+            WN_PIN4(T[i][y][0], T[i][y][1], T[i][y][2], T[i][y][3]);
+        }
+    }
+};
+
+template <int H>
+__device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int pair)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    const int gX = a.X, gY = a.Y, gZ = a.Z;
+    const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
+    const int ox0 = bx * VX, oy0 = by * VY, oz0 = bz * VZ;
+    const float *__restrict__ p_in = a.in[prob];
+    const float *__restrict__ p_wp = a.wp[prob];
+    const int nk = a.nk;
+
+    float *raw = lds;                                   // [NRAW][4][CHS]
+    float *bst = lds + NRAW * RAW_STAGE;                // [NBST][2][16][64][4]
+
+    // ---- staging plan: item = halo voxel (4 channels = one float4 of its channels-last row).  Branch-free and VALU-free (an
+    // fp32 VALU instruction costs the wave a 4-cycle issue slot that the matrix pipe cannot overlap): addresses are a uniform
+    // base pointer that advances with k (scalar adds) plus a 32-bit per-lane offset fixed for the whole launch; a halo voxel
+    // outside the grid (the same voxels in every K-step) is zeroed once in all three ring stages and its item loads from
+    // offset 0 and stores to a dump slot in the pad behind the last x-plane of each channel, as do the items past the brick
+    int goff[NIT], loff[NIT];
+    static_for<0, NIT>([&](auto I) {
+        constexpr int it = decltype(I)::value;
+        const int v = tid + it * NTHR;
+        const int hz = v % HZ, hy = (v / HZ) % HY, hx = v / (HZ * HY);
+        const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
+        const bool inside = v < NVOX && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
+        goff[it] = inside ? ((gx * gY + gy) * gZ + gz) * a.cin_stride : 0;
+        loff[it] = inside ? hx * PS + hy * HZS + hz : HX * PS + (lane & 31);       // dump: floats 1000..1031 of the 1040
+        if (v < NVOX && !inside) {
+            static_for<0, NRAW * 4>([&](auto C) { raw[decltype(C)::value * CHS + hx * PS + hy * HZS + hz] = 0.f; });
+        }
+    });
+    // In the loop the loads are inline asm: hipcc waits vmcnt(0) -- i.e. also for every LDS-DMA in flight -- at the first use of an
+    // ordinary load's result; here the only wait is the counted one in front of the LDS stores (step()).
+    f32x4 sv[NIT];
+    auto stage_load_item = [&](auto I, int k) {
+        constexpr int it = decltype(I)::value;
+        const float *base = p_in + 4 * k;
+        const int boff = goff[it] * 4;
+        load16_asm(sv[it], boff, base);
+    };
+    auto stage_store_item = [&](auto I, int buf) {
+        constexpr int it = decltype(I)::value;
+        float *dst = raw + buf * RAW_STAGE + loff[it];
+        dst[0] = sv[it][0];
+        dst[CHS] = sv[it][1];
+        dst[2 * CHS] = sv[it][2];
+        dst[3 * CHS] = sv[it][3];
+    };
+    // U stage of K-step k: 32 wave-instructions of 1 KB, eight per wave: block n = 8 wave + i = (cout tile n >> 4, xi quad n & 15)
+    const float *wbase = p_wp + (size_t)(2 * pair) * nk * B_TILE;
+    const int woff = lane * 4;
+    auto fill_b_item = [&](auto I, int k, int buf) {
+        constexpr int i = decltype(I)::value;
+        const int n = wave * 8 + i, cc = n >> 4, xq = n & 15;
+        glds16((wbase + ((size_t)cc * nk + k) * B_TILE + xq * 256) + woff, bst + buf * B_STAGE + n * 256);
+    };
+
+    f32x4 acc[2][32];                                    // [cout tile c][xi of this half]
+    static_for<0, 64>([&](auto I) { acc[decltype(I)::value >> 5][decltype(I)::value & 31] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
+
+    // lane (li, kq): tile li of group g = (txl, ty, tz), channel kq of the K-step
+    const int txl = li >> 3, ty = (li >> 2) & 1, tz = li & 3;
+    const int rbase = kq * CHS + (2 * (2 * g + txl)) * PS + (2 * ty) * HZS + 2 * tz;
+    const int bbase = H * 8 * 256 + lane * 4;
+
+    // ---- prologue: U stages 0 and 1 and raw stages 0 and 1 all in flight together, then V of step 0
+    static_for<0, 8>([&](auto I) { fill_b_item(I, 0, 0); });
+    static_for<0, 8>([&](auto I) { fill_b_item(I, nk > 1 ? 1 : 0, 1); });
+    static_for<0, NIT>([&](auto I) { stage_load_item(I, 0); });
+    wait_vmcnt<0>(sv[0], sv[1], sv[2]);
+    static_for<0, NIT>([&](auto I) { stage_store_item(I, 0); });
+    static_for<0, NIT>([&](auto I) { stage_load_item(I, nk > 1 ? 1 : 0); });
+    wait_vmcnt<0>(sv[0], sv[1], sv[2]);
+    static_for<0, NIT>([&](auto I) { stage_store_item(I, 1); });
+    __syncthreads();
+    // V ping-pongs between two NextV objects (no register copies): step k multiplies with one while the other is being built
+    NextV<H> va, vb;
+    static_for<0, 64>([&](auto M) { va.template unit<decltype(M)::value>(raw + rbase); });
+
+    // ---- main loop.  Step k: the 64 MFMAs of step k (32 xi x 2 cout tiles); behind them, one small unit per MFMA slot: the
+    // global loads of raw stage k + 2 (slots 1..5), the LDS-DMA of U stage k + 2 (7..21), the input transform of step k + 1
+    // (even slots, NextV::unit), the LDS stores of raw stage k + 2 (41..45).  A lone wave issues in order: anything placed in
+    // front of or behind the MFMA block would hold the matrix pipe up by its whole issue time.
+    // LDS-DMA lands ~1 us after issue under load (longer than a step), so U runs TWO stages ahead through a ring of three, and
+    // no wait in the loop is a vmcnt(0): the one in front of the raw-stage stores leaves this step's eight DMA instructions
+    // outstanding (vmcnt(8): the three loads of this step and everything older -- the previous step's DMA -- have completed).
+    // One barrier per step, and it sits INSIDE the MFMA block, after quad 5: by then every LDS read of U stage k is issued and
+    // stage k + 1 has landed, so the barrier is followed by the first U reads of step k + 1 and then by the 16 MFMAs of quads
+    // 6, 7 of step k, whose operands are already in registers -- the barrier skew and the LDS latency of the next step's first
+    // operands hide behind 512 cycles of matrix work instead of idling the pipe.
+    // Loads / DMA of the steps past the end are clamped to the last step (harmless duplicates, landed before the final barrier):
+    // no branches in the block.
+    static_assert(NIT == 3, "the counted waits below assume three staging loads and eight DMA instructions per step");
+    int cur = 0;                                         // k % 3: raw stage of step k, U stage of step k
+    f32x4 bq[4][2];                                      // ring over xi quads (slot q & 3), both cout tiles
+    auto read_b = [&](auto Q, const float *bs) {
+        constexpr int q = decltype(Q)::value;
+        bq[q & 3][0] = *reinterpret_cast<const f32x4 *>(bs + q * 256);
+        bq[q & 3][1] = *reinterpret_cast<const f32x4 *>(bs + B_TILE + q * 256);
+    };
+    read_b(std::integral_constant<int, 0>{}, bst + bbase);
+    read_b(std::integral_constant<int, 1>{}, bst + bbase);
+    auto step = [&](int k, NextV<H> &vu, NextV<H> &vn) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+        const int ks = k + 2 < nk ? k + 2 : nk - 1;
+        const float *bs = bst + cur * B_STAGE + bbase;
+        const float *bs_next = bst + nxt * B_STAGE + bbase;
+        const float *rn = raw + nxt * RAW_STAGE + rbase;
+        static_for<0, 8>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            if constexpr (q + 2 < 8) read_b(std::integral_constant<int, q + 2>{}, bs);
+            if constexpr (q == 6) {
+                // everything but this step's DMA has completed (the counted wait at slot 40 stands); LDS traffic of this wave done
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!(WN_EXP & 4)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                read_b(std::integral_constant<int, 0>{}, bs_next);
+                read_b(std::integral_constant<int, 1>{}, bs_next);
+            }
+            static_for<0, 8>([&](auto E) {
+                constexpr int e8 = decltype(E)::value, e = e8 >> 1, cc = e8 & 1, m = 8 * q + e8;
+                acc[cc][4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vu.T[q >> 2][q & 3][e], bq[q & 3][cc][e], acc[cc][4 * q + e], 0, 0, 0);
+                if constexpr (!(WN_EXP & 16)) vn.template unit<m>(rn);
+                if constexpr (m >= 1 && m < 1 + 2 * NIT && (m & 1) == 1 && !(WN_EXP & 2)) stage_load_item(std::integral_constant<int, (m - 1) / 2>{}, ks);
+                if constexpr (m >= 7 && m < 23 && (m & 1) == 1 && !(WN_EXP & 1)) fill_b_item(std::integral_constant<int, (m - 7) / 2>{}, ks, nn);
+                if constexpr (m == 40 && !(WN_EXP & 2)) wait_vmcnt<8>(sv[0], sv[1], sv[2]);
+                if constexpr (m >= 41 && m < 41 + 2 * NIT && (m & 1) == 1 && !(WN_EXP & 2)) stage_store_item(std::integral_constant<int, (m - 41) / 2>{}, nn);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        cur = nxt;
+    };
+    // nk is even (cin % 8 == 0) and BOTH steps of the loop body always transform: the last step's transform re-reads a stale
+    // (valid) raw stage and its result is never used -- 96 wasted adds once per launch buy a loop with exactly two step shapes
+    // and one register assignment for the 256 accumulator registers (hipcc otherwise moves them between the AGPR and VGPR halves
+    // at every change of shape: 512 v_accvgpr moves per transition)
+    for (int k = 0; k < nk; k += 2) {
+        step(k, va, vb);
+        step(k + 1, vb, va);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped duplicate DMA of the last steps
+    __syncthreads();                                     // quads 6, 7 of the last step ran behind the last in-loop barrier
+
+    // ---- output transform A^T M A: per lane, cout tile c and row r (tile 4 (lane >> 4) + r, cout lane & 15): 32 xi -> 8 partial
+    // outputs (this wave's xi_x half).  The halves meet through LDS (the U stages are free: the loop ended on a barrier, no DMA
+    // is in flight): each wave FINISHES two of the four rows (H = 0: r = 0, 1; H = 1: r = 2, 3) and ships the partials of the
+    // other two to its partner.
+    const int j = lane & 15, q4 = lane >> 4;
+    float *__restrict__ p_out = a.out[prob];
+    float P[2][4][8];                                    // [cout tile][row r][ox oy oz]
+    static_for<0, 2>([&](auto C) {
+        constexpr int cc = decltype(C)::value;
+        static_for<0, 4>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            float t[2][4][2];
+            static_for<0, 2>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                static_for<0, 4>([&](auto Y) {
+                    constexpr int y = decltype(Y)::value;
+                    const float m0 = acc[cc][i * 16 + y * 4 + 0][r], m1 = acc[cc][i * 16 + y * 4 + 1][r], m2 = acc[cc][i * 16 + y * 4 + 2][r],
+                                m3 = acc[cc][i * 16 + y * 4 + 3][r];
+                    t[i][y][0] = (m0 + m1) + m2;
+                    t[i][y][1] = (m1 - m2) - m3;
+                });
+            });
+            float s2[2][2][2];
+            static_for<0, 2>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                static_for<0, 2>([&](auto Z) {
+                    constexpr int z = decltype(Z)::value;
+                    s2[i][0][z] = (t[i][0][z] + t[i][1][z]) + t[i][2][z];
+                    s2[i][1][z] = (t[i][1][z] - t[i][2][z]) - t[i][3][z];
+                });
+            });
+            static_for<0, 4>([&](auto O) {
+                constexpr int o = decltype(O)::value, oy = o >> 1, oz = o & 1;
+                if constexpr (H == 0) {
+                    P[cc][r][0 * 4 + o] = s2[0][oy][oz] + s2[1][oy][oz];     // ox = 0: m0 + m1 (+ m2 from the other half)
+                    P[cc][r][1 * 4 + o] = s2[1][oy][oz];                      // ox = 1: m1 (- m2 - m3 from the other half)
+                } else {
+                    P[cc][r][0 * 4 + o] = s2[0][oy][oz];                      // m2
+                    P[cc][r][1 * 4 + o] = -s2[0][oy][oz] - s2[1][oy][oz];     // - m2 - m3
+                }
+            });
+            if constexpr ((r >> 1) != H) {               // the partner finishes this row
+                float *scr = bst + ((g * 2 + cc) * 4 + r) * (8 * 64) + lane;
+                static_for<0, 8>([&](auto O) { scr[decltype(O)::value * 64] = P[cc][r][decltype(O)::value]; });
+            }
+        });
+    });
+    __syncthreads();
+    // finish rows r = 2H, 2H + 1: + partner's partial, + bias, ReLU; transpose through LDS (second U stage) so that a lane
+    // stores 16 B = four consecutive couts of one voxel: [cc][voxel = (r', tile quad q4, o)][cout 16] per wave
+    float *tr = bst + B_STAGE + wave * (2 * 2 * 4 * 8 * 16);
+    static_for<0, 2>([&](auto C) {
+        constexpr int cc = decltype(C)::value;
+        const int co = 16 * (2 * pair + cc) + j;
+        const float bv = (a.bias[prob] && co < a.cout) ? a.bias[prob][co] : 0.f;
+        static_for<0, 2>([&](auto RR) {
+            constexpr int rr = decltype(RR)::value, r = 2 * H + rr;
+            const float *scr = bst + ((g * 2 + cc) * 4 + r) * (8 * 64) + lane;
+            static_for<0, 8>([&](auto O) {
+                constexpr int o = decltype(O)::value;
+                float v = (P[cc][r][o] + scr[o * 64]) + bv;
+                if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.f);
+                tr[(((cc * 2 + rr) * 4 + q4) * 8 + o) * 16 + j] = v;
+            });
+        });
+    });
+    // wave-local exchange: every lane reads what other lanes of its own wave wrote
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    static_for<0, 8>([&](auto S) {
+        constexpr int sidx = decltype(S)::value;                    // 128 voxel rows (cc, rr, q4, o) x 4 float4 = 512 pieces / 64 lanes
+        const int piece = sidx * 64 + lane, row = piece >> 2, c4 = piece & 3;
+        const int o = row & 7, tq = (row >> 3) & 3, rr = (row >> 5) & 1, cc = row >> 6;
+        const float4 v = *reinterpret_cast<const float4 *>(tr + row * 16 + c4 * 4);
+        const int tl = 4 * tq + 2 * H + rr;
+        const int x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2), y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1), z = oz0 + 2 * (tl & 3) + (o & 1);
+        const int co = 16 * (2 * pair + cc) + 4 * c4;
+        if (x < gX && y < gY && z < gZ && (!(WN_EXP & 32) || v.x == 123.456f)) {
+            float *dst = p_out + ((size_t)(x * gY + y) * gZ + z) * a.out_stride + a.out_coff + co;
+            if (co + 3 < a.cout && (((a.out_stride | a.out_coff) & 3) == 0)) {
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                if (co < a.cout) dst[0] = v.x;
+                if (co + 1 < a.cout) dst[1] = v.y;
+                if (co + 2 < a.cout) dst[2] = v.z;
+                if (co + 3 < a.cout) dst[3] = v.w;
+            }
+        }
+    });
+}
+
+__global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // work list: cout pair major, block minor; every XCD (block b runs on XCD b % 8, private L2) takes one contiguous range
+    // of it, i.e. few cout pairs x all blocks: its L2 holds 1/8 of U (8.4 MB for rpn_net) and the whole activation map
+    int wid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int nbr = a.nbx * a.nby * a.nbz;
+    const int pair = wid / nbr, brick = wid - pair * nbr;
+    // waves (h, g): h = xi_x half, g = tile group; each wave serves both cout tiles of the pair
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+    if (h == 0) wino_wave<0>(a, lds, blockIdx.y, brick, pair);
+    else wino_wave<1>(a, lds, blockIdx.y, brick, pair);
+}
+
+// (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:
+// lane (j = lane & 15, kq = lane >> 4) holds U[xi = 4 xq + e][ci = 4 k + kq][co = 16 tile + j]
+__global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float *__restrict__ w, int cout, int cin, int ntp, int nk,
+                                                               float *__restrict__ packed)
+{
+    const int64_t total = (int64_t)ntp * 16 * nk * 4;                      // (co padded, ci) pairs
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % (nk * 4)), co = (int)(idx / (nk * 4));
+        float g[3][3][3];
+        for (int t = 0; t < 27; ++t) (&g[0][0][0])[t] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * 27 + t] : 0.f;
+        // z axis
+        float gz[3][3][4];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const float w0 = g[i][j][0], w1 = g[i][j][1], w2 = g[i][j][2];
+                gz[i][j][0] = w0; gz[i][j][1] = 0.5f * ((w0 + w2) + w1); gz[i][j][2] = 0.5f * ((w0 + w2) - w1); gz[i][j][3] = w2;
+            }
+        float gy[3][4][4];
+        for (int i = 0; i < 3; ++i)
+            for (int z = 0; z < 4; ++z) {
+                const float w0 = gz[i][0][z], w1 = gz[i][1][z], w2 = gz[i][2][z];
+                gy[i][0][z] = w0; gy[i][1][z] = 0.5f * ((w0 + w2) + w1); gy[i][2][z] = 0.5f * ((w0 + w2) - w1); gy[i][3][z] = w2;
+            }
+        const int tile = co >> 4, j = co & 15, k = ci >> 2, kq = ci & 3;
+        float *dst = packed + ((int64_t)tile * nk + k) * B_TILE + (kq * 16 + j) * 4;
+        for (int y = 0; y < 4; ++y)
+            for (int z = 0; z < 4; ++z) {
+                const float w0 = gy[0][y][z], w1 = gy[1][y][z], w2 = gy[2][y][z];
+                const float u[4] = {w0, 0.5f * ((w0 + w2) + w1), 0.5f * ((w0 + w2) - w1), w2};
+                for (int x = 0; x < 4; ++x) {
+                    const int xi = x * 16 + y * 4 + z;
+                    dst[(xi >> 2) * 256 + (xi & 3)] = u[x];
+                }
+            }
+    }
+}
+
+} // namespace
+
+extern "C" size_t sis3d_conv_k3wino_packed_floats(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0 || cin % 8) return 0;
+    const int nt = (cout + 15) / 16, ntp = (nt + 1) & ~1;
+    return (size_t)ntp * (cin / 4) * B_TILE;
+}
+
+extern "C" int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream)
+{
+    if (!w || !packed || cout <= 0 || cin <= 0 || cin % 8) return SIS3D_EINVAL;
+    const int nt = (cout + 15) / 16, ntp = (nt + 1) & ~1, nk = cin / 4;
+    const int64_t total = (int64_t)ntp * 16 * nk * 4;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), w, cout, cin,
+                       ntp, nk, packed);
+    return sis3d_check_launch();
+}
+
+// 1 when this kernel is expected to beat the direct one (sis3d_conv3d_k3t16) on the layer: its workgroup is a block of 8 x 4 x 8
+// voxels x 32 couts holding 148 KB of LDS (one per CU), so it needs >= ~200 (block, cout pair) items to fill the chip and a
+// channel loop long enough to amortise its ~10 us of prologue + output transform.  Measured (tools/wino_bench.cpp, us, direct ->
+// Winograd): rpn_net 128->256 @24x12x24: 102 -> 60 (pair 194 -> 114); geometry2[0] 128->128: 53 -> 56; 64->64: 17.8 -> 32.
+extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob)
+{
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nprob < 1 || (cin % 8)) return 0;
+    const int64_t items = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ) * (((cout + 15) / 16 + 1) / 2);
+    return items >= 200 && cin >= 64 && cout >= 64 ? 1 : 0;
+}
+
+extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                   const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                                   int out_stride, int out_coff, sis3d_stream_t stream)
+{
+    if (nprob < 1 || nprob > WN_MAXP || !ins || !packed_ws || !outs) return SIS3D_EINVAL;
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || cin_stride < cin || (cin_stride % 4)) return SIS3D_EINVAL;
+    if ((cin % 8) || out_stride < out_coff + cout) return SIS3D_EUNSUPPORTED;        // K-steps of 4 channels, taken two at a time
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    if ((int64_t)X * Y * Z * cin_stride > 0x7fffffffLL) return SIS3D_EUNSUPPORTED;      // 32-bit element offsets in the staging plan
+    WinoArgs a;
+    for (int p = 0; p < WN_MAXP; ++p) {
+        const int s = p < nprob ? p : 0;
+        if (!ins[s] || !packed_ws[s] || !outs[s]) return SIS3D_EINVAL;
+        a.in[p] = ins[s]; a.wp[p] = packed_ws[s]; a.bias[p] = biases ? biases[s] : nullptr; a.out[p] = outs[s];
+    }
+    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.npairs = ((cout + 15) / 16 + 1) / 2; a.nk = cin / 4;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
+    a.nbx = cdiv(X, VX); a.nby = cdiv(Y, VY); a.nbz = cdiv(Z, VZ);
+    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * a.npairs;
+    if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return SIS3D_ELAUNCH;
+    hipLaunchKernelGGL(conv3d_k3wino_kernel, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, as_stream(stream), a);
+    return sis3d_check_launch();
+}

@@ -480,6 +480,12 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
         raise _lib.Sis3dError("conv3d_k3t16: activation has %d channels, packed weight expects %d" % (cin_t, p0.cin))
     if SPLIT_BF16 and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs):
         return conv3d_k3b16(xs, pcs, None, relu=relu, outs=outs, out_coff=out_coff)
+    if WINOGRAD and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs) and \
+            lib().sis3d_conv3d_k3wino_prefer(X, Y, Z, p0.cin, p0.cout, n):
+        try:
+            return conv3d_k3wino(xs, pcs, relu=relu, outs=outs, out_coff=out_coff)
+        except Sis3dUnsupported:
+            pass
     if outs is None:
         outs, out_coff = [new_act(p0.cout, (X, Y, Z), x0.device) for _ in range(n)], 0
     for o in outs:
@@ -495,6 +501,61 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     if rc == -4:
         raise Sis3dUnsupported("conv3d_k3t16: unsupported shape")
     check(rc, "sis3d_conv3d_k3t16")
+    return outs
+
+
+# ---- Winograd F(2x2x2, 3x3x3), exact fp32 (csrc/conv3d_wino.hip): the default route of the k3 convs that conv3d_k3t16 serves
+WINOGRAD = bool(int(_os.environ.get("SIS3D_WINOGRAD", "1") or 0))
+
+
+def set_winograd(on):
+    """Algorithm switch for the k3 / pad-1 convs that run on conv3d_k3t16: True (default) = layers the Winograd kernel is expected
+    to win on (sis3d_conv3d_k3wino_prefer: the two rpn_net_level* convs, 58 % of the network's FLOPs) take Winograd
+    F(2x2x2, 3x3x3) in fp32 (3.375x fewer multiplications; only binary32 adds and fp32 MFMAs, same error class as the direct
+    kernel), False = every layer on the direct implicit-GEMM kernel.  Read at launch / capture time."""
+    global WINOGRAD
+    WINOGRAD = bool(on)
+
+
+def packed_wino(pc):
+    """transformed-weight pack U = G g G^T of a k3 PackedConv (sis3d_conv_k3wino_pack_weight), built on first use"""
+    if getattr(pc, "_packed_wino", None) is None:
+        if getattr(pc, "_w", None) is None:
+            raise Sis3dUnsupported("winograd conv: no fp32 weight kept for this layer")
+        n = lib().sis3d_conv_k3wino_packed_floats(pc.cout, pc.cin)
+        if n == 0:
+            raise Sis3dUnsupported("winograd conv: cin % 8 != 0")
+        pc._packed_wino = torch.empty(n, device=pc._w.device)
+        check(lib().sis3d_conv_k3wino_pack_weight(_ptr(pc._w), pc.cout, pc.cin, _ptr(pc._packed_wino), _stream()), "sis3d_conv_k3wino_pack_weight")
+    return pc._packed_wino
+
+
+def conv3d_k3wino(xs, pcs, relu=True, outs=None, out_coff=0):
+    """Conv3d(k3, p1) + bias (+ ReLU) of 1..4 same-shape problems in one launch of the Winograd kernel (sis3d_conv3d_k3wino)."""
+    n = len(xs)
+    x0, p0 = xs[0], pcs[0]
+    for x, pc in zip(xs, pcs):
+        if not is_cl(x) or x.shape != x0.shape or (pc.cin, pc.cout, pc.k) != (p0.cin, p0.cout, 3) or (pc.bias is None) != (p0.bias is None):
+            raise _lib.Sis3dError("conv3d_k3wino: problems must share shape and geometry (k3)")
+    _, cin_t, X, Y, Z = x0.shape
+    if cin_t != p0.cin:
+        raise _lib.Sis3dError("conv3d_k3wino: activation has %d channels, packed weight expects %d" % (cin_t, p0.cin))
+    wps_t = [packed_wino(pc) for pc in pcs]
+    if outs is None:
+        outs, out_coff = [new_act(p0.cout, (X, Y, Z), x0.device) for _ in range(n)], 0
+    for o in outs:
+        if not is_cl(o) or tuple(o.shape[2:]) != (X, Y, Z) or out_coff + p0.cout > o.shape[1]:
+            raise _lib.Sis3dError("conv3d_k3wino: bad `out`")
+    arr = ctypes.c_void_p * n
+    ins = arr(*[x.data_ptr() for x in xs])
+    wps = arr(*[w.data_ptr() for w in wps_t])
+    bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
+    os_ = arr(*[o.data_ptr() for o in outs])
+    rc = lib().sis3d_conv3d_k3wino(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, EPI_RELU if relu else 0, os_, outs[0].shape[1],
+                                   int(out_coff), _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("conv3d_k3wino: unsupported shape")
+    check(rc, "sis3d_conv3d_k3wino")
     return outs
 
 
@@ -748,7 +809,7 @@ class PackedConv:
                   "sis3d_conv_pw16_pack_weight")
         # second pack for the balanced k3 kernel (csrc/conv3d_t16.hip): [cout/16][cin/32][4][27][64][2]
         self.packed_t16 = None
-        self._w = w if (k == 3 and self.cin % 32 == 0) else None       # kept for the optional split-bf16 pack (packed_b16)
+        self._w = w if k == 3 else None                       # kept for the Winograd pack (packed_wino) and the optional split-bf16 pack
         if k == 3 and self.cin % 32 == 0 and self.cout % 4 == 0 and not K3_LEGACY:
             nt = lib().sis3d_conv_k3t16_packed_floats(self.cout, self.cin)
             self.packed_t16 = torch.empty(nt, device=w.device)

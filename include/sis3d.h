@@ -353,6 +353,23 @@ int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int Y, int Z, 
                        const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
                        int out_stride, int out_coff, int brick, sis3d_stream_t stream);
 
+/* ---- k3 / pad-1 convolution by Winograd F(2x2x2, 3x3x3), exact fp32 (csrc/conv3d_wino.hip) --------------------------------
+ * Replaces the same cuDNN calls as sis3d_conv3d_k3t16 (nn.Conv3d(C, C', 3, padding=1) + bias + ReLU: lib/nets/backbones.py:20-22,
+ * 188-231, lib/nets/network.py:40) with 3.375x fewer multiplications: every operation is a binary32 add or an fp32 MFMA, the
+ * transform matrices hold 0, +-1, +-1/2 only, so the result differs from a direct fp32 convolution by summation order /
+ * association (same error class: ~2-3e-6 against float64 on the rpn_net layer for both).  1..4 same-shape problems per launch,
+ * channels-last activations, any grid size (partial 2x2x2 output blocks are masked), cin % 8 == 0, output may be a channel
+ * slice (out_stride, out_coff).  Weights: sis3d_conv_k3wino_pack_weight transforms (Cout,Cin,3,3,3) once (fp32) into
+ * U[cout tile][cin / 4][xi / 4][lane 64][4] (sis3d_conv_k3wino_packed_floats floats).  flags: 0 or SIS3D_EPI_RELU. */
+/* 1 when the Winograd kernel is expected to beat sis3d_conv3d_k3t16 on this layer (enough (block, cout pair) work items to fill
+ * the chip; measured table in csrc/conv3d_wino.hip), else 0: the host-side dispatch rule */
+int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob);
+size_t sis3d_conv_k3wino_packed_floats(int cout, int cin);
+int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
+int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                        const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                        int out_stride, int out_coff, sis3d_stream_t stream);
+
 /* nprob (<= 4) INDEPENDENT convolutions of identical shape in ONE launch (different input / weights / bias /
  * residual / output pointers; host arrays of device pointers, read at call time).  Used for the two RPN levels
  * (lib/nets/network.py:539,552): their 432 workgroups each leave 80 of the 256 CUs a workgroup short, a single

@@ -1,0 +1,54 @@
+// Stand-alone timing harness of the Winograd k3 kernel (3d-sis_amd/csrc/conv3d_wino.hip) for compile-time experiments:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I3d-sis_amd/csrc -DWN_EXP=<bits> tools/wino_bench.cpp \
+//         3d-sis_amd/csrc/conv3d_wino.hip 3d-sis_amd/csrc/api.hip -o tools/_bin/wino_bench_<bits>
+//   tools/_bin/wino_bench_<bits> [cin cout X Y Z nprob]      -> us per launch (HIP events around 20 back-to-back launches, best of 5)
+// No torch, no Python: the variants with WN_EXP != 0 compute garbage on purpose (they remove one cost at a time).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "sis3d.h"
+
+int main(int argc, char **argv)
+{
+    int cin = argc > 1 ? atoi(argv[1]) : 128, cout = argc > 2 ? atoi(argv[2]) : 256;
+    int X = argc > 3 ? atoi(argv[3]) : 24, Y = argc > 4 ? atoi(argv[4]) : 12, Z = argc > 5 ? atoi(argv[5]) : 24;
+    int nprob = argc > 6 ? atoi(argv[6]) : 1;
+    size_t nin = (size_t)X * Y * Z * cin, nout = (size_t)X * Y * Z * cout, nw = (size_t)cout * cin * 27;
+    std::vector<float> h(nin > nw ? nin : nw);
+    srand(1);
+    float *in[4], *out[4], *wp[4], *w, *bias;
+    const float *cin_p[4], *cwp[4], *cb[4];
+    hipMalloc(&w, nw * 4);
+    hipMalloc(&bias, cout * 4);
+    hipMemset(bias, 0, cout * 4);
+    size_t np = sis3d_conv_k3wino_packed_floats(cout, cin);
+    for (int p = 0; p < nprob; ++p) {
+        hipMalloc(&in[p], nin * 4); hipMalloc(&out[p], nout * 4); hipMalloc(&wp[p], np * 4);
+        for (size_t i = 0; i < nin; ++i) { float v = (rand() % 2001 - 1000) * 1e-3f; h[i] = v > 0 ? v : 0; }
+        hipMemcpy(in[p], h.data(), nin * 4, hipMemcpyHostToDevice);
+        for (size_t i = 0; i < nw; ++i) h[i] = (rand() % 2001 - 1000) * 5e-5f;
+        hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice);
+        if (sis3d_conv_k3wino_pack_weight(w, cout, cin, wp[p], nullptr)) return 1;
+        cin_p[p] = in[p]; cwp[p] = wp[p]; cb[p] = bias;
+    }
+    hipDeviceSynchronize();
+    auto launch = [&]() { return sis3d_conv3d_k3wino(nprob, cin_p, X, Y, Z, cin, cin, cwp, cb, cout, SIS3D_EPI_RELU, out, cout, 0, nullptr); };
+    for (int i = 0; i < 30; ++i) if (launch()) { printf("launch failed: %s\n", sis3d_last_hip_error()); return 1; }
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        hipEventRecord(e0, nullptr);
+        for (int i = 0; i < 20; ++i) launch();
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms / 20 < best) best = ms / 20;
+    }
+    double fl = 2.0 * X * Y * Z * cout * (double)cin * 27 * nprob;
+    printf("WN_EXP=%d %d->%d %dx%dx%d x%d: %.1f us  (%.1f TF algorithmic, %.1f TF executed)\n", WN_EXP, cin, cout, X, Y, Z, nprob, best * 1e3,
+           fl / best / 1e9, fl / 3.375 / best / 1e9);
+    return 0;
+}
