@@ -58,9 +58,8 @@ constexpr int CHS = 1040;                                       // channel strid
 constexpr int RAW_STAGE = 4 * CHS;                              // floats of one K-step's raw brick (4 channels)
 constexpr int NRAW = 3;                                         // raw ring depth (class-1 waves read one step ahead)
 constexpr int B_TILE = 64 * 64;                                 // floats of one (cout tile, K-step) block of U: [16][64][4]
-constexpr int B_STAGE = 2 * B_TILE;
 constexpr int NBST = 3;                                         // U ring depth: LDS-DMA lands ~1 us after issue -> two steps ahead
-constexpr int LDS_FLOATS = NRAW * RAW_STAGE + NBST * B_STAGE;   // 37,056 floats = 148,224 B
+constexpr int lds_floats(int nc) { return NRAW * RAW_STAGE + NBST * nc * B_TILE; }    // NC = 2: 37,056 floats = 148,224 B; NC = 1: 98 KB
 constexpr int NVOX = HX * HY * HZ;                              // 600 staging items (voxel x 4 channels)
 constexpr int NTHR = 256;                                        // 4 waves, one per SIMD
 constexpr int NIT = (NVOX + NTHR - 1) / NTHR;
@@ -72,7 +71,7 @@ struct WinoArgs {
     float *out[WN_MAXP];
     int X, Y, Z;
     int cin_stride;
-    int cout, npairs;          // npairs = ceil(ceil(cout/16) / 2)
+    int cout, ngroups;         // ngroups = ceil(ceil(cout/16) / NC): cout-tile groups, one per workgroup
     int nk;                    // cin / 4
     int flags;
     int out_stride, out_coff;
@@ -171,8 +170,8 @@ struct NextV {
     }
 };
 
-template <int H>
-__device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int pair)
+template <int H, int NC>
+__device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,7 +185,8 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     const int nk = a.nk;
 
     float *raw = lds;                                   // [NRAW][4][CHS]
-    float *bst = lds + NRAW * RAW_STAGE;                // [NBST][2][16][64][4]
+    constexpr int B_STAGE = NC * B_TILE;                // floats of one K-step's U stage: NC cout tiles
+    float *bst = lds + NRAW * RAW_STAGE;                // [NBST][NC][16][64][4]
 
     // ---- staging plan: item = halo voxel (4 channels = one float4 of its channels-last row).  Branch-free and VALU-free (an
     // fp32 VALU instruction costs the wave a 4-cycle issue slot that the matrix pipe cannot overlap): addresses are a uniform
@@ -223,32 +223,34 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         dst[2 * CHS] = sv[it][2];
         dst[3 * CHS] = sv[it][3];
     };
-    // U stage of K-step k: 32 wave-instructions of 1 KB, eight per wave: block n = 8 wave + i = (cout tile n >> 4, xi quad n & 15)
-    const float *wbase = p_wp + (size_t)(2 * pair) * nk * B_TILE;
+    // U stage of K-step k: 16 NC wave-instructions of 1 KB, 4 NC per wave: block n = 4 NC wave + i = (cout tile n >> 4, xi quad n & 15)
+    constexpr int NFILL = 4 * NC;
+    const float *wbase = p_wp + (size_t)(NC * grp) * nk * B_TILE;
     const int woff = lane * 4;
     auto fill_b_item = [&](auto I, int k, int buf) {
         constexpr int i = decltype(I)::value;
-        const int n = wave * 8 + i, cc = n >> 4, xq = n & 15;
+        const int n = wave * NFILL + i, cc = n >> 4, xq = n & 15;
         glds16((wbase + ((size_t)cc * nk + k) * B_TILE + xq * 256) + woff, bst + buf * B_STAGE + n * 256);
     };
 
-    f32x4 acc[2][32];                                    // [cout tile c][xi of this half]
-    static_for<0, 64>([&](auto I) { acc[decltype(I)::value >> 5][decltype(I)::value & 31] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
+    f32x4 acc[NC][32];                                   // [cout tile c][xi of this half]
+    static_for<0, 32 * NC>([&](auto I) { acc[decltype(I)::value >> 5][decltype(I)::value & 31] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
 
     // lane (li, kq): tile li of group g = (txl, ty, tz), channel kq of the K-step
     const int txl = li >> 3, ty = (li >> 2) & 1, tz = li & 3;
     const int rbase = kq * CHS + (2 * (2 * g + txl)) * PS + (2 * ty) * HZS + 2 * tz;
     const int bbase = H * 8 * 256 + lane * 4;
 
-    // ---- prologue: U stages 0 and 1 and raw stages 0 and 1 all in flight together, then V of step 0
-    static_for<0, 8>([&](auto I) { fill_b_item(I, 0, 0); });
-    static_for<0, 8>([&](auto I) { fill_b_item(I, nk > 1 ? 1 : 0, 1); });
+    // ---- prologue: U stages 0 and 1 and raw stages 0 and 1 all in flight together (one wait), then V of step 0
+    static_for<0, NFILL>([&](auto I) { fill_b_item(I, 0, 0); });
     static_for<0, NIT>([&](auto I) { stage_load_item(I, 0); });
+    f32x4 sw[NIT];
+    static_for<0, NIT>([&](auto I) { load16_asm(sw[decltype(I)::value], goff[decltype(I)::value] * 4, p_in + (nk > 1 ? 4 : 0)); });
+    static_for<0, NFILL>([&](auto I) { fill_b_item(I, nk > 1 ? 1 : 0, 1); });
     wait_vmcnt<0>(sv[0], sv[1], sv[2]);
+    wait_vmcnt<0>(sw[0], sw[1], sw[2]);
     static_for<0, NIT>([&](auto I) { stage_store_item(I, 0); });
-    static_for<0, NIT>([&](auto I) { stage_load_item(I, nk > 1 ? 1 : 0); });
-    wait_vmcnt<0>(sv[0], sv[1], sv[2]);
-    static_for<0, NIT>([&](auto I) { stage_store_item(I, 1); });
+    static_for<0, NIT>([&](auto I) { sv[decltype(I)::value] = sw[decltype(I)::value]; stage_store_item(I, 1); });
     __syncthreads();
     // V ping-pongs between two NextV objects (no register copies): step k multiplies with one while the other is being built
     NextV<H> va, vb;
@@ -269,11 +271,10 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // no branches in the block.
     static_assert(NIT == 3, "the counted waits below assume three staging loads and eight DMA instructions per step");
     int cur = 0;                                         // k % 3: raw stage of step k, U stage of step k
-    f32x4 bq[4][2];                                      // ring over xi quads (slot q & 3), both cout tiles
+    f32x4 bq[4][NC];                                     // ring over xi quads (slot q & 3), every cout tile of the group
     auto read_b = [&](auto Q, const float *bs) {
         constexpr int q = decltype(Q)::value;
-        bq[q & 3][0] = *reinterpret_cast<const f32x4 *>(bs + q * 256);
-        bq[q & 3][1] = *reinterpret_cast<const f32x4 *>(bs + B_TILE + q * 256);
+        static_for<0, NC>([&](auto C) { bq[q & 3][decltype(C)::value] = *reinterpret_cast<const f32x4 *>(bs + decltype(C)::value * B_TILE + q * 256); });
     };
     read_b(std::integral_constant<int, 0>{}, bst + bbase);
     read_b(std::integral_constant<int, 1>{}, bst + bbase);
@@ -294,14 +295,18 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
                 read_b(std::integral_constant<int, 0>{}, bs_next);
                 read_b(std::integral_constant<int, 1>{}, bs_next);
             }
-            static_for<0, 8>([&](auto E) {
-                constexpr int e8 = decltype(E)::value, e = e8 >> 1, cc = e8 & 1, m = 8 * q + e8;
+            static_for<0, 4 * NC>([&](auto E) {
+                constexpr int en = decltype(E)::value, e = en / NC, cc = en % NC, m = 4 * NC * q + en;
                 acc[cc][4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vu.T[q >> 2][q & 3][e], bq[q & 3][cc][e], acc[cc][4 * q + e], 0, 0, 0);
-                if constexpr (!(WN_EXP & 16)) vn.template unit<m>(rn);
-                if constexpr (m >= 1 && m < 1 + 2 * NIT && (m & 1) == 1 && !(WN_EXP & 2)) stage_load_item(std::integral_constant<int, (m - 1) / 2>{}, ks);
-                if constexpr (m >= 7 && m < 23 && (m & 1) == 1 && !(WN_EXP & 1)) fill_b_item(std::integral_constant<int, (m - 7) / 2>{}, ks, nn);
-                if constexpr (m == 40 && !(WN_EXP & 2)) wait_vmcnt<8>(sv[0], sv[1], sv[2]);
-                if constexpr (m >= 41 && m < 41 + 2 * NIT && (m & 1) == 1 && !(WN_EXP & 2)) stage_store_item(std::integral_constant<int, (m - 41) / 2>{}, nn);
+                // the units are laid out on 64 virtual slots: one per MFMA with two cout tiles, two per MFMA with one
+                static_for<0, 2 / NC>([&](auto V) {
+                    constexpr int sl = m * (2 / NC) + decltype(V)::value;
+                    if constexpr (!(WN_EXP & 16)) vn.template unit<sl>(rn);
+                    if constexpr (sl >= 1 && sl < 1 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_load_item(std::integral_constant<int, (sl - 1) / 2>{}, ks);
+                    if constexpr (sl >= 7 && sl < 7 + 2 * NFILL && (sl & 1) == 1 && !(WN_EXP & 1)) fill_b_item(std::integral_constant<int, (sl - 7) / 2>{}, ks, nn);
+                    if constexpr (sl == 40 && !(WN_EXP & 2)) wait_vmcnt<NFILL>(sv[0], sv[1], sv[2]);
+                    if constexpr (sl >= 41 && sl < 41 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_store_item(std::integral_constant<int, (sl - 41) / 2>{}, nn);
+                });
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -324,8 +329,8 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // other two to its partner.
     const int j = lane & 15, q4 = lane >> 4;
     float *__restrict__ p_out = a.out[prob];
-    float P[2][4][8];                                    // [cout tile][row r][ox oy oz]
-    static_for<0, 2>([&](auto C) {
+    float P[NC][4][8];                                   // [cout tile][row r][ox oy oz]
+    static_for<0, NC>([&](auto C) {
         constexpr int cc = decltype(C)::value;
         static_for<0, 4>([&](auto R) {
             constexpr int r = decltype(R)::value;
@@ -360,7 +365,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
                 }
             });
             if constexpr ((r >> 1) != H) {               // the partner finishes this row
-                float *scr = bst + ((g * 2 + cc) * 4 + r) * (8 * 64) + lane;
+                float *scr = bst + ((g * NC + cc) * 4 + r) * (8 * 64) + lane;
                 static_for<0, 8>([&](auto O) { scr[decltype(O)::value * 64] = P[cc][r][decltype(O)::value]; });
             }
         });
@@ -368,14 +373,14 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     __syncthreads();
     // finish rows r = 2H, 2H + 1: + partner's partial, + bias, ReLU; transpose through LDS (second U stage) so that a lane
     // stores 16 B = four consecutive couts of one voxel: [cc][voxel = (r', tile quad q4, o)][cout 16] per wave
-    float *tr = bst + B_STAGE + wave * (2 * 2 * 4 * 8 * 16);
-    static_for<0, 2>([&](auto C) {
+    float *tr = bst + B_STAGE + wave * (NC * 2 * 4 * 8 * 16);
+    static_for<0, NC>([&](auto C) {
         constexpr int cc = decltype(C)::value;
-        const int co = 16 * (2 * pair + cc) + j;
+        const int co = 16 * (NC * grp + cc) + j;
         const float bv = (a.bias[prob] && co < a.cout) ? a.bias[prob][co] : 0.f;
         static_for<0, 2>([&](auto RR) {
             constexpr int rr = decltype(RR)::value, r = 2 * H + rr;
-            const float *scr = bst + ((g * 2 + cc) * 4 + r) * (8 * 64) + lane;
+            const float *scr = bst + ((g * NC + cc) * 4 + r) * (8 * 64) + lane;
             static_for<0, 8>([&](auto O) {
                 constexpr int o = decltype(O)::value;
                 float v = (P[cc][r][o] + scr[o * 64]) + bv;
@@ -387,14 +392,14 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // wave-local exchange: every lane reads what other lanes of its own wave wrote
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    static_for<0, 8>([&](auto S) {
-        constexpr int sidx = decltype(S)::value;                    // 128 voxel rows (cc, rr, q4, o) x 4 float4 = 512 pieces / 64 lanes
+    static_for<0, 4 * NC>([&](auto S) {
+        constexpr int sidx = decltype(S)::value;                    // 64 NC voxel rows (cc, rr, q4, o) x 4 float4 pieces / 64 lanes
         const int piece = sidx * 64 + lane, row = piece >> 2, c4 = piece & 3;
         const int o = row & 7, tq = (row >> 3) & 3, rr = (row >> 5) & 1, cc = row >> 6;
         const float4 v = *reinterpret_cast<const float4 *>(tr + row * 16 + c4 * 4);
         const int tl = 4 * tq + 2 * H + rr;
         const int x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2), y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1), z = oz0 + 2 * (tl & 3) + (o & 1);
-        const int co = 16 * (2 * pair + cc) + 4 * c4;
+        const int co = 16 * (NC * grp + cc) + 4 * c4;
         if (x < gX && y < gY && z < gZ && (!(WN_EXP & 32) || v.x == 123.456f)) {
             float *dst = p_out + ((size_t)(x * gY + y) * gZ + z) * a.out_stride + a.out_coff + co;
             if (co + 3 < a.cout && (((a.out_stride | a.out_coff) & 3) == 0)) {
@@ -409,22 +414,23 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     });
 }
 
+template <int NC>
 __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // work list: cout pair major, block minor; every XCD (block b runs on XCD b % 8, private L2) takes one contiguous range
-    // of it, i.e. few cout pairs x all blocks: its L2 holds 1/8 of U (8.4 MB for rpn_net) and the whole activation map
+    // work list: cout group major, block minor; every XCD (block b runs on XCD b % 8, private L2) takes one contiguous range
+    // of it, i.e. few cout groups x all blocks: its L2 holds 1/8 of U (8.4 MB for rpn_net) and the whole activation map
     int wid;
     {
         const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
         wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
     }
     const int nbr = a.nbx * a.nby * a.nbz;
-    const int pair = wid / nbr, brick = wid - pair * nbr;
-    // waves (h, g): h = xi_x half, g = tile group; each wave serves both cout tiles of the pair
+    const int grp = wid / nbr, brick = wid - grp * nbr;
+    // waves (h, g): h = xi_x half, g = tile group; each wave serves every cout tile of the group
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-    if (h == 0) wino_wave<0>(a, lds, blockIdx.y, brick, pair);
-    else wino_wave<1>(a, lds, blockIdx.y, brick, pair);
+    if (h == 0) wino_wave<0, NC>(a, lds, blockIdx.y, brick, grp);
+    else wino_wave<1, NC>(a, lds, blockIdx.y, brick, grp);
 }
 
 // (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:
@@ -484,15 +490,24 @@ extern "C" int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, 
     return sis3d_check_launch();
 }
 
-// 1 when this kernel is expected to beat the direct one (sis3d_conv3d_k3t16) on the layer: its workgroup is a block of 8 x 4 x 8
-// voxels x 32 couts holding 148 KB of LDS (one per CU), so it needs >= ~200 (block, cout pair) items to fill the chip and a
-// channel loop long enough to amortise its ~10 us of prologue + output transform.  Measured (tools/wino_bench.cpp, us, direct ->
-// Winograd): rpn_net 128->256 @24x12x24: 102 -> 60 (pair 194 -> 114); geometry2[0] 128->128: 53 -> 56; 64->64: 17.8 -> 32.
+// Cout tiles per workgroup this kernel would use on the layer (2 or 1), or 0 when the direct kernel (sis3d_conv3d_k3t16) is
+// expected to win.  A workgroup is a block of 8 x 4 x 8 voxels x 16 NC couts, one per CU (148 / 98 KB of LDS), so the layer needs
+// >= ~200 (block, cout group) items to fill the chip -- with two cout tiles per wave if that still gives 200 (the input
+// transform is shared by both), else with one -- and a channel loop long enough to amortise ~10 us of prologue + output
+// transform.  Measured (tools/wino_bench.cpp, us, direct -> Winograd): rpn_net 128->256 @24x12x24: 102 -> 58 (pair 194 -> 112).
+static int wino_nc(int X, int Y, int Z, int cin, int cout)
+{
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin < 64 || cout < 64 || (cin % 8)) return 0;
+    const int64_t blocks = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ);
+    const int nt = (cout + 15) / 16;
+    if (blocks * ((nt + 1) / 2) >= 200) return 2;
+    if (blocks * nt >= 200 && cin >= 128) return 1;
+    return 0;
+}
+
 extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob)
 {
-    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nprob < 1 || (cin % 8)) return 0;
-    const int64_t items = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ) * (((cout + 15) / 16 + 1) / 2);
-    return items >= 200 && cin >= 64 && cout >= 64 ? 1 : 0;
+    return nprob >= 1 && wino_nc(X, Y, Z, cin, cout) > 0 ? 1 : 0;
 }
 
 extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
@@ -510,14 +525,21 @@ extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, in
         if (!ins[s] || !packed_ws[s] || !outs[s]) return SIS3D_EINVAL;
         a.in[p] = ins[s]; a.wp[p] = packed_ws[s]; a.bias[p] = biases ? biases[s] : nullptr; a.out[p] = outs[s];
     }
-    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.npairs = ((cout + 15) / 16 + 1) / 2; a.nk = cin / 4;
+    static const int force_nc = [] { const char *e = getenv("SIS3D_WINO_NC"); return e ? atoi(e) : 0; }();      // tuning hook
+    int nc = force_nc == 1 || force_nc == 2 ? force_nc : wino_nc(X, Y, Z, cin, cout);
+    if (nc == 0) nc = 2;                                 // called directly on a layer the dispatch rule would not send here
+    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ngroups = ((cout + 15) / 16 + nc - 1) / nc; a.nk = cin / 4;
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
     a.nbx = cdiv(X, VX); a.nby = cdiv(Y, VY); a.nbz = cdiv(Z, VZ);
-    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * a.npairs;
+    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups;
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
-    constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SIS3D_ELAUNCH;
-    hipLaunchKernelGGL(conv3d_k3wino_kernel, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, as_stream(stream), a);
+    const size_t lds = (size_t)lds_floats(nc) * sizeof(float);
+    static const hipError_t attr2 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(lds_floats(2) * sizeof(float)));
+    static const hipError_t attr1 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(lds_floats(1) * sizeof(float)));
+    if (attr1 != hipSuccess || attr2 != hipSuccess) return SIS3D_ELAUNCH;
+    if (nc == 2) hipLaunchKernelGGL(conv3d_k3wino_kernel<2>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL(conv3d_k3wino_kernel<1>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, as_stream(stream), a);
     return sis3d_check_launch();
 }
