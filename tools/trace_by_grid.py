@@ -12,7 +12,8 @@ def main():
     agg = collections.defaultdict(list)
     for r in rows:
         n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])
-        key = (n[:100], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Workgroup_Size_X"]),
+        gy = int(r.get("Grid_Size_Y", 1) or 1) // max(1, int(r.get("Workgroup_Size_Y", 1) or 1))
+        key = (n[:100] + (" [x%d problems]" % gy if gy > 1 else ""), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Workgroup_Size_X"]),
                r.get("VGPR_Count", ""), r.get("LDS_Block_Size", ""))
         agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     tot = sum(sum(v) for v in agg.values()) or 1.0
