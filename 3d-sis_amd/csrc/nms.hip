@@ -448,8 +448,9 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
         hipLaunchKernelGGL((nms_cand_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, nullptr, 6, thresh, mask, nz, nzw);
         int rc = sis3d_check_launch();
         if (rc) return rc;
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // granted once, at the largest size any launch may ask for (never lowered by a later, smaller launch)
+        static const hipError_t lds_ok = hipFuncSetAttribute((const void *)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
         hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), lds, st, mask, nz, nzw, n, nullptr, max_keep, keep, num_keep);
         return sis3d_check_launch();
     }
@@ -471,8 +472,10 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     if (need() > LDS_LIMIT) return SIS3D_EUNSUPPORTED;
     const size_t lds = need();
     auto kern = nms_sweep_kernel<SELECT>;
-    // per call: the attribute is per device (and this may be another thread's first call); it costs < 1 us
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+    // once per instantiation (one process drives one GPU): not per launch, so that no attribute write can coincide with the
+    // enqueue of a captured graph that contains this kernel
+    static const hipError_t lds_ok = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+    if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, mask, n, max_keep, keep, num_keep, boxes, level_all, scores_sorted, order,
                        rois, roi_scores, roi_levels, stage_mask, stage_meta);
     return sis3d_check_launch();
@@ -544,8 +547,8 @@ extern "C" int sis3d_scene_merge(const float *blocks, int n_chunks, int k_rows, 
     int rc = sis3d_check_launch();
     if (rc) return rc;
     const size_t sort_lds = (size_t)((T + 255) & ~255) * 8;
-    if (sort_lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)scene_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+    static const hipError_t rank_lds_ok = hipFuncSetAttribute((const void *)scene_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);     // once
+    if (rank_lds_ok != hipSuccess || sort_lds > 160 * 1024 - 64) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(scene_rank_kernel, dim3((T + 63) / 64), dim3(1024), sort_lds, st, blocks, mask, counts, k_rows, width, recs, order);
     rc = sis3d_check_launch();
     if (rc) return rc;
