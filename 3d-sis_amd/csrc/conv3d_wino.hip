@@ -15,24 +15,25 @@
 // In the transformed domain the layer is 64 independent GEMMs  M_xi[tile][cout] = V_xi[tile][cin] * U_xi[cin][cout]
 // (xi = the 4x4x4 positions of a transformed input tile, tile = a 2x2x2 output block).  Mapping on the chip:
 //   * v_mfma_f32_16x16x4_f32: A = V_xi (16 tiles x 4 channels), B = U_xi (4 channels x 16 couts), one accumulator tile per xi.
-//     All xi of a (tile, cout) pair must stay live over the whole channel loop: 64 x 4 registers -- so a wave takes HALF of
-//     them (xi_x in {2h, 2h+1}: 128 accumulator registers) and two waves per SIMD are resident (<= 256 registers each), which
-//     also gives the hardware a second instruction stream: the input transform is ~3 VALU operations per MFMA and a single
-//     in-order wave cannot issue that many beside its MFMAs.
-//   * workgroup = 8 waves (h, g, c) = a block of 4 x 2 x 4 Winograd tiles (8 x 4 x 8 output voxels; g = which 16 tiles)
-//     x 2 cout tiles (c) x the two xi halves (h).  rpn_net 128 -> 256 on 24 x 12 x 24: 27 blocks x 8 cout pairs = 216
-//     workgroups, one per CU.
+//     All xi of a (tile, cout) pair must stay live over the whole channel loop (64 x 4 registers) and every MFMA needs a fresh A
+//     and a fresh B operand.  A wave therefore takes HALF of the xi (xi_x in {2h, 2h+1}) for 16 tiles and NC = 2 (or 1) cout tiles:
+//     128 NC accumulator registers (the AGPR half of the file), one wave per SIMD, and every transformed input value feeds NC MFMAs.
+//   * workgroup = 4 waves (h, g) = a block of 4 x 2 x 4 Winograd tiles (8 x 4 x 8 output voxels; g = which 16 tiles) x NC cout
+//     tiles.  rpn_net 128 -> 256 on 24 x 12 x 24: 27 blocks x 8 cout pairs = 216 workgroups, one per CU; geometry2[0] 128 -> 128:
+//     NC = 1, 27 x 8 = 216.  sis3d_conv3d_k3wino_prefer says which layers have enough work items; the rest stay on conv3d_t16.hip.
 //   * V is never materialised: the raw halo brick (10 x 6 x 10 voxels) of the 4 channels of a K-step is staged in LDS in a
 //     planar layout [channel][x][y][z] whose strides (16, 100, 1040 floats) put the 32 lanes of a ds_read_b64 group on 32
 //     distinct bank pairs; a lane (tile, channel) reads the 3 x-planes its xi half needs (24 x 8 B) and transforms them in
-//     registers (96 adds) into the A operands of its 32 MFMAs.
-//   * U (the transformed weights, packed once: [cout tile][K-step][xi / 4][lane][4]) streams through a double-buffered
-//     32 KB LDS stage filled by LDS-DMA (global_load_lds_dwordx4: no staging registers); a lane's B operands of a K-step are
-//     8 x ds_read_b128.
-//   * the two waves of a SIMD run half a step apart: class-1 waves transform the NEXT step's input behind their MFMAs,
-//     before the barrier, class-0 waves after it -- so one wave of each SIMD multiplies while the other transforms.
-//   * epilogue: output transform in registers (per lane: 32 xi -> 8 partial outputs per tile), the two xi halves are added
-//     through LDS, + bias, ReLU, store.
+//     registers (96 adds) into the A operands of its 32 NC MFMAs -- for the NEXT step, as 28 small units issued one behind each
+//     MFMA of the current step (struct NextV), ping-ponging between two register sets.
+//   * U (the transformed weights, packed once: [cout tile][K-step][xi / 4][lane][4]) streams through a three-deep LDS ring filled
+//     by LDS-DMA (global_load_lds_dwordx4: no staging registers) two steps ahead; a lane's B operands of a K-step are 8 NC x
+//     ds_read_b128 through a four-quad register ring.
+//   * gfx950 does not overlap a wave's fp32 MFMAs with its other instructions (measured: 36.7 cycles per MFMA + 4 per other
+//     instruction), so the loop is built to issue as few as possible: addresses are uniform bases + fixed lane offsets, no branch
+//     and no select in the block, the one barrier per step sits inside the MFMA block, every wait is counted.
+//   * epilogue: output transform in registers (per lane: 32 xi -> 8 partial outputs per tile and cout tile), the two xi halves
+//     meet through LDS (each wave finishes two of its four rows), + bias, ReLU, a wave-local LDS transpose, 16 B stores.
 // The weight transform (G g G^T per axis) runs once at pack time in fp32.
 #include "common.h"
 #include "mfma16.h"
@@ -56,7 +57,7 @@ constexpr int HZS = 16;                                         // LDS row strid
 constexpr int PS = 100;                                         // x-plane stride: >= HY * HZS, == 4 (mod 32)
 constexpr int CHS = 1040;                                       // channel stride: >= HX * PS, == 16 (mod 64)
 constexpr int RAW_STAGE = 4 * CHS;                              // floats of one K-step's raw brick (4 channels)
-constexpr int NRAW = 3;                                         // raw ring depth (class-1 waves read one step ahead)
+constexpr int NRAW = 3;                                         // raw ring depth: step k + 1 is transformed during step k, k + 2 is being staged
 constexpr int B_TILE = 64 * 64;                                 // floats of one (cout tile, K-step) block of U: [16][64][4]
 constexpr int NBST = 3;                                         // U ring depth: LDS-DMA lands ~1 us after issue -> two steps ahead
 constexpr int lds_floats(int nc) { return NRAW * RAW_STAGE + NBST * nc * B_TILE; }    // NC = 2: 37,056 floats = 148,224 B; NC = 1: 98 KB
