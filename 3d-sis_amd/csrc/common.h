@@ -18,5 +18,15 @@ static inline int sis3d_check_launch()
     return SIS3D_OK;
 }
 
+// grant a kernel the largest dynamic LDS size it can ever be launched with (160 KB minus its static LDS).  Called ONCE per kernel
+// (function-local static at the call site), never per launch and never with a smaller value later.
+static inline hipError_t sis3d_allow_max_lds(const void *kern)
+{
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, kern);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+}
+
 static inline hipStream_t as_stream(sis3d_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

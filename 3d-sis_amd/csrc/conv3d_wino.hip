@@ -65,6 +65,16 @@ constexpr int NVOX = HX * HY * HZ;                              // 600 staging i
 constexpr int NTHR = 256;                                        // 4 waves, one per SIMD
 constexpr int NIT = (NVOX + NTHR - 1) / NTHR;
 
+// ragged batch (the mask head: one launch per layer for all detected boxes' crops): problems of different grid sizes packed back to
+// back in one activation buffer; same descriptor layout as conv3d_t16.hip / conv3d.hip's ragged launches (ops.MaskPlan)
+struct WinoRagged {
+    int X, Y, Z;
+    int nbx, nby, nbz;         // 8 x 4 x 8 blocks per axis
+    int block0;                // first work item (block x cout group) of this problem
+    int pad;
+    int64_t in_off, out_off;   // element offsets of this problem's activations inside the packed in / out buffers
+};
+
 struct WinoArgs {
     const float *in[WN_MAXP];
     const float *wp[WN_MAXP];
@@ -77,6 +87,8 @@ struct WinoArgs {
     int flags;
     int out_stride, out_coff;
     int nbx, nby, nbz;
+    const WinoRagged *rag;
+    int nrag;
 };
 
 __device__ __forceinline__ void glds16(const float *gsrc, float *lds_dst)
@@ -172,16 +184,16 @@ struct NextV {
 };
 
 template <int H, int NC>
-__device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp)
+__device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp, int gX, int gY, int gZ, int nby, int nbz,
+                                          int64_t in_off, int64_t out_off)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave & 1;
     const int li = lane & 15, kq = lane >> 4;
-    const int gX = a.X, gY = a.Y, gZ = a.Z;
-    const int bz = brick % a.nbz, by = (brick / a.nbz) % a.nby, bx = brick / (a.nbz * a.nby);
+    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
     const int ox0 = bx * VX, oy0 = by * VY, oz0 = bz * VZ;
-    const float *__restrict__ p_in = a.in[prob];
+    const float *__restrict__ p_in = a.in[prob] + in_off;
     const float *__restrict__ p_wp = a.wp[prob];
     const int nk = a.nk;
 
@@ -329,7 +341,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // is in flight): each wave FINISHES two of the four rows (H = 0: r = 0, 1; H = 1: r = 2, 3) and ships the partials of the
     // other two to its partner.
     const int j = lane & 15, q4 = lane >> 4;
-    float *__restrict__ p_out = a.out[prob];
+    float *__restrict__ p_out = a.out[prob] + out_off;
     float P[NC][4][8];                                   // [cout tile][row r][ox oy oz]
     static_for<0, NC>([&](auto C) {
         constexpr int cc = decltype(C)::value;
@@ -426,12 +438,30 @@ __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a
         const int nb = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8, qd = nb / 8, rm = nb % 8;
         wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
     }
-    const int nbr = a.nbx * a.nby * a.nbz;
-    const int grp = wid / nbr, brick = wid - grp * nbr;
+    int gX = a.X, gY = a.Y, gZ = a.Z, nby = a.nby, nbz = a.nbz, grp, brick;
+    int64_t in_off = 0, out_off = 0;
+    if (a.nrag > 0) {
+        // this workgroup's problem (block0 ascending): uniform -> scalar loads; work items of a problem are cout-group fastest
+        int lo = 0, hi = a.nrag - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.rag[mid].block0 <= wid) lo = mid; else hi = mid - 1;
+        }
+        const WinoRagged d = a.rag[lo];
+        wid -= d.block0;
+        gX = d.X; gY = d.Y; gZ = d.Z; nby = d.nby; nbz = d.nbz;
+        in_off = d.in_off; out_off = d.out_off;
+        grp = wid % a.ngroups;
+        brick = wid / a.ngroups;
+    } else {
+        const int nbr = a.nbx * a.nby * a.nbz;
+        grp = wid / nbr;
+        brick = wid - grp * nbr;
+    }
     // waves (h, g): h = xi_x half, g = tile group; each wave serves every cout tile of the group
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-    if (h == 0) wino_wave<0, NC>(a, lds, blockIdx.y, brick, grp);
-    else wino_wave<1, NC>(a, lds, blockIdx.y, brick, grp);
+    if (h == 0) wino_wave<0, NC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    else wino_wave<1, NC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
 }
 
 // (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:
@@ -511,6 +541,21 @@ extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout
     return nprob >= 1 && wino_nc(X, Y, Z, cin, cout) > 0 ? 1 : 0;
 }
 
+static int launch_wino(WinoArgs &a, int nc, int64_t nwg, int nprob, hipStream_t st)
+{
+    if (nwg <= 0 || nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    const size_t lds = (size_t)lds_floats(nc) * sizeof(float);
+    // once per instantiation, never per launch (see the note in conv3d_t16.hip)
+    static const hipError_t attr2 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(lds_floats(2) * sizeof(float)));
+    static const hipError_t attr1 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(lds_floats(1) * sizeof(float)));
+    if (attr1 != hipSuccess || attr2 != hipSuccess) return SIS3D_ELAUNCH;
+    if (nc == 2) hipLaunchKernelGGL(conv3d_k3wino_kernel<2>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
+    else hipLaunchKernelGGL(conv3d_k3wino_kernel<1>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
+    return sis3d_check_launch();
+}
+
 extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
                                    const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
                                    int out_stride, int out_coff, sis3d_stream_t stream)
@@ -532,15 +577,34 @@ extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, in
     a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ngroups = ((cout + 15) / 16 + nc - 1) / nc; a.nk = cin / 4;
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
     a.nbx = cdiv(X, VX); a.nby = cdiv(Y, VY); a.nbz = cdiv(Z, VZ);
-    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz * a.ngroups;
-    if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
-    const size_t lds = (size_t)lds_floats(nc) * sizeof(float);
-    static const hipError_t attr2 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)(lds_floats(2) * sizeof(float)));
-    static const hipError_t attr1 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)(lds_floats(1) * sizeof(float)));
-    if (attr1 != hipSuccess || attr2 != hipSuccess) return SIS3D_ELAUNCH;
-    if (nc == 2) hipLaunchKernelGGL(conv3d_k3wino_kernel<2>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, as_stream(stream), a);
-    else hipLaunchKernelGGL(conv3d_k3wino_kernel<1>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, as_stream(stream), a);
-    return sis3d_check_launch();
+    a.rag = nullptr; a.nrag = 0;
+    return launch_wino(a, nc, (int64_t)a.nbx * a.nby * a.nbz * a.ngroups, nprob, as_stream(stream));
+}
+
+// ---- ragged batch: every detected box's mask-head crop (lib/nets/network.py:303-317, backbones.py:243-249) through ONE launch per k3
+// layer.  Work items: (crop, 8 x 4 x 8 block, group of two cout tiles); the descriptor table is ops.MaskPlan's (block0 counts
+// blocks x groups).  The caller asks sis3d_ragged_tiling_k3wino for the block and the group count first.
+extern "C" int sis3d_ragged_tiling_k3wino(int cin, int cout, int *bx, int *by, int *bz, int *ngroups)
+{
+    if (!bx || !by || !bz || !ngroups) return SIS3D_EINVAL;
+    if ((cin % 8) || cin <= 0 || cout <= 0) return SIS3D_EUNSUPPORTED;
+    *bx = VX; *by = VY; *bz = VZ;
+    *ngroups = ((cout + 15) / 16 + 1) / 2;
+    return SIS3D_OK;
+}
+
+extern "C" int sis3d_conv3d_k3wino_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                                          int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks,
+                                          sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || !desc_dev || ndesc <= 0 || total_blocks <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
+    if ((cin % 8) || (cin_stride % 4) || cin_stride < cin || out_stride < cout) return SIS3D_EUNSUPPORTED;
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    WinoArgs a;
+    for (int p = 0; p < WN_MAXP; ++p) { a.in[p] = in; a.wp[p] = packed_w; a.bias[p] = bias; a.out[p] = out; }
+    a.X = a.Y = a.Z = 1; a.cin_stride = cin_stride; a.cout = cout; a.ngroups = ((cout + 15) / 16 + 1) / 2; a.nk = cin / 4;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = 0;
+    a.nbx = a.nby = a.nbz = 1;
+    a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
+    return launch_wino(a, 2, total_blocks, 1, as_stream(stream));
 }

@@ -1109,6 +1109,23 @@ class MaskPlan:
                 d3t["in_off"] = voffs[:-1] * C
                 d3t["out_off"] = voffs[:-1] * C
                 self.t16, self.brick_t16, self.blocks_t16 = True, brick, int(blt[-1])
+        # the same layers on the Winograd kernel (csrc/conv3d_wino.hip): 8x4x8 blocks x groups of two cout tiles; taken when the batch
+        # has enough work items to fill the chip (a lone small box stays on the direct kernel)
+        self.wino, self.blocks_wino = False, 0
+        d3w = np.zeros(0, dtype=rdt)
+        tb = [ctypes.c_int() for _ in range(4)]
+        if C % 8 == 0 and lib().sis3d_ragged_tiling_k3wino(C, C, *[ctypes.byref(v) for v in tb]) == 0:
+            wbx, wby, wbz, wng = (v.value for v in tb)
+            nbw = -(-ext // np.array([wbx, wby, wbz]))
+            blw = np.concatenate([[0], np.cumsum(nbw.prod(1) * wng)])
+            d3w = np.zeros(n, dtype=rdt)
+            d3w["X"], d3w["Y"], d3w["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
+            d3w["nbx"], d3w["nby"], d3w["nbz"] = nbw[:, 0], nbw[:, 1], nbw[:, 2]
+            d3w["block0"] = blw[:-1]
+            d3w["in_off"] = voffs[:-1] * C
+            d3w["out_off"] = voffs[:-1] * C
+            self.blocks_wino = int(blw[-1])
+            self.wino = self.blocks_wino >= int(_os.environ.get("SIS3D_MASK_WINO_MIN", "200"))
         # the same layers on the opt-in split-bf16 kernel (csrc/conv3d_b16.hip): 3x6x6 bricks, two cout tiles per workgroup
         self.b16, self.brick_b16, self.blocks_b16 = False, 4, 0
         d3b = np.zeros(0, dtype=rdt)
@@ -1133,7 +1150,7 @@ class MaskPlan:
         self.windows = [tuple(int(v) for v in r) for r in w]
         # ONE upload for the three descriptor tables (each is a blocking pageable copy)
         parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1),
-                 d3t.view(np.uint8).reshape(-1), d3b.view(np.uint8).reshape(-1)]
+                 d3t.view(np.uint8).reshape(-1), d3b.view(np.uint8).reshape(-1), d3w.view(np.uint8).reshape(-1)]
         pad = [(-p.size) % 16 for p in parts]
         host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
         self.devbuf = torch.from_numpy(host).to(device)
@@ -1142,7 +1159,8 @@ class MaskPlan:
         o3 = o2 + parts[2].size + pad[2]
         o4 = o3 + parts[3].size + pad[3]
         self.g3, self.g1, self.gp = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:o3]
-        self.g3t, self.g3b = self.devbuf[o3:o4], self.devbuf[o4:]
+        o5 = o4 + parts[4].size + pad[4]
+        self.g3t, self.g3b, self.g3w = self.devbuf[o3:o4], self.devbuf[o4:o5], self.devbuf[o5:]
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
         self.out = torch.empty(self.voxels, NC, device=device)
@@ -1173,6 +1191,9 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
         if SPLIT_BF16 and plan.b16 and getattr(pc, "_w", None) is not None:
             check(lib().sis3d_conv3d_k3b16_ragged(_ptr(src), C, C, _ptr(packed_b16(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                   _ptr(plan.g3b), n, plan.blocks_b16, plan.brick_b16, _stream()), "sis3d_conv3d_k3b16_ragged")
+        elif WINOGRAD and plan.wino and getattr(pc, "_w", None) is not None:
+            check(lib().sis3d_conv3d_k3wino_ragged(_ptr(src), C, C, _ptr(packed_wino(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
+                                                   _ptr(plan.g3w), n, plan.blocks_wino, _stream()), "sis3d_conv3d_k3wino_ragged")
         elif plan.t16 and pc.packed_t16 is not None:
             check(lib().sis3d_conv3d_k3t16_ragged(_ptr(src), C, C, _ptr(pc.packed_t16), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                   _ptr(plan.g3t), n, plan.blocks_t16, plan.brick_t16, _stream()), "sis3d_conv3d_k3t16_ragged")

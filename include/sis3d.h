@@ -369,6 +369,13 @@ int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, float *pack
 int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
                         const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
                         int out_stride, int out_coff, sis3d_stream_t stream);
+/* ragged batch (the mask head's crops, lib/nets/network.py:303-317): one launch per k3 layer for all boxes.  Work items are
+ * (crop, 8 x 4 x 8 block, group of two cout tiles); desc_dev = ndesc descriptors {int X,Y,Z, nbx,nby,nbz, block0, pad; int64 in_off,
+ * out_off} (the layout of sis3d_conv3d_k3t16_ragged) with block0 counting blocks x groups, total_blocks their sum.
+ * sis3d_ragged_tiling_k3wino returns the block and the group count the caller sizes the table with. */
+int sis3d_ragged_tiling_k3wino(int cin, int cout, int *bx, int *by, int *bz, int *ngroups);
+int sis3d_conv3d_k3wino_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout, int flags,
+                               float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks, sis3d_stream_t stream);
 
 /* nprob (<= 4) INDEPENDENT convolutions of identical shape in ONE launch (different input / weights / bias /
  * residual / output pointers; host arrays of device pointers, read at call time).  Used for the two RPN levels
