@@ -353,11 +353,37 @@ class MaskBackbone(nn.Module):
         return last(x)
 
 
-def _mask_forward_batched(self, scene, windows):
-    """all boxes at once: one launch per layer over the ragged batch of crops (ops.mask_head_batched)"""
+def _mask_forward_batched(self, scene, windows, imageft=None):
+    """all boxes at once: one launch per layer over the ragged batch of crops.  Geometry-only head: ops.mask_head_batched.
+    r3: MASK_USE_IMAGES / MASK_ONLY_IMAGES (backbones.py:253-284) batched as well -- the image-volume crops are gathered into the
+    same packing, the colour stack and `combine` run as ragged launches (ops.RaggedBatch), the geometry stack through the same
+    MaskPlan as the geometry-only head with its last 1x1x1 conv producing the 64 features of the concatenation."""
     g = self.geometry
+    sig = not self.training
     pcs = [g[i]._packed.get(g[i]) for i in (2, 4, 6, 8)]
-    return ops.mask_head_batched(scene, windows, g[0].weight, pcs, g[10]._packed.get(g[10]), sigmoid=not self.training)
+    if not self.use_images:
+        return ops.mask_head_batched(scene, windows, g[0].weight, pcs, g[10]._packed.get(g[10]), sigmoid=sig)
+    if len(windows) == 0:
+        return []
+    if imageft is None:
+        raise ops._lib.Sis3dError("MASK_USE_IMAGES: the mask head needs the image volume")
+    if isinstance(imageft, ops.ProjectedVolume):
+        imageft = imageft.dense()
+    vol = ops.to_cl(imageft)
+    rb = ops.RaggedBatch(windows, vol.device)
+    c = self.color
+    x = rb.gather(vol)
+    for i in (0, 2, 4, 6, 8):
+        x = rb.conv(x, c[i]._packed.get(c[i]), relu=True)
+    if self.only_images:
+        return rb.views(rb.conv(x, c[10]._packed.get(c[10]), sigmoid=sig))
+    col = rb.conv(x, c[10]._packed.get(c[10]))
+    plan = ops.MaskPlan(windows, g[2].out_channels, g[10].out_channels, vol.device)
+    ops.mask_head_run(scene, plan, g[0].weight, pcs, g[10]._packed.get(g[10]), sigmoid=False)
+    both = torch.cat([plan.out, col], 1)                       # torch.cat([geometry, color], 1) of backbones.py:282, all boxes at once
+    m = self.combine
+    y = rb.conv(both, m[0]._packed.get(m[0]), relu=True)
+    return rb.views(rb.conv(y, m[2]._packed.get(m[2]), sigmoid=sig))
 
 
 def _mask_plan(self, windows, device):

@@ -123,6 +123,8 @@ class Network(nn.Module):
         if getattr(self.mask_backbone, "use_images", False):
             # network.py:307-316 with USE_IMAGES: every box's crop of the scene AND of the back-projected volume
             vol = self._imageft
+            if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
+                return [self.mask_backbone.forward_batched(self._scene, windows, vol)]      # r3: one launch per layer for ALL boxes
             return [[self.mask_backbone(self._scene, vol, window=w) for w in windows]]
         if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
             return [self.mask_backbone.forward_batched(self._scene, windows)]   # one launch per layer for ALL boxes

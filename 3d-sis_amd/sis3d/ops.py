@@ -1201,9 +1201,94 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
             check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(plan.g3), n,
                                             plan.blocks, _stream()), "sis3d_conv3d_ragged")
         src, dst = dst, src
-    check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
-                                    _ptr(plan.out), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
+    if NC <= 32:
+        check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
+                                        _ptr(plan.out), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
+    else:
+        # a 1x1x1 conv does not see the crop structure: the packed buffer is one (voxels x 1 x 1) channels-last activation
+        # (the 64-feature output of the geometry stack under MASK_USE_IMAGES, lib/nets/backbones.py:246)
+        V = plan.voxels
+        conv3d(src.view(1, V, 1, 1, C).permute(0, 4, 1, 2, 3), pc_last, sigmoid=sigmoid, out=plan.out.view(1, V, 1, 1, NC).permute(0, 4, 1, 2, 3))
     return plan.views()
+
+
+class RaggedBatch:
+    """A ragged batch of crops (one per detected box) packed back to back, crop after crop, voxels x-major, channels last --
+    the packing of MaskPlan -- with descriptor tables built on demand per layer shape for sis3d_conv3d_ragged.  Serves the layers of
+    the mask head's colour variants (lib/nets/backbones.py:253-284) that MaskPlan's fixed 64-channel tables do not cover."""
+
+    def __init__(self, windows, device):
+        import numpy as np
+        self.n = len(windows)
+        self.device = device
+        w = np.asarray(windows, dtype=np.int64).reshape(self.n, 6)
+        self.w = w
+        self.ext = w[:, 3:] - w[:, :3]
+        self.voffs = np.concatenate([[0], np.cumsum(self.ext.prod(1))])
+        self.voxels = int(self.voffs[-1])
+        self._tables = {}
+
+    T16_BRICK = 2                                                   # 3x6x6: the brick MaskPlan mostly picks for 9-20 voxel crops
+
+    def table(self, cin, cout, in_stride, out_stride):
+        """descriptors of a k3 layer for sis3d_conv3d_k3t16_ragged (block0 counts bricks x cout tiles)"""
+        import numpy as np
+        key = (cin, cout, in_stride, out_stride)
+        hit = self._tables.get(key)
+        if hit is None:
+            tb = [ctypes.c_int() for _ in range(5)]
+            rc = lib().sis3d_ragged_tiling_k3t16(cin, cout, self.T16_BRICK, *[ctypes.byref(v) for v in tb])
+            if rc != 0:
+                raise Sis3dUnsupported("RaggedBatch: no balanced k3 tiling for %d -> %d" % (cin, cout))
+            bx, by, bz, ng, _ = (v.value for v in tb)
+            rdt, _ = _rag_dtypes()
+            nbk = -(-self.ext // np.array([bx, by, bz]))
+            blks = np.concatenate([[0], np.cumsum(nbk.prod(1) * ng)])
+            d = np.zeros(self.n, dtype=rdt)
+            d["X"], d["Y"], d["Z"] = self.ext[:, 0], self.ext[:, 1], self.ext[:, 2]
+            d["nbx"], d["nby"], d["nbz"] = nbk[:, 0], nbk[:, 1], nbk[:, 2]
+            d["block0"] = blks[:-1]
+            d["in_off"] = self.voffs[:-1] * in_stride
+            d["out_off"] = self.voffs[:-1] * out_stride
+            hit = (torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(self.device), int(blks[-1]))
+            self._tables[key] = hit
+        return hit
+
+    def gather(self, vol):
+        """crops of a channels-last volume (1,C,X,Y,Z) -> packed (voxels, C)"""
+        C = vol.shape[1]
+        out = torch.empty(self.voxels, C, device=vol.device)
+        for i in range(self.n):
+            x0, y0, z0, x1, y1, z1 = (int(v) for v in self.w[i])
+            out[int(self.voffs[i]):int(self.voffs[i + 1])] = vol[0, :, x0:x1, y0:y1, z0:z1].permute(1, 2, 3, 0).reshape(-1, C)
+        return out
+
+    def conv(self, src, pc, relu=False, sigmoid=False):
+        """one launch of a k1 / k3 conv over the whole batch: (voxels, cin) -> (voxels, cout).  k3: the balanced kernel's ragged
+        launch; k1: a 1x1x1 conv does not see the crop structure -- the packed buffer is one (voxels x 1 x 1) activation."""
+        cin_stride = src.shape[1]
+        if cin_stride != pc.cin:
+            raise _lib.Sis3dError("RaggedBatch.conv: activation has %d channels, packed weight expects %d" % (cin_stride, pc.cin))
+        if pc.k == 1:
+            x = src.view(1, self.voxels, 1, 1, cin_stride).permute(0, 4, 1, 2, 3)       # logical (1,C,V,1,1), channels-last memory
+            y = conv3d(x, pc, relu=relu, sigmoid=sigmoid)
+            return y.permute(0, 2, 3, 4, 1).reshape(self.voxels, pc.cout)
+        if pc.packed_t16 is None or sigmoid:
+            raise Sis3dUnsupported("RaggedBatch.conv: k3 layers need the balanced-kernel pack (cin % 32 == 0)")
+        out = torch.empty(self.voxels, pc.cout, device=src.device)
+        desc, blocks = self.table(pc.cin, pc.cout, cin_stride, pc.cout)
+        check(lib().sis3d_conv3d_k3t16_ragged(_ptr(src), pc.cin, cin_stride, _ptr(pc.packed_t16), _ptr(pc.bias), pc.cout,
+                                              EPI_RELU if relu else 0, _ptr(out), pc.cout, _ptr(desc), self.n, blocks, self.T16_BRICK, _stream()),
+              "sis3d_conv3d_k3t16_ragged")
+        return out
+
+    def views(self, out):
+        res = []
+        NC = out.shape[1]
+        for i in range(self.n):
+            dx, dy, dz = (int(v) for v in self.ext[i])
+            res.append(out[int(self.voffs[i]):int(self.voffs[i + 1])].view(dx, dy, dz, NC).permute(3, 0, 1, 2).unsqueeze(0))
+        return res
 
 
 def mask_head_batched(scene, windows, w0, pcs, pc_last, sigmoid=True):

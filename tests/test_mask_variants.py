@@ -79,6 +79,13 @@ def test_mask_head_with_colour_vs_oracle(golden, oracle, kind):
         assert float((m.cpu() - by[w]).abs().max()) <= 1e-4, w
         checked += 1
     assert checked == len(owins) > 0
+    # r3: the masks above came out of the BATCHED colour-variant head (one ragged launch per layer for all boxes); the per-box
+    # launches of round 2 give the same values (same kernels per layer up to the ragged / Winograd routing: fp32 noise)
+    assert net.batch_masks
+    vol = net._imageft
+    for w, m in zip(wins, masks):
+        single = net.mask_backbone(net._scene, vol, window=w)
+        assert float((m - single).abs().max()) <= 1e-5, w
     # against the reference's own first masks
     for i in range(min(4, int(g["n_masks"]))):
         assert float((dict(zip(wins, masks))[owins[i]].cpu() - torch.from_numpy(g["mask_%d" % i])).abs().max()) <= 1e-4
