@@ -436,6 +436,11 @@ def cpu_baseline(workload, sd, cfg, seconds):
                        "single_thread: %d passes" % (n, workload, best_t, per * n, n1))
 
 
+def ops_mod():
+    from sis3d import ops
+    return ops
+
+
 def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):
     """weak-scaling workloads: `inflight` independent chunks per GPU per step -> dict(dt, vox_per_step, single_ms, extra)"""
     import torch
@@ -496,6 +501,35 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
             eng.run(0)
             torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 50 * 1e3
+        if masks and eng.engines[0].mask_plan is not None:
+            # the mask head alone on the same fixed detection set (one chunk, nothing else on the GPU): captured graph of the six
+            # ragged launches, HIP events around 50 replays -> mask_head_ms / mask_head_tf (algorithmic FLOPs / time)
+            e0 = eng.engines[0]
+            with torch.no_grad():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    net.mask_backbone.forward_planned(e0.scenes[0], e0.mask_plan)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    net.mask_backbone.forward_planned(e0.scenes[0], e0.mask_plan)
+                for _ in range(5):
+                    g.replay()
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(50):
+                    g.replay()
+                ev1.record()
+                torch.cuda.synchronize()
+            mh_ms = ev0.elapsed_time(ev1) / 50
+            extra["mask_head_ms"] = mh_ms
+            extra["mask_head_tf"] = e0.mask_plan.flops / (mh_ms * 1e-3) / 1e12
+            extra["mask_head_fp32_frac"] = extra["mask_head_tf"] / FP32_PEAK_TF
+            extra["mask_head_kernel"] = ("Winograd ragged launch for the four 64->64 k3 layers (%d work items)" % e0.mask_plan.blocks_wino
+                                         if (ops_mod().WINOGRAD and e0.mask_plan.wino) else "direct balanced kernel, ragged")
     snap = None
     if rank == 0 and grp == 1:
         torch.cuda.synchronize()
