@@ -28,5 +28,11 @@ static inline hipError_t sis3d_allow_max_lds(const void *kern)
     return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
 }
 
+// Fill `bytes` (a multiple of 4, 4-byte aligned) with a 32-bit pattern: a KERNEL of this library, not hipMemsetAsync.  A
+// hipMemsetAsync captured in a HIP graph becomes a memset node, and on ROCm 7.2 replaying a graph with a memset node after the host
+// has synchronised and launched anything else faults ("Memory access fault by GPU", tools/hipgraph_memset_repro.py: no sis3d code
+// involved) -- the root cause of the image-path hazard of rounds 1-2.  Defined in api.hip.
+int sis3d_fill32(void *dst, uint32_t pattern, size_t bytes, hipStream_t st);
+
 static inline hipStream_t as_stream(sis3d_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -444,7 +444,7 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
         const size_t lds = (size_t)cb * (4 * 8 + 4) + 16;
         if (lds > 160 * 1024 - 64) return SIS3D_EUNSUPPORTED;
         unsigned long long *nz = (unsigned long long *)((char *)ws + mask_bytes);
-        if (hipMemsetAsync(nz, 0, nz_bytes, st) != hipSuccess) return SIS3D_ELAUNCH;
+        if (sis3d_fill32(nz, 0u, nz_bytes, st) != SIS3D_OK) return SIS3D_ELAUNCH;
         hipLaunchKernelGGL((nms_cand_kernel<INDIRECT>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, boxes, order, n, nullptr, 6, thresh, mask, nz, nzw);
         int rc = sis3d_check_launch();
         if (rc) return rc;
@@ -553,7 +553,7 @@ extern "C" int sis3d_scene_merge(const float *blocks, int n_chunks, int k_rows, 
     rc = sis3d_check_launch();
     if (rc) return rc;
     unsigned long long *nz = (unsigned long long *)((char *)ws + mask_bytes);
-    if (hipMemsetAsync(nz, 0, nz_bytes, st) != hipSuccess) return SIS3D_ELAUNCH;
+    if (sis3d_fill32(nz, 0u, nz_bytes, st) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL((nms_cand_kernel<false>), dim3(cb, cb), dim3(64 * MASK_WAVES), 0, st, recs + box_col, nullptr, T, counts, width,
                        thresh, mask, nz, nzw);
     rc = sis3d_check_launch();

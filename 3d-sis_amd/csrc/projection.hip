@@ -139,7 +139,7 @@ extern "C" int sis3d_projection_forward(const float *feat, int C, int64_t npix, 
 {
     if (!feat || !lin3d || !lin2d || !out || C <= 0 || npix <= 0 || nvox <= 0) return SIS3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)C * (size_t)nvox, st) != hipSuccess) return SIS3D_ELAUNCH;
+    if (sis3d_fill32(out, 0u, sizeof(float) * (size_t)C * (size_t)nvox, st) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(proj_scatter_kernel, dim3(1024), dim3(256), 0, st, feat, C, npix, lin3d, lin2d, nvox, out);
     return sis3d_check_launch();
 }
@@ -171,7 +171,7 @@ extern "C" int sis3d_project_views_max(const float *feats, int V, int C, int64_t
     unsigned char *base = (unsigned char *)ws;
     int32_t *vox2pix = (int32_t *)base;
     float *featT = (float *)(base + align256(sizeof(int32_t) * (size_t)V * (size_t)nvox));
-    if (hipMemsetAsync(vox2pix, 0xFF, sizeof(int32_t) * (size_t)nslots * (size_t)nvox, st) != hipSuccess) return SIS3D_ELAUNCH;
+    if (sis3d_fill32(vox2pix, 0xFFFFFFFFu, sizeof(int32_t) * (size_t)nslots * (size_t)nvox, st) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(proj_table_kernel, dim3(64, nslots), dim3(256), 0, st, lin3d, lin2d, nvox, ids, vox2pix);
     int rc = sis3d_check_launch();
     if (rc) return rc;
@@ -206,7 +206,7 @@ extern "C" int sis3d_project_views_prepare(const float *feats, int V, int C, int
         }
     *nslots_out = ids.n;
     if (ids.n == 0) return SIS3D_EINVAL;
-    if (hipMemsetAsync(vox2pix, 0xFF, sizeof(int32_t) * (size_t)ids.n * (size_t)nvox, st) != hipSuccess) return SIS3D_ELAUNCH;
+    if (sis3d_fill32(vox2pix, 0xFFFFFFFFu, sizeof(int32_t) * (size_t)ids.n * (size_t)nvox, st) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(proj_table_kernel, dim3(64, ids.n), dim3(256), 0, st, lin3d, lin2d, nvox, ids, vox2pix);
     int rc = sis3d_check_launch();
     if (rc) return rc;

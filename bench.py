@@ -236,8 +236,8 @@ def build_net(workload, masks=False, rgb=False):
 def time_dominant_kernel(net, iters=50):
     """mean duration of the rpn_net k3 128->256 conv launch (12.23 algorithmic GFLOP; the default route is the fp32 Winograd kernel,
     ops.set_winograd(False) = the direct fp32 MFMA kernel), HIP events on the launch (current) stream.
-    Runs BEFORE any graph is captured, on its own input: on ROCm 7.2 eager launches of these kernels between replays
-    of a captured graph were observed to fault the next replay, so the bench never interleaves them."""
+    Runs before any graph is captured, on its own input, so the timed launches have the chip to themselves.  (The round-1/2 fault of
+    "eager launches between graph replays" was a HIP-graph memset node, removed in round 3: DESIGN.md section 7.)"""
     import torch
     from sis3d import ops
     x = ops.new_act(128, (24, 12, 24), torch.device("cuda"))
