@@ -42,7 +42,8 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // timing experiments (tools/wino_bench.cpp builds variants; results are WRONG with any bit set): 1 = no U fill, 2 = no raw staging,
-// 4 = no barrier in the loop, 16 = no input transform, 32 = no output stores, 64 = no epilogue at all, 128 = no prologue staging
+// 4 = no barrier in the loop, 16 = no input transform, 32 = no output stores, 64 = phase timestamps (100 MHz) instead of the output,
+// 128 = input transform without its packed adds, 256 = input transform without its LDS reads
 #ifndef WN_EXP
 #define WN_EXP 0
 #endif
@@ -91,10 +92,34 @@ struct WinoArgs {
     int nrag;
 };
 
+// OFF: immediate byte offset of the instruction, added to BOTH the global and the LDS address (< 4096)
+template <int OFF = 0>
 __device__ __forceinline__ void glds16(const float *gsrc, float *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gsrc,
-                                     (void __attribute__((address_space(3))) *)lds_dst, 16, 0, 0);
+                                     (void __attribute__((address_space(3))) *)lds_dst, 16, OFF, 0);
+}
+
+// fp32 MFMA with its accumulator pinned in AGPRs ("+a"): left to the register allocator, the 256 accumulator registers of the NC = 2
+// kernel wander between the VGPR and AGPR halves whenever the loop body changes (dozens of v_accvgpr moves per step).  hipcc's hazard
+// recogniser does not see inside asm: an accumulator is touched again 64 MFMAs later at the earliest, and a barrier stands between
+// the loop and the epilogue's reads.
+__device__ __forceinline__ void mfma_agpr(f32x4 &acc, float a, float b)
+{
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+typedef const __attribute__((address_space(3))) float lds_f32;
+typedef const __attribute__((address_space(3))) f32x2 lds_f32x2;
+// byte address of a lane's raw rows inside the LDS (for the ds_read asm)
+struct LdsRow {
+    unsigned lo;
+    __device__ __forceinline__ explicit LdsRow(const float *p) : lo((unsigned)(size_t)(lds_f32 *)p) {}
+};
+template <int OFF>
+__device__ __forceinline__ void ds_read_b64_asm(f32x2 &dst, unsigned addr)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 
 // raw-stage loads and their counted waits as inline asm (see wino_wave): free functions, because clang rejects asm operands that
@@ -119,66 +144,127 @@ __device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c)
 // where it is written
 #define WN_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
+// packed fp32 adds (two IEEE binary32 adds per issue slot; a - b is a + (-b) exactly, so the results are those of the scalar adds).
+// Inline asm: left to itself hipcc either does not pair the adds or pairs them with v_mov shuffles that cost more than they save;
+// here every operand is a natural even-aligned pair (two consecutive z of one LDS row) and the z pass picks halves with op_sel.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    if constexpr (WN_EXP & 128) return a;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    if constexpr (WN_EXP & 128) return a;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// B^T along z on a row held as a = (t0, t1), b = (t2, t3):  (t0 - t2, t1 + t2)  and  (t2 - t1, t1 - t3)
+__device__ __forceinline__ f32x2 pk_bt_lo(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    if constexpr (WN_EXP & 128) return a;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_bt_hi(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    if constexpr (WN_EXP & 128) return a;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // The input transform of the NEXT K-step as 28 units, issued behind MFMAs of the current step.  fp32 MFMA and fp32 VALU share
 // the SIMD's fp32 lanes on gfx950 (their cycles ADD: measured, tools/wino_bench.cpp), so the transform is not hidden -- it is
-// kept small instead: a wave transforms HALF of the xi (xi_x in {2H, 2H + 1}: 96 adds + 24 LDS reads) and uses every transformed
-// value for TWO cout tiles, i.e. 1.5 adds per MFMA.
-//   read unit (4):  raw row dy of the three x-planes this half needs: 6 x ds_read_b64, two rows in flight at most
-//   x unit    (8):  (dy, dz pair) over x            4 adds
-//   y unit    (8):  line (i, dz) over y              4 adds, in place
-//   z unit    (8):  line (i, xi_y) over z            4 adds, in place  -> T[i][xi_y][xi_z] = the A operands of the next step
+// kept small instead: a wave transforms HALF of the xi (xi_x in {2H, 2H + 1}: 96 adds = 48 packed adds, + 24 LDS reads) and uses
+// every transformed value for TWO cout tiles.  Everything is held as z PAIRS (the two halves of one ds_read_b64):
+//   read_row (4):  raw row dy of the three x-planes this half needs: 6 x ds_read_b64, two rows in flight at most
+//   x_pair   (8):  (dy, z pair) over x                2 packed adds
+//   y_col    (4):  (i, z pair) over y                 4 packed adds, in place
+//   z_row    (8):  row (i, xi_y) over z               2 packed adds (op_sel)  -> T[i][xi_y][z pair] = the A operands of the next step
 template <int H>
 struct NextV {
-    float T[2][4][4];
+    f32x2 T[2][4][2];                                           // [xi_x - 2H][xi_y][xi_z pair]
     f32x2 d[2][3][2];                                           // [dy & 1][plane][lo / hi]
 
+    __device__ __forceinline__ float a_operand(int i, int y, int e) const { return e & 1 ? T[i][y][e >> 1].y : T[i][y][e >> 1].x; }
+
+    // One ds_read_b64 per z pair as inline asm, NOT the ds_read2_b64 hipcc fuses any two 8-byte reads off one base into: the LDS serves
+    // ds_read2_b64 at a quarter of the rate (two accesses x four 16-lane groups on banks mod 32, where the ty lanes of a group
+    // collide: 16 cycles per instruction, and the U reads queue behind it), a plain ds_read_b64 as two 32-lane groups on banks mod
+    // 64, where this lane layout (2 tz + 8 txl + 32 ty + 16 kq) is conflict-free: 2 cycles.  hipcc does not count asm reads: the
+    // bursts that consume the rows start with wait_rows().
     template <int DY>
-    __device__ __forceinline__ void read_row(const float *__restrict__ r)
+    __device__ __forceinline__ void read_row(const LdsRow &r)
     {
+        if constexpr (WN_EXP & 256) return;
         static_for<0, 3>([&](auto P) {
             constexpr int p = decltype(P)::value, dx = p + H;
-            d[DY & 1][p][0] = *reinterpret_cast<const f32x2 *>(r + dx * PS + DY * HZS);
-            d[DY & 1][p][1] = *reinterpret_cast<const f32x2 *>(r + dx * PS + DY * HZS + 2);
+            ds_read_b64_asm<(dx * PS + DY * HZS) * 4>(d[DY & 1][p][0], r.lo);
+            ds_read_b64_asm<(dx * PS + DY * HZS + 2) * 4>(d[DY & 1][p][1], r.lo);
         });
+    }
+    __device__ __forceinline__ void wait_rows()
+    {
+        // volatile asm statements keep their order: the reads stay in front of this wait, the packed adds (the only consumers of the
+        // rows) behind it
+        asm volatile("s_waitcnt lgkmcnt(0)");
     }
     template <int DY, int ZP>
     __device__ __forceinline__ void x_pair()
     {
-        static_for<0, 2>([&](auto E) {
-            constexpr int dz = 2 * ZP + decltype(E)::value;
-            const float p0 = dz & 1 ? d[DY & 1][0][dz >> 1].y : d[DY & 1][0][dz >> 1].x;
-            const float p1 = dz & 1 ? d[DY & 1][1][dz >> 1].y : d[DY & 1][1][dz >> 1].x;
-            const float p2 = dz & 1 ? d[DY & 1][2][dz >> 1].y : d[DY & 1][2][dz >> 1].x;
-            if constexpr (H == 0) {
-                T[0][DY][dz] = p0 - p2;                              // xi_x = 0: d0 - d2
-                T[1][DY][dz] = p1 + p2;                              // xi_x = 1: d1 + d2
-            } else {
-                T[0][DY][dz] = p1 - p0;                              // xi_x = 2: d2 - d1   (planes held: 1, 2, 3)
-                T[1][DY][dz] = p0 - p2;                              // xi_x = 3: d1 - d3
-            }
-        });
-        WN_PIN4(T[0][DY][2 * ZP], T[0][DY][2 * ZP + 1], T[1][DY][2 * ZP], T[1][DY][2 * ZP + 1]);
+        const f32x2 p0 = d[DY & 1][0][ZP], p1 = d[DY & 1][1][ZP], p2 = d[DY & 1][2][ZP];
+        if constexpr (H == 0) {
+            T[0][DY][ZP] = pk_sub(p0, p2);                       // xi_x = 0: d0 - d2
+            T[1][DY][ZP] = pk_add(p1, p2);                       // xi_x = 1: d1 + d2
+        } else {
+            T[0][DY][ZP] = pk_sub(p1, p0);                       // xi_x = 2: d2 - d1   (planes held: 1, 2, 3)
+            T[1][DY][ZP] = pk_sub(p0, p2);                       // xi_x = 3: d1 - d3
+        }
     }
-    // unit M rides behind MFMA M (0..63) of the current step
-    template <int M>
-    __device__ __forceinline__ void unit(const float *__restrict__ r)
+    template <int I, int ZP>
+    __device__ __forceinline__ void y_col()
     {
-        if constexpr (M == 0) read_row<0>(r);
-        else if constexpr (M == 2) read_row<1>(r);
-        else if constexpr (M == 8 || M == 10) x_pair<0, (M - 8) / 2>();
-        else if constexpr (M == 12) read_row<2>(r);
-        else if constexpr (M == 14 || M == 16) x_pair<1, (M - 14) / 2>();
-        else if constexpr (M == 18) read_row<3>(r);
-        else if constexpr (M == 24 || M == 26) x_pair<2, (M - 24) / 2>();
-        else if constexpr (M == 28 || M == 30) x_pair<3, (M - 28) / 2>();
-        else if constexpr (M >= 32 && M < 48 && (M & 1) == 0) {
-            constexpr int u = (M - 32) / 2, i = u >> 2, dz = u & 3;
-            WN_BT_INPLACE(T[i][0][dz], T[i][1][dz], T[i][2][dz], T[i][3][dz]);
-            WN_PIN4(T[i][0][dz], T[i][1][dz], T[i][2][dz], T[i][3][dz]);
-        } else if constexpr (M >= 48 && (M & 1) == 0) {
-            constexpr int u = (M - 48) / 2, i = u >> 2, y = u & 3;
-            WN_BT_INPLACE(T[i][y][0], T[i][y][1], T[i][y][2], T[i][y][3]);
-            WN_PIN4(T[i][y][0], T[i][y][1], T[i][y][2], T[i][y][3]);
+        const f32x2 v0 = T[I][0][ZP], v1 = T[I][1][ZP], v2 = T[I][2][ZP], v3 = T[I][3][ZP];
+        T[I][0][ZP] = pk_sub(v0, v2);
+        T[I][1][ZP] = pk_add(v1, v2);
+        T[I][2][ZP] = pk_sub(v2, v1);
+        T[I][3][ZP] = pk_sub(v1, v3);
+    }
+    template <int I, int Y>
+    __device__ __forceinline__ void z_row()
+    {
+        const f32x2 lo = pk_bt_lo(T[I][Y][0], T[I][Y][1]);
+        T[I][Y][1] = pk_bt_hi(T[I][Y][0], T[I][Y][1]);
+        T[I][Y][0] = lo;
+    }
+    // Unit M rides behind MFMA slot M (0..63) of the current step.  The packed adds go out in THREE BURSTS, not one or two per
+    // MFMA: an fp32 VALU instruction between two MFMAs costs the matrix pipe ~11 cycles when it stands alone and 4 when it follows
+    // another VALU instruction (tools/issue_overlap.hip: 48 packed adds cost 223 ns spread one per gap, 80 ns in bursts of >= 8),
+    // while LDS reads, LDS writes and scalar instructions between MFMAs are free.
+    template <int M>
+    __device__ __forceinline__ void unit(const LdsRow &r)
+    {
+        // every burst sits in the LAST slot of a quad of MFMAs: the U reads of the quad were issued at its start, seven MFMAs earlier,
+        // so the wait for the raw rows in front of a burst (hipcc emits lgkmcnt(0), not a counted wait) finds nothing young in flight
+        if constexpr (M == 0) {
+            read_row<0>(r);
+            read_row<1>(r);
+        } else if constexpr (M == 15) {
+            wait_rows();
+            x_pair<0, 0>(); x_pair<0, 1>(); x_pair<1, 0>(); x_pair<1, 1>();
+        } else if constexpr (M == 16) {                         // behind the first MFMA of the next quad, see step()
+            read_row<2>(r);
+            read_row<3>(r);
+        } else if constexpr (M == 31) {
+            wait_rows();
+            x_pair<2, 0>(); x_pair<2, 1>(); x_pair<3, 0>(); x_pair<3, 1>();
+            y_col<0, 0>(); y_col<0, 1>(); y_col<1, 0>(); y_col<1, 1>();
+        } else if constexpr (M == 39) {
+            static_for<0, 8>([&](auto U) { z_row<(decltype(U)::value >> 2), (decltype(U)::value & 3)>(); });
         }
     }
 };
@@ -189,6 +275,8 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (WN_EXP & 64) ts0 = wall_clock64();       // experiment: 100 MHz timestamps of the phases, written instead of the output
     const int g = wave & 1;
     const int li = lane & 15, kq = lane >> 4;
     const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
@@ -240,10 +328,13 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     constexpr int NFILL = 4 * NC;
     const float *wbase = p_wp + (size_t)(NC * grp) * nk * B_TILE;
     const int woff = lane * 4;
+    // a wave's NFILL blocks are consecutive in the packed weights and in the stage (NFILL divides 16): one global base and one LDS
+    // base (M0) per four instructions, the 1 KB steps in between as the instructions' immediate offsets
+    const int n0 = wave * NFILL;
+    const float *wwave = wbase + (size_t)(n0 >> 4) * nk * B_TILE + (n0 & 15) * 256;
     auto fill_b_item = [&](auto I, int k, int buf) {
         constexpr int i = decltype(I)::value;
-        const int n = wave * NFILL + i, cc = n >> 4, xq = n & 15;
-        glds16((wbase + ((size_t)cc * nk + k) * B_TILE + xq * 256) + woff, bst + buf * B_STAGE + n * 256);
+        glds16<(i & 3) * 1024>(wwave + (size_t)k * B_TILE + (i >> 2) * 1024 + woff, bst + buf * B_STAGE + (n0 + (i >> 2) * 4) * 256);
     };
 
     f32x4 acc[NC][32];                                   // [cout tile c][xi of this half]
@@ -265,21 +356,30 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     static_for<0, NIT>([&](auto I) { stage_store_item(I, 0); });
     static_for<0, NIT>([&](auto I) { sv[decltype(I)::value] = sw[decltype(I)::value]; stage_store_item(I, 1); });
     __syncthreads();
+    // raw stage 2 goes in flight now: in the loop, the loads of stage k + 3 are issued at the END of step k (behind the LDS stores of
+    // stage k + 2) and waited for 54 MFMAs later, in front of the stores of step k + 1 -- an L2 round trip under load is longer than
+    // the 35 MFMAs the loads had when they were issued at the start of the step that stores them
+    if (!(WN_EXP & 2)) static_for<0, NIT>([&](auto I) { stage_load_item(I, nk > 2 ? 2 : nk - 1); });
     // V ping-pongs between two NextV objects (no register copies): step k multiplies with one while the other is being built
     NextV<H> va, vb;
-    static_for<0, 64>([&](auto M) { va.template unit<decltype(M)::value>(raw + rbase); });
+    static_for<0, 64>([&](auto M) { va.template unit<decltype(M)::value>(LdsRow(raw + rbase)); });
 
-    // ---- main loop.  Step k: the 64 MFMAs of step k (32 xi x 2 cout tiles); behind them, one small unit per MFMA slot: the
-    // global loads of raw stage k + 2 (slots 1..5), the LDS-DMA of U stage k + 2 (7..21), the input transform of step k + 1
-    // (even slots, NextV::unit), the LDS stores of raw stage k + 2 (41..45).  A lone wave issues in order: anything placed in
-    // front of or behind the MFMA block would hold the matrix pipe up by its whole issue time.
+    // ---- main loop.  Step k: the 64 MFMAs of step k (32 xi x 2 cout tiles); behind them, in the gaps between MFMAs: the LDS-DMA of
+    // U stage k + 2 (slots 7..21, one per gap), the input transform of step k + 1 (NextV::unit: LDS reads + three bursts of packed
+    // adds), the LDS stores of raw stage k + 2 (41..45) and the global loads of raw stage k + 3 (49..53).  A lone wave issues in
+    // order: anything placed in front of or behind the MFMA block would hold the matrix pipe up by its whole issue time.
+    // What the gaps cost (tools/issue_overlap.hip, one wave per SIMD): LDS reads, LDS writes and scalar instructions nothing; a VMEM
+    // instruction ~11 ns wherever it stands; an fp32 VALU instruction ~11 cycles alone but 4 in a burst -- hence the bursts.
+    // Waits: hipcc waits with lgkmcnt(0) in front of the first use of any freshly read register, so every LDS read is issued right
+    // BEHIND an MFMA that carries such a wait, never in front of one (the wait would cover the read just issued: a full LDS round
+    // trip per quad); the rows' own waits (NextV::wait_rows) sit at quad ends, seven MFMAs after the quad's U reads.
     // LDS-DMA lands ~1 us after issue under load (longer than a step), so U runs TWO stages ahead through a ring of three, and
     // no wait in the loop is a vmcnt(0): the one in front of the raw-stage stores leaves this step's eight DMA instructions
-    // outstanding (vmcnt(8): the three loads of this step and everything older -- the previous step's DMA -- have completed).
+    // outstanding (vmcnt(8): the three loads issued at the end of the previous step and everything older have completed).
     // One barrier per step, and it sits INSIDE the MFMA block, after quad 5: by then every LDS read of U stage k is issued and
-    // stage k + 1 has landed, so the barrier is followed by the first U reads of step k + 1 and then by the 16 MFMAs of quads
-    // 6, 7 of step k, whose operands are already in registers -- the barrier skew and the LDS latency of the next step's first
-    // operands hide behind 512 cycles of matrix work instead of idling the pipe.
+    // stage k + 1 has landed, so the barrier is followed by the 16 MFMAs of quads 6, 7 of step k, whose operands are already in
+    // registers (and, behind the first of them, by the first U reads of step k + 1) -- the barrier skew and the LDS latency of
+    // the next step's first operands hide behind 512 cycles of matrix work instead of idling the pipe.
     // Loads / DMA of the steps past the end are clamped to the last step (harmless duplicates, landed before the final barrier):
     // no branches in the block.
     static_assert(NIT == 3, "the counted waits below assume three staging loads and eight DMA instructions per step");
@@ -293,31 +393,35 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     read_b(std::integral_constant<int, 1>{}, bst + bbase);
     auto step = [&](int k, NextV<H> &vu, NextV<H> &vn) {
         const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
-        const int ks = k + 2 < nk ? k + 2 : nk - 1;
+        const int ks = k + 2 < nk ? k + 2 : nk - 1, ks3 = k + 3 < nk ? k + 3 : nk - 1;
         const float *bs = bst + cur * B_STAGE + bbase;
         const float *bs_next = bst + nxt * B_STAGE + bbase;
-        const float *rn = raw + nxt * RAW_STAGE + rbase;
+        const LdsRow rn(raw + nxt * RAW_STAGE + rbase);
         static_for<0, 8>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
-            if constexpr (q + 2 < 8) read_b(std::integral_constant<int, q + 2>{}, bs);
             if constexpr (q == 6) {
                 // everything but this step's DMA has completed (the counted wait at slot 40 stands); LDS traffic of this wave done
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (!(WN_EXP & 4)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                read_b(std::integral_constant<int, 0>{}, bs_next);
-                read_b(std::integral_constant<int, 1>{}, bs_next);
             }
             static_for<0, 4 * NC>([&](auto E) {
                 constexpr int en = decltype(E)::value, e = en / NC, cc = en % NC, m = 4 * NC * q + en;
-                acc[cc][4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vu.T[q >> 2][q & 3][e], bq[q & 3][cc][e], acc[cc][4 * q + e], 0, 0, 0);
+                mfma_agpr(acc[cc][4 * q + e], vu.a_operand(q >> 2, q & 3, e), bq[q & 3][cc][e]);
+                // U reads of quad q + 2 go out BEHIND the first MFMA of quad q: hipcc waits with lgkmcnt(0) in front of the first use of
+                // a freshly read register, i.e. in front of that MFMA -- anything issued just before it would be waited for in full
+                if constexpr (en == 0 && q + 2 < 8) read_b(std::integral_constant<int, q + 2>{}, bs);
+                if constexpr (en == 0 && q == 6) {              // first U operands of the next step (its stage landed before the barrier)
+                    read_b(std::integral_constant<int, 0>{}, bs_next);
+                    read_b(std::integral_constant<int, 1>{}, bs_next);
+                }
                 // the units are laid out on 64 virtual slots: one per MFMA with two cout tiles, two per MFMA with one
                 static_for<0, 2 / NC>([&](auto V) {
                     constexpr int sl = m * (2 / NC) + decltype(V)::value;
                     if constexpr (!(WN_EXP & 16)) vn.template unit<sl>(rn);
-                    if constexpr (sl >= 1 && sl < 1 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_load_item(std::integral_constant<int, (sl - 1) / 2>{}, ks);
+                    if constexpr (sl >= 49 && sl < 49 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_load_item(std::integral_constant<int, (sl - 49) / 2>{}, ks3);
                     if constexpr (sl >= 7 && sl < 7 + 2 * NFILL && (sl & 1) == 1 && !(WN_EXP & 1)) fill_b_item(std::integral_constant<int, (sl - 7) / 2>{}, ks, nn);
-                    if constexpr (sl == 40 && !(WN_EXP & 2)) wait_vmcnt<NFILL>(sv[0], sv[1], sv[2]);
+                    if constexpr (sl == 40 && !(WN_EXP & 2)) wait_vmcnt<(WN_EXP & 512) ? 0 : NFILL>(sv[0], sv[1], sv[2]);
                     if constexpr (sl >= 41 && sl < 41 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_store_item(std::integral_constant<int, (sl - 41) / 2>{}, nn);
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -329,11 +433,15 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // (valid) raw stage and its result is never used -- 96 wasted adds once per launch buy a loop with exactly two step shapes
     // and one register assignment for the 256 accumulator registers (hipcc otherwise moves them between the AGPR and VGPR halves
     // at every change of shape: 512 v_accvgpr moves per transition)
+    if constexpr (WN_EXP & 64) ts1 = wall_clock64();
     for (int k = 0; k < nk; k += 2) {
         step(k, va, vb);
         step(k + 1, vb, va);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped duplicate DMA of the last steps
+    if constexpr (WN_EXP & 64) ts2 = wall_clock64();
+    // the clamped duplicate DMA and raw-stage loads of the last steps.  The wait names sv: the loads are asm, so hipcc does not know
+    // they are still writing those registers -- without the operands it hands them to the epilogue above this line
+    wait_vmcnt<0>(sv[0], sv[1], sv[2]);
     __syncthreads();                                     // quads 6, 7 of the last step ran behind the last in-loop barrier
 
     // ---- output transform A^T M A: per lane, cout tile c and row r (tile 4 (lane >> 4) + r, cout lane & 15): 32 xi -> 8 partial
@@ -425,6 +533,13 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
             }
         }
     });
+    if constexpr (WN_EXP & 64) {
+        const unsigned long long ts3 = wall_clock64();
+        if (tid == 0) {
+            float *d = p_out + (size_t)(brick * a.ngroups + grp) * 4;
+            d[0] = (float)(ts1 - ts0) * 10.f; d[1] = (float)(ts2 - ts1) * 10.f; d[2] = (float)(ts3 - ts2) * 10.f; d[3] = (float)(ts0 % 100000000ull) * 10.f;
+        }
+    }
 }
 
 template <int NC>

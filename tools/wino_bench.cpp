@@ -50,5 +50,18 @@ int main(int argc, char **argv)
     double fl = 2.0 * X * Y * Z * cout * (double)cin * 27 * nprob;
     printf("WN_EXP=%d %d->%d %dx%dx%d x%d: %.1f us  (%.1f TF algorithmic, %.1f TF executed)\n", WN_EXP, cin, cout, X, Y, Z, nprob, best * 1e3,
            fl / best / 1e9, fl / 3.375 / best / 1e9);
+    if (WN_EXP & 64) {          // phase timestamps (ns) written by thread 0 of every workgroup in place of the output
+        hipMemset(out[0], 0, nout * 4);
+        launch();
+        hipDeviceSynchronize();
+        int nwg = ((X + 7) / 8) * ((Y + 3) / 4) * ((Z + 7) / 8) * ((cout / 16 + 1) / 2);
+        std::vector<float> t(nwg * 4);
+        hipMemcpy(t.data(), out[0], nwg * 16, hipMemcpyDeviceToHost);
+        double s[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, t0min = 1e30, t0max = 0;
+        for (int i = 0; i < nwg; ++i) { for (int j = 0; j < 3; ++j) { s[j] += t[4 * i + j]; if (t[4 * i + j] > mx[j]) mx[j] = t[4 * i + j]; }
+                                        if (t[4 * i + 3] < t0min) t0min = t[4 * i + 3]; if (t[4 * i + 3] > t0max) t0max = t[4 * i + 3]; }
+        printf("  %d workgroups: prologue %.0f ns (max %.0f), loop %.0f (max %.0f), epilogue %.0f (max %.0f); start-time spread %.0f ns\n", nwg,
+               s[0] / nwg, mx[0], s[1] / nwg, mx[1], s[2] / nwg, mx[2], t0max - t0min);
+    }
     return 0;
 }
