@@ -181,7 +181,7 @@ __device__ __forceinline__ f32x2 pk_bt_hi(f32x2 a, f32x2 b)
 // the SIMD's fp32 lanes on gfx950 (their cycles ADD: measured, tools/wino_bench.cpp), so the transform is not hidden -- it is
 // kept small instead: a wave transforms HALF of the xi (xi_x in {2H, 2H + 1}: 96 adds = 48 packed adds, + 24 LDS reads) and uses
 // every transformed value for TWO cout tiles.  Everything is held as z PAIRS (the two halves of one ds_read_b64):
-//   read_row (4):  raw row dy of the three x-planes this half needs: 6 x ds_read_b64, two rows in flight at most
+//   read_half_row (8):  half of raw row dy of the three x-planes this half needs: 3 x ds_read_b64, two rows in flight at most
 //   x_pair   (8):  (dy, z pair) over x                2 packed adds
 //   y_col    (4):  (i, z pair) over y                 4 packed adds, in place
 //   z_row    (8):  row (i, xi_y) over z               2 packed adds (op_sel)  -> T[i][xi_y][z pair] = the A operands of the next step
@@ -197,14 +197,15 @@ struct NextV {
     // collide: 16 cycles per instruction, and the U reads queue behind it), a plain ds_read_b64 as two 32-lane groups on banks mod
     // 64, where this lane layout (2 tz + 8 txl + 32 ty + 16 kq) is conflict-free: 2 cycles.  hipcc does not count asm reads: the
     // bursts that consume the rows start with wait_rows().
-    template <int DY>
-    __device__ __forceinline__ void read_row(const LdsRow &r)
+    // half a row: reads 3 J .. 3 J + 2 of the six (plane p = read / 2, z pair = read & 1).  Three per MFMA gap: a gap hides ~32 cycles
+    // of issue, and twelve reads issued back to back cost the matrix pipe ~85 ns per step
+    template <int DY, int J>
+    __device__ __forceinline__ void read_half_row(const LdsRow &r)
     {
         if constexpr (WN_EXP & 256) return;
-        static_for<0, 3>([&](auto P) {
-            constexpr int p = decltype(P)::value, dx = p + H;
-            ds_read_b64_asm<(dx * PS + DY * HZS) * 4>(d[DY & 1][p][0], r.lo);
-            ds_read_b64_asm<(dx * PS + DY * HZS + 2) * 4>(d[DY & 1][p][1], r.lo);
+        static_for<3 * J, 3 * J + 3>([&](auto R) {
+            constexpr int p = decltype(R)::value >> 1, h = decltype(R)::value & 1, dx = p + H;
+            ds_read_b64_asm<(dx * PS + DY * HZS + 2 * h) * 4>(d[DY & 1][p][h], r.lo);
         });
     }
     __device__ __forceinline__ void wait_rows()
@@ -250,15 +251,13 @@ struct NextV {
     {
         // every burst sits in the LAST slot of a quad of MFMAs: the U reads of the quad were issued at its start, seven MFMAs earlier,
         // so the wait for the raw rows in front of a burst (hipcc emits lgkmcnt(0), not a counted wait) finds nothing young in flight
-        if constexpr (M == 0) {
-            read_row<0>(r);
-            read_row<1>(r);
+        if constexpr (M >= 1 && M <= 4) {                       // behind MFMAs 1..4 of a quad whose wait stood in front of MFMA 0
+            this->template read_half_row<((M - 1) >> 1), ((M - 1) & 1)>(r);
         } else if constexpr (M == 15) {
             wait_rows();
             x_pair<0, 0>(); x_pair<0, 1>(); x_pair<1, 0>(); x_pair<1, 1>();
-        } else if constexpr (M == 16) {                         // behind the first MFMA of the next quad, see step()
-            read_row<2>(r);
-            read_row<3>(r);
+        } else if constexpr (M >= 17 && M <= 20) {
+            this->template read_half_row<(2 + ((M - 17) >> 1)), ((M - 17) & 1)>(r);
         } else if constexpr (M == 31) {
             wait_rows();
             x_pair<2, 0>(); x_pair<2, 1>(); x_pair<3, 0>(); x_pair<3, 1>();
@@ -302,7 +301,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
         const bool inside = v < NVOX && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
         goff[it] = inside ? ((gx * gY + gy) * gZ + gz) * a.cin_stride : 0;
-        loff[it] = inside ? hx * PS + hy * HZS + hz : HX * PS + (lane & 31);       // dump: floats 1000..1031 of the 1040
+        loff[it] = 4 * (inside ? hx * PS + hy * HZS + hz : HX * PS + (lane & 31));  // BYTES; dump: floats 1000..1031 of the 1040
         if (v < NVOX && !inside) {
             static_for<0, NRAW * 4>([&](auto C) { raw[decltype(C)::value * CHS + hx * PS + hy * HZS + hz] = 0.f; });
         }
@@ -318,7 +317,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     };
     auto stage_store_item = [&](auto I, int buf) {
         constexpr int it = decltype(I)::value;
-        float *dst = raw + buf * RAW_STAGE + loff[it];
+        float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(raw) + (buf * (RAW_STAGE * 4) + loff[it]));   // one VALU add
         dst[0] = sv[it][0];
         dst[CHS] = sv[it][1];
         dst[2 * CHS] = sv[it][2];
