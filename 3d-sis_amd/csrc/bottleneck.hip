@@ -14,8 +14,10 @@
 //     pointwise.hip, whose result is again the operand layout of conv1_next: no further staging;
 //   * same summation orders as the two-launch path (wave partials (s0+s1)+(s2+s3)+bias; acc+bias+residual), so `out` is
 //     bit-identical to it.
-// Bricks: 6x6x6 (256 workgroups on 48x24x48) and 3x3x3 (256 workgroups on 24x12x24); planes = 32 only: with 64 planes a
+// Bricks: 6x6x3 (512 workgroups on 48x24x48, two per CU), 6x6x6 (256 workgroups there, one per CU: the round-2 choice) and 3x3x3
+// (256 workgroups on 24x12x24); planes = 32 only: with 64 planes a
 // 27-voxel brick would stream the whole 442 KB conv2 weight through every workgroup (measured slower than two launches).
+#include <stdlib.h>
 #include "common.h"
 #include "mfma16.h"
 
@@ -63,7 +65,7 @@ struct BnArgs {
 #endif
 
 template <int BX, int BY, int BZ, int PL, int CIO, int C2>
-__global__ __launch_bounds__(256, 1) void bottleneck16_kernel(const BnArgs a)
+__global__ __launch_bounds__(256, (BX * BY * BZ <= 108 ? 2 : 1)) void bottleneck16_kernel(const BnArgs a)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
     constexpr int NTC = PL / 16, NQ = PL / CK, NT3 = CIO / 16, NTN = C2 / 16;
@@ -397,7 +399,13 @@ extern "C" int sis3d_bottleneck16_brick(int X, int Y, int Z, int planes)
     // 64 planes: a 27-voxel brick streams the whole 442 KB conv2 weight through every workgroup -- measured 25.8 us against
     // 17.8 + 7.6 us for the two launches on 24x12x24 (profiles/README.md): the two-launch path serves those blocks
     if (planes != 32) return -1;
+    static const int big = getenv("SIS3D_BN_BRICK_BIG") ? atoi(getenv("SIS3D_BN_BRICK_BIG")) : 2;    // tuning hook: 0 = 6x6x6 on big grids
     const int64_t n6 = (int64_t)cdiv(X, 6) * cdiv(Y, 6) * cdiv(Z, 6), n3 = (int64_t)cdiv(X, 3) * cdiv(Y, 3) * cdiv(Z, 3);
+    // big grid: 6x6x3 bricks, two workgroups per CU (72 KB of LDS, <= 256 registers each: 512 workgroups on 48x24x48 = one round):
+    // the second workgroup's waves fill the stalls of the first (halo load, cross-wave sum, 1x1x1 tail) -- measured 0.2145 ->
+    // 0.210 ms on the backbone against one 6x6x6 brick per CU (14 tiles per wave, 143 KB)
+    const int64_t n63 = (int64_t)cdiv(X, 6) * cdiv(Y, 6) * cdiv(Z, 3);
+    if (n63 >= 384 && big == 2) return 2;
     if (n6 >= 192) return 0;                                 // the chip is full with 6x6x6 bricks (14 tiles per wave, 96 % fill)
     if (n3 <= 1024) return 1;                                // small grid: 3x3x3 bricks (256 workgroups on 24x12x24)
     return 0;
@@ -427,6 +435,7 @@ extern "C" int sis3d_bottleneck16(const float *y1, int X, int Y, int Z, int plan
     switch (brick) {
     case 0: return dispatch_bn<6, 6, 6>(a, planes, cio, c2, st);
     case 1: return dispatch_bn<3, 3, 3>(a, planes, cio, c2, st);
+    case 2: return dispatch_bn<6, 6, 3>(a, planes, cio, c2, st);
     default: return SIS3D_EINVAL;
     }
 }

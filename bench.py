@@ -15,8 +15,9 @@ all-gather and whole-scene NMS, `records_gathered`, `kept_after_scene_nms`, `ms_
 same scene = `single_gpu` and `speedup_vs_1gpu`).  So value(N) / value(1) compares like with like, and the strong-scaling figure
 of the collective path can be read off the `scene` key of the same lines.  `--workload scene` makes the scene the headline instead.
   backbone_rpn  BASELINE config[1]: one 96x48x96 geometry-only chunk per pipeline, HIP backbone + RPN; a step = one pass
-                over `--inflight` (default 3) independent chunks per GPU, each on its own HIP stream / captured graph, inputs
-                resident in HBM.  Ranks share nothing (scaling: weak).
+                over `--inflight` (default 4 here, 3 for the other workloads: the measured best of each, tools/r03_inflight.sh)
+                independent chunks per GPU, each on its own HIP stream / captured graph, inputs resident in HBM.  Ranks share
+                nothing (scaling: weak).
   detect        config[2]: + decode / top-k / NMS / RoI pooling / classifier (+ `--masks`: mask head on a fixed
                 deterministic detection set).
   images        config[3]: 5-view back-projection + colour/geometry backbone + RPN.
@@ -76,7 +77,7 @@ def parse(argv=None):
     ap.add_argument("--workload", default="auto", choices=["auto", "backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
-                    "measured best: 3")
+                    "measured best: 4 for backbone_rpn, 3 for detect / images / scene")
     ap.add_argument("--masks", action="store_true", help="detect: also run the mask head (config[2] in full) on a fixed "
                     "deterministic detection set; scene: mask the detections that survive the whole-scene NMS, each on the "
                     "chunk / rank that produced it")
@@ -146,6 +147,13 @@ def emit(line):
 def scene_origin(c, stride):
     """origin of chunk c of the scene's 4 x 1 x n/4 chunk grid, in scene voxels"""
     return (float(stride) * (c % 4), 0.0, float(stride) * (c // 4))
+
+
+def default_inflight(workload):
+    """chunks in flight per GPU that measured best (profiles/r03_inflight.txt): the Winograd kernels take a CU whole (148 KB of LDS, 512
+    registers per lane), so the backbone + RPN pass gains from a fourth stream filling the CUs they leave; the passes with long
+    single-workgroup tails (detect, scene) and the image path lose with it"""
+    return 4 if workload == "backbone_rpn" else 3
 
 
 def chunk_pipeline_entry(value, unit, ms_per_step, chunks_per_step_per_gpu, single_ms):
@@ -620,7 +628,7 @@ def main(argv=None):
     # both workloads ride on every line of the default and the scene run, at every N, under the same two keys
     both = args.workload in ("auto", "scene") and not args.masks and not args.no_graph and not args.no_side_workloads
     if args.inflight <= 0 and workload != "scene":
-        args.inflight = 3
+        args.inflight = default_inflight(workload)
 
     from sis3d import ops
     ops.lib()
@@ -649,7 +657,7 @@ def main(argv=None):
 
     def chunk_pipeline_side():
         saved = args.inflight
-        args.inflight = 3
+        args.inflight = default_inflight("backbone_rpn")
         cp = run_chunk_pipeline(net, cfg, args, rank, world, "backbone_rpn", barrier)
         args.inflight = saved
         cp["dt"] = max_over_ranks(cp["dt"])

@@ -425,7 +425,7 @@ int sis3d_conv3d_k3t16_ragged(const float *in, int cin, int cin_stride, const fl
  * The workgroup that owns a brick of voxels owns all `planes` channels of conv2 (the balanced k3 scheme of
  * sis3d_conv3d_k3t16), so the 1x1x1 tail runs on the brick while it is on the CU; `out` is bit-identical to
  * sis3d_conv3d_k3t16 followed by sis3d_conv3d_pw16.  w2_t16: sis3d_conv_k3t16_pack_weight(planes, planes); w3_pw16 / w1n_pw16:
- * sis3d_conv_pw16_pack_weight.  brick: 0 = 6x6x6, 1 = 3x3x3, -1 = sis3d_bottleneck16_brick's choice (which is
+ * sis3d_conv_pw16_pack_weight.  brick: 0 = 6x6x6, 1 = 3x3x3, 2 = 6x6x3 (two workgroups per CU), -1 = sis3d_bottleneck16_brick's choice (which is
  * -1 itself -> SIS3D_EUNSUPPORTED when the two-launch path is the better one: 64-plane blocks).  (planes, cio, c2)
  * instantiated: (32,32,{0,32}) (32,64,0) (32,128,{0,32}); others -> SIS3D_EUNSUPPORTED. */
 int sis3d_bottleneck16_brick(int X, int Y, int Z, int planes);

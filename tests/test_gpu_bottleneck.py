@@ -64,8 +64,8 @@ def test_network_shapes_vs_torch_cpu_and_two_launch_path(ops, planes, cio, c2, d
         assert y1n is None
 
 
-# partial bricks, grids smaller than a brick, both bricks forced; no bias; output into a channel range of a wider tensor
-@pytest.mark.parametrize("brick", [0, 1])
+# partial bricks, grids smaller than a brick, every brick forced; no bias; output into a channel range of a wider tensor
+@pytest.mark.parametrize("brick", [0, 1, 2])
 @pytest.mark.parametrize("dims", [(13, 9, 11), (5, 3, 2), (7, 6, 19)])
 def test_ragged_grids_both_bricks(ops, brick, dims):
     x, y1, pc2, pc3, stage, want, wantn = _case(ops, 32, 128, 32, dims, 7 * brick + dims[2], bias=(dims[0] != 5))
