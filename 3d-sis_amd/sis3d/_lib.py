@@ -100,6 +100,10 @@ SIGNATURES = {
                                    c_int, c_vp, c_int, c_vp]),
     "sis3d_conv3d_planar2_ragged": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "sis3d_maxpool3d_3x3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "sis3d_enet_initial": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "sis3d_enet_conv1": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "sis3d_enet_block": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                 c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "sis3d_planar_to_cl": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
     "sis3d_cl_to_planar": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
 }

@@ -158,8 +158,15 @@ class Network(nn.Module):
         with torch.no_grad():
             self.image_enet_fixed.eval()
             self.image_enet_trainable.eval()
-            if getattr(self, "fold_enet", True):
-                # same modules, BatchNorm + eval-dropout scale folded into the convolutions (nets/enet_folded.py): ~45 % fewer launches
+            impl = getattr(self, "enet_impl", "hip") if getattr(self, "fold_enet", True) else "modules"
+            if impl == "hip" and images.is_cuda:
+                # csrc/enet.hip: one launch per bottleneck (nets/enet_hip.py), 25 launches for the 5 views instead of ~190 operators
+                if getattr(self, "_enet_hip", None) is None:
+                    from .enet_hip import HipEncoder
+                    self._enet_hip = HipEncoder(self.image_enet_fixed, self.image_enet_trainable)
+                return self._enet_hip(images)
+            if impl in ("hip", "folded"):
+                # same modules on PyTorch-ROCm operators, BatchNorm + eval-dropout scale folded into the convolutions (nets/enet_folded.py)
                 if getattr(self, "_enet_folded", None) is None:
                     from .enet_folded import FoldedEncoder
                     self._enet_folded = FoldedEncoder(self.image_enet_fixed, self.image_enet_trainable)

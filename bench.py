@@ -90,7 +90,7 @@ def parse(argv=None):
     ap.add_argument("--from-depth", action="store_true", help="images workload: views arrive as depth maps + poses and the "
                     "voxel->pixel lists are computed on the device inside the timed step (sis3d_compute_projection)")
     ap.add_argument("--rgb", action="store_true", help="images workload: the views are RGB images and the ENet 2D encoder "
-                    "(PyTorch-ROCm operators, own captured graph) runs inside the timed step (BASELINE config[3] from pixels)")
+                    "(csrc/enet.hip, own captured graph) runs inside the timed step (BASELINE config[3] from pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--no-split-line", action="store_true", help="skip the separately reported split-bf16 measurement")
@@ -491,8 +491,24 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
     dt = time.perf_counter() - t0
     extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl}
     if workload == "images" and args.rgb:
-        extra["views_from"] = "RGB images (5 x 3 x 256 x 328) through the ENet encoder inside the step (5.2 GFLOP, PyTorch-ROCm operators)"
-        extra["enet_graph_captured"] = eng.engines[0].enet_graph is not None
+        extra["views_from"] = ("RGB images (5 x 3 x 256 x 328) through the ENet encoder inside the step (5.2 GFLOP; csrc/enet.hip, one launch "
+                               "per bottleneck: 25 launches)")
+        extra["enet_impl"] = getattr(net, "enet_impl", "hip")
+        e0 = eng.engines[0]
+        extra["enet_graph_captured"] = e0.enet_graph is not None
+        # the encoder alone on one pipeline: 30 passes (graph replays when captured) between HIP events on that pipeline's stream
+        with torch.cuda.stream(eng.streams[0]), torch.no_grad():
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(30):
+                if e0.enet_graph is not None:
+                    e0.enet_graph.replay()
+                else:
+                    e0._encode_views()
+            ev1.record()
+            ev1.synchronize()
+        extra["enet_ms_5_views"] = ev0.elapsed_time(ev1) / 30
     if from_depth:
         torch.cuda.synchronize()
         extra.update({"views_from": "depth maps + poses (lists computed on device inside the step)",

@@ -478,6 +478,31 @@ int sis3d_scene_merge(const float *blocks, int n_chunks, int k_rows, int width, 
                       int max_keep, float *recs, int32_t *order, int64_t *keep, int32_t *counts, void *workspace,
                       size_t workspace_bytes, sis3d_stream_t stream);
 
+/* ---- ENet 2D encoder of the RGB image path (lib/nets/enet.py:130-694 `create_enet`, run by lib/nets/network.py:203-205 as
+ * image_enet_trainable(image_enet_fixed(images)), eval mode) -- csrc/enet.hip.  These replace the cuDNN / MIOpen operator calls behind
+ * the nn.Conv2d / nn.BatchNorm2d / nn.PReLU / nn.MaxPool2d modules of that Sequential: BatchNorm (eval) and the torch7-style dropout
+ * scale are folded into the weights by the caller (sis3d/nets/enet_hip.py), activations are rows of channels per pixel (NHWC),
+ * weights are in the lane order of the 16x16x4 fp32 MFMA: [cout/16][cin/16][64][4] per filter tap (lane 16 kq + i of tile (ct, g)
+ * holds W[16 ct + i][16 g + 4 kq + r], r = 0..3; the layout sis3d_conv_pw16_pack_weight writes), taps in (ky, kx) order.
+ *   sis3d_enet_initial  cat(Conv2d(3,13,3,stride 2,padding 1)(x), MaxPool2d(2,2)(x)) -> BatchNorm2d(16) -> PReLU(16) (enet.py's first
+ *                       four entries): NCHW images (V,3,Hi,Wi), Hi / Wi even -> rows of 16 floats at Hi/2 x Wi/2.  w (13,3,3,3) / b (13):
+ *                       the filters with the BatchNorm affine folded in; pool_scale / pool_shift (3): the affine of the pooled channels.
+ *   sis3d_enet_conv1    a bottleneck's first convolution + BatchNorm + PReLU: taps = 4: Conv2d(cin, mid, 2, stride 2) of a down block
+ *                       (x at 2H x 2W -> y1 at H x W); taps = 1: the 1x1 reduction.  (cin, mid) in {(16,16), (64,16), (64,32), (128,32)}.
+ *   sis3d_enet_block    the rest of a bottleneck in one launch: y2 = prelu(conv2(y1) + b2, s2) with conv2 = 3x3 / dilation `dil`
+ *                       (kind 0, w2 = 9 taps) or the asymmetric Conv2d(1x5, no bias) -> Conv2d(5x1) pair (kind 1, w2 / w2b = 5 taps each);
+ *                       out = prelu(conv3(y2) + b3 + skip, s3), skip = x (pool_cin = 0) or MaxPool2d(2,2)(x) with x = rows of pool_cin
+ *                       floats at 2H x 2W, zero channels appended (down blocks); out = rows of c floats, or NCHW (V,c,H,W) if out_nchw;
+ *                       midn > 0: y1n = prelu(conv1_next(out) + b1n, s1n), the next bottleneck's 1x1 reduction (rows of midn floats).
+ *                       (c, mid, midn) in {(64,16,16), (64,16,0), (128,32,32), (128,32,0)}; others -> SIS3D_EUNSUPPORTED. */
+int sis3d_enet_initial(const float *images, int V, int Hi, int Wi, const float *w, const float *b, const float *pool_scale,
+                       const float *pool_shift, const float *slope, float *out, sis3d_stream_t stream);
+int sis3d_enet_conv1(const float *x, int V, int H, int W, int cin, int mid, int taps, const float *w, const float *b, const float *slope,
+                     float *y1, sis3d_stream_t stream);
+int sis3d_enet_block(const float *x, const float *y1, int V, int H, int W, int c, int mid, int kind, int dil, const float *w2, const float *b2,
+                     const float *s2, const float *w2b, const float *w3, const float *b3, const float *s3, int pool_cin, float *out, int out_nchw,
+                     const float *w1n, const float *b1n, const float *s1n, int midn, float *y1n, sis3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

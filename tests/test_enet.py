@@ -209,3 +209,75 @@ def test_folded_encoder_equals_module_tree_cpu():
         fixed[2].weight.mul_(1.5)                                # a parameter update must invalidate the folded copy
         want2, got2 = train(fixed(x)), enc(x)
         assert float((want2 - want).abs().max()) > 1e-3 and float((got2 - want2).abs().max()) <= 1e-5 * max(1.0, float(want2.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------- csrc/enet.hip executor
+def _seeded_encoder(seed=0):
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "enet_cases.npz"))
+    sd = synthetic.synth_enet_state_dict(_shapes(g), seed=seed)
+    m = enet.create_enet(41)
+    m.load_state_dict(sd)
+    fixed, train, _ = enet.split_enet_for_3d(m)
+    return sd, fixed.eval(), train.eval()
+
+
+def test_hip_encoder_plan_reads_the_module_tree_cpu():
+    """nets/enet_hip.py: the launch plan built from the reference-named modules (no GPU needed): 22 bottlenecks, the two stride-2
+    blocks where enet.py has them, stages 2 and 3 = regular, dilated 2, asymmetric 5, dilated 4, regular, dilated 8, asymmetric 5,
+    dilated 16; packed weights have the lane-order size; pack_pw is the documented permutation"""
+    from sis3d.nets.enet_hip import HipEncoder, pack_pw, pack_taps
+    sd, fixed, train = _seeded_encoder()
+    plan = HipEncoder(fixed, train)._build()
+    bl = plan["blocks"]
+    assert len(bl) == 22
+    assert [i for i, b in enumerate(bl) if b.down] == [0, 5]
+    assert [(b.cin, b.c, b.mid) for b in bl[:6]] == [(16, 64, 16)] + [(64, 64, 16)] * 4 + [(64, 128, 32)]
+    stage = [(0, 1), (0, 2), (1, 1), (0, 4), (0, 1), (0, 8), (1, 1), (0, 16)]
+    assert [(b.kind, b.dil) for b in bl[6:]] == stage + stage
+    for b in bl:
+        assert b.w2.numel() == (5 if b.kind else 9) * b.mid * b.mid and b.w3.numel() == b.c * b.mid
+        assert b.w1.numel() == (4 if b.down else 1) * b.mid * b.cin and (b.w2b is None) == (b.kind == 0)
+    w = torch.arange(32 * 48, dtype=torch.float32).view(32, 48)
+    p = pack_pw(w).view(2, 3, 64, 4)
+    for ct, g_, lane, r in [(0, 0, 0, 0), (1, 2, 37, 3), (0, 1, 63, 1), (1, 0, 16, 2)]:
+        assert float(p[ct, g_, lane, r]) == float(w[16 * ct + (lane & 15), 16 * g_ + 4 * (lane >> 4) + r])
+    w4 = torch.randn(16, 16, 2, 2)
+    assert torch.equal(pack_taps(w4).view(4, -1)[3], pack_pw(w4[:, :, 1, 1]))
+    assert plan["init"][0].shape == (13, 3, 3, 3) and plan["init"][2].numel() == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(5, 3, 256, 328), (3, 3, 40, 56), (1, 3, 64, 80)])
+def test_hip_encoder_vs_oracle_and_operators(oracle, shape):
+    """csrc/enet.hip (one launch per bottleneck) against the CPU oracle (1e-4 of the feature scale, the bound of the operator path) and
+    against the same folded weights on PyTorch-ROCm operators; 105- and 80-pixel maps exercise the partial last tile and the borders of
+    the dilated / asymmetric convolutions (dilation 16 on an 5 x 7 map: only the centre tap is inside)"""
+    from sis3d.nets.enet_folded import FoldedEncoder
+    from sis3d.nets.enet_hip import HipEncoder
+    sd, fixed, train = _seeded_encoder(seed=1)
+    fixed.cuda()
+    train.cuda()
+    x = synthetic.synth_images(7, shape[0])[:, :, :shape[2], :shape[3]].contiguous()
+    assert tuple(x.shape) == shape
+    with torch.no_grad():
+        got = HipEncoder(fixed, train)(x.cuda())
+        ops_ = FoldedEncoder(fixed, train)(x.cuda())
+    torch.cuda.synchronize()
+    want = oracle.enet_forward(sd, x, 0, 26)
+    assert tuple(got.shape) == tuple(want.shape) == (shape[0], 128, shape[2] // 8, shape[3] // 8) and got.is_contiguous()
+    e_o, e_t = _rel_err(got.cpu(), want), _rel_err(got, ops_)
+    print("[enet hip] %s: vs oracle %.2e, vs PyTorch-ROCm operators %.2e (feature scale %.2f)" % (shape, e_o, e_t, float(want.abs().max())))
+    assert e_o <= 1e-4 and e_t <= 1e-4
+
+
+@pytest.mark.gpu
+def test_network_image_features_runs_the_hip_encoder():
+    c = config.scannet_benchmark_cfg()
+    c.USE_IMAGES, c.USE_IMAGES_GT, c.USE_MASK = True, False, False
+    net, _ = _rgb_net(c)
+    x = synthetic.synth_images(5, 2).cuda()
+    a = net.image_features(x)
+    assert net._enet_hip is not None and getattr(net, "_enet_folded", None) is None
+    net.enet_impl = "folded"
+    b = net.image_features(x)
+    assert net._enet_folded is not None and _rel_err(a, b) <= 1e-4
