@@ -14,6 +14,7 @@ run python bench.py --workload detect --no-cpu-baseline 2>/dev/null | tail -1 > 
 run python bench.py --workload detect --masks --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_detect_masks.json"
 run python bench.py --workload images --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_images.json"
 run python bench.py --workload images --rgb --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_images_rgb.json"
+run python bench.py --inflight 3 --no-cpu-baseline --no-side-workloads 2>/dev/null | tail -1 > "$OUT/bench_backbone_rpn_inflight3.json"
 SIS3D_FORCE_DIST=1 run python bench.py --workload scene --steps 20 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_scene.json"
 SIS3D_FORCE_DIST=1 run python bench.py --workload scene --scene-chunks 4 --steps 100 --warmup 20 --no-cpu-baseline --no-side-workloads 2>/dev/null | tail -1 > "$OUT/bench_scene4.json"
 cd /tmp && export TMPDIR=/tmp
@@ -36,6 +37,16 @@ for wl in backbone_rpn detect; do
 done
 cd "$ROOT"
 bash tools/r03_wpmc.sh "$TAG/wino_pmc" rpn > "$OUT/wino_pmc.log" 2>&1
+# issue-cost microbenchmark and the Winograd kernel's phase timestamps / one-cost-at-a-time variants (tools/_bin: built on the build host by
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/issue_overlap.hip -o tools/_bin/issue_overlap
+#   hipcc ... -fno-slp-vectorize -Iinclude -I3d-sis_amd/csrc -DWN_EXP=<bits> tools/wino_bench.cpp 3d-sis_amd/csrc/conv3d_wino.hip 3d-sis_amd/csrc/api.hip)
+if [ -x tools/_bin/issue_overlap ]; then timeout 120 tools/_bin/issue_overlap > "$OUT/issue_overlap.txt" 2>&1; fi
+: > "$OUT/wino_phases.txt"
+for b in 0 96 119 103 118 117 115 112; do
+  if [ -x tools/_bin/wino_bench_$b ]; then
+    for a in "128 256 24 12 24 1" "128 256 24 12 24 2" "128 128 24 12 24 1"; do timeout 60 tools/_bin/wino_bench_$b $a | tail -2 >> "$OUT/wino_phases.txt"; done
+  fi
+done
 bash tools/hbm_pmc.sh "$TAG/hbm" > "$OUT/hbm_pmc.log" 2>&1
 for f in "$OUT"/bench_*.json; do echo "$(basename $f): $(cut -c1-200 $f)"; done
 tail -12 "$OUT/hbm_pmc.log"
