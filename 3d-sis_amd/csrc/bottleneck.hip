@@ -65,7 +65,7 @@ struct BnArgs {
 #endif
 
 template <int BX, int BY, int BZ, int PL, int CIO, int C2>
-__global__ __launch_bounds__(256, (BX * BY * BZ <= 108 ? 2 : 1)) void bottleneck16_kernel(const BnArgs a)
+__global__ __launch_bounds__(256, (BX * BY * BZ == 108 ? 2 : 1)) void bottleneck16_kernel(const BnArgs a)
 {
     constexpr int M = BX * BY * BZ, MT = (M + 15) / 16;
     constexpr int NTC = PL / 16, NQ = PL / CK, NT3 = CIO / 16, NTN = C2 / 16;

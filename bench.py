@@ -708,7 +708,7 @@ def main(argv=None):
             sc = scene_side(scene_steps)
     if both:
         side["chunk_pipeline"] = chunk_pipeline_entry(cp["vox_per_step"] * args.steps / cp["dt"], "voxels/s", cp["dt"] / args.steps * 1e3,
-                                                      3, cp["single_ms"])
+                                                      cp["vox_per_step"] / VOXELS / world, cp["single_ms"])
         side["scene"] = scene_entry(sc["vox_per_step"] * sc["steps"] / sc["dt"], "voxels/s", sc["dt"] / sc["steps"] * 1e3, sc["steps"],
                                     sc["extra"])
         if world > 1 and rank == 0:
