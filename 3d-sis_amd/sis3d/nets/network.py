@@ -159,13 +159,16 @@ class Network(nn.Module):
             self.image_enet_fixed.eval()
             self.image_enet_trainable.eval()
             impl = getattr(self, "enet_impl", "hip") if getattr(self, "fold_enet", True) else "modules"
-            if impl == "hip" and images.is_cuda:
+            if impl == "hip":
+                if not images.is_cuda:
+                    raise ops._lib.Sis3dError("image_features: images must be on the GPU (sis3d has no CPU path; enet_impl = 'folded' / "
+                                          "fold_enet = False run the module tree on PyTorch operators)")
                 # csrc/enet.hip: one launch per bottleneck (nets/enet_hip.py), 25 launches for the 5 views instead of ~190 operators
                 if getattr(self, "_enet_hip", None) is None:
                     from .enet_hip import HipEncoder
                     self._enet_hip = HipEncoder(self.image_enet_fixed, self.image_enet_trainable)
                 return self._enet_hip(images)
-            if impl in ("hip", "folded"):
+            if impl == "folded":
                 # same modules on PyTorch-ROCm operators, BatchNorm + eval-dropout scale folded into the convolutions (nets/enet_folded.py)
                 if getattr(self, "_enet_folded", None) is None:
                     from .enet_folded import FoldedEncoder

@@ -281,3 +281,18 @@ def test_network_image_features_runs_the_hip_encoder():
     net.enet_impl = "folded"
     b = net.image_features(x)
     assert net._enet_folded is not None and _rel_err(a, b) <= 1e-4
+
+
+def test_image_features_rejects_cpu_images_on_the_hip_route():
+    """the default route of Network.image_features is csrc/enet.hip: a CPU tensor is an error, not a silent run on CPU operators"""
+    from sis3d import _lib
+    from sis3d.nets import backbones
+    c = config.scannet_benchmark_cfg()
+    c.USE_IMAGES, c.USE_IMAGES_GT, c.USE_MASK = True, False, False
+    net = backbones.ScanNet_Backbone(cfg=c)
+    net.init_modules()
+    net.eval()
+    with pytest.raises(_lib.Sis3dError):
+        net.image_features(torch.zeros(1, 3, 64, 80))
+    net.enet_impl = "folded"                                     # an explicit choice of the operator path runs wherever the tensors are
+    assert tuple(net.image_features(torch.zeros(1, 3, 64, 80)).shape) == (1, 128, 8, 10)
