@@ -441,6 +441,9 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // the clamped duplicate DMA and raw-stage loads of the last steps.  The wait names sv: the loads are asm, so hipcc does not know
     // they are still writing those registers -- without the operands it hands them to the epilogue above this line
     wait_vmcnt<0>(sv[0], sv[1], sv[2]);
+    // the MFMAs are asm: hipcc's hazard recogniser does not know that the accumulators the epilogue is about to read were written by
+    // the matrix pipe a few cycles ago (an 8-pass MFMA needs up to 11 wait states before a VALU read of its result)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();                                     // quads 6, 7 of the last step ran behind the last in-loop barrier
 
     // ---- output transform A^T M A: per lane, cout tile c and row r (tile 4 (lane >> 4) + r, cout lane & 15): 32 xi -> 8 partial

@@ -68,6 +68,35 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
     const int x0 = pc % W, y0 = (pc / W) % H;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // ---- every operand that does not depend on conv2 is requested first: the weights of conv3 and of the next block's conv1 and the
+    // skip rows travel while conv2 runs, so the kernel pays one L2 round trip instead of three
+    const float4 *w3 = reinterpret_cast<const float4 *>(a.w3) + lane;
+    float4 w3v[CT][MT];
+    static_for<0, CT>([&](auto N) { static_for<0, MT>([&](auto G) { w3v[decltype(N)::value][decltype(G)::value] = w3[(decltype(N)::value * MT + decltype(G)::value) * 64]; }); });
+    float4 skip[CT];
+    if (a.pool_cin > 0) {
+        // down blocks: MaxPool2d(2,2) of the input at 2H x 2W, zero channels appended up to C (enet.py's padding layer)
+        const int v = pc / (W * H);
+        const float *s00 = a.x + ((size_t)(v * 2 * H + 2 * y0) * (2 * W) + 2 * x0) * a.pool_cin + 4 * kq;
+        const size_t rowstep = (size_t)2 * W * a.pool_cin;
+        static_for<0, CT>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            if (16 * n < a.pool_cin) {
+                const float *q = s00 + 16 * n;
+                skip[n] = max4(max4(ld4(q), ld4(q + a.pool_cin)), max4(ld4(q + rowstep), ld4(q + rowstep + a.pool_cin)));
+            } else {
+                skip[n] = zero4;
+            }
+        });
+    } else {
+        static_for<0, CT>([&](auto N) { skip[decltype(N)::value] = ld4(a.x + (size_t)pc * C + 16 * decltype(N)::value + 4 * kq); });
+    }
+    [[maybe_unused]] float4 w1v[NT > 0 ? NT : 1][CT];
+    if constexpr (NT > 0) {
+        const float4 *w1 = reinterpret_cast<const float4 *>(a.w1n) + lane;
+        static_for<0, NT>([&](auto N) { static_for<0, CT>([&](auto G) { w1v[decltype(N)::value][decltype(G)::value] = w1[(decltype(N)::value * CT + decltype(G)::value) * 64]; }); });
+    }
+
     // ---- conv2 (zero padding: taps outside the image contribute nothing)
     f32x4 acc[MT][2];
     static_for<0, MT>([&](auto N) { acc[decltype(N)::value][0] = acc[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
@@ -117,28 +146,7 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
                                    acc[n][0][3] + acc[n][1][3] + b.w), s);
     });
 
-    // ---- conv3 + skip + PReLU
-    const float4 *w3 = reinterpret_cast<const float4 *>(a.w3) + lane;
-    float4 w3v[CT][MT];
-    static_for<0, CT>([&](auto N) { static_for<0, MT>([&](auto G) { w3v[decltype(N)::value][decltype(G)::value] = w3[(decltype(N)::value * MT + decltype(G)::value) * 64]; }); });
-    float4 skip[CT];
-    if (a.pool_cin > 0) {
-        // down blocks: MaxPool2d(2,2) of the input at 2H x 2W, zero channels appended up to C (enet.py's padding layer)
-        const int v = pc / (W * H);
-        const float *s00 = a.x + ((size_t)(v * 2 * H + 2 * y0) * (2 * W) + 2 * x0) * a.pool_cin + 4 * kq;
-        const size_t rowstep = (size_t)2 * W * a.pool_cin;
-        static_for<0, CT>([&](auto N) {
-            constexpr int n = decltype(N)::value;
-            if (16 * n < a.pool_cin) {
-                const float *q = s00 + 16 * n;
-                skip[n] = max4(max4(ld4(q), ld4(q + a.pool_cin)), max4(ld4(q + rowstep), ld4(q + rowstep + a.pool_cin)));
-            } else {
-                skip[n] = zero4;
-            }
-        });
-    } else {
-        static_for<0, CT>([&](auto N) { skip[decltype(N)::value] = ld4(a.x + (size_t)pc * C + 16 * decltype(N)::value + 4 * kq); });
-    }
+    // ---- conv3 + skip + PReLU (operands requested at the top of the kernel)
     f32x4 o[CT];
     static_for<0, CT>([&](auto N) { o[decltype(N)::value] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
     static_for<0, MT>([&](auto G) {
@@ -173,10 +181,18 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
 
     // ---- the next bottleneck's conv1 (1x1, C -> MIDN) + PReLU on the block output while it is in registers
     if constexpr (NT > 0) {
-        const float4 *w1 = reinterpret_cast<const float4 *>(a.w1n) + lane;
         f32x4 n1[NT][2];
         static_for<0, NT>([&](auto N) { n1[decltype(N)::value][0] = n1[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
-        gemm_acc<NT, CT>(w1, ov, n1);
+        static_for<0, CT>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            static_for<0, 4>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                static_for<0, NT>([&](auto N) {
+                    constexpr int n = decltype(N)::value;
+                    n1[n][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp<r>(w1v[n][g]), comp<r>(ov[g]), n1[n][r & 1], 0, 0, 0);
+                });
+            });
+        });
         if (live) {
             static_for<0, NT>([&](auto N) {
                 constexpr int n = decltype(N)::value;
