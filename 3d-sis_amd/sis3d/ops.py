@@ -872,6 +872,44 @@ def conv3d(x, pc, stride=1, relu=False, residual=None, sigmoid=False, out=None, 
     return ret
 
 
+# ---- sparse colour stem (csrc/proj_sparse.hip): only the output voxels that see a visible input voxel are computed
+SPARSE_PROJECTION = _os.environ.get("SIS3D_SPARSE_PROJECTION", "1") != "0"
+
+
+def set_sparse_projection(on):
+    """True (default): Conv3d(128, 64, k=2, s=2) on a ProjectedVolume runs on the sparse kernels (sis3d_conv3d_k2s2_projected_sparse);
+    False: the dense kernel that reads every voxel through the table (sis3d_conv3d_chain_projected).  Same arithmetic, different
+    summation order (~1e-6 of the output scale)."""
+    global SPARSE_PROJECTION
+    SPARSE_PROJECTION = bool(on)
+
+
+def _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main):
+    """-> (main, [stage out]) or None when the shape is not the colour stem's (the dense kernel serves it then)"""
+    if pc.cin != 128 or pc.cout != 64 or pc.packed_pw16 is None or len(stages) > 1 or any(d % 2 for d in x.dims):
+        return None
+    spc = None
+    if stages:
+        st = stages[0]
+        spc = st["pc"]
+        if (spc.k != 1 or spc.cin != 64 or spc.cout != 32 or spc.packed_pw16 is None or not st.get("relu", True) or st.get("residual") is not None
+                or st.get("out") is not None):
+            return None
+    X, Y, Z = x.dims
+    od = (X // 2, Y // 2, Z // 2)
+    main = new_act(pc.cout, od, x.device)
+    so = new_act(spc.cout, od, x.device) if spc is not None else None
+    wsb = lib().sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(X, Y, Z)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    rc = lib().sis3d_conv3d_k2s2_projected_sparse(_ptr(x.table), _ptr(x.rows), x.nslots, x.npix, X, Y, Z, pc.cin, _ptr(pc.packed_pw16),
+                                                  _ptr(pc.bias), pc.cout, 1 if relu else 0, _ptr(main), _ptr(spc.packed_pw16) if spc else None,
+                                                  _ptr(spc.bias) if spc else None, spc.cout if spc else 0, _ptr(so), _ptr(ws), wsb, _stream())
+    if rc == -4:
+        return None
+    check(rc, "sis3d_conv3d_k2s2_projected_sparse")
+    return (main if want_main else None), ([so] if spc is not None else [])
+
+
 def conv3d_chain(x, pc, stride, stages, relu=True, want_main=False):
     """Main conv (k3 / k2s2, + bias, ReLU) followed by fused 1x1x1 stages on the on-chip tile (sis3d_conv3d_chain).
     stages: list of dicts(pc=PackedConv(k=1), relu=bool, residual=tensor|None, keep=bool).  Returns
@@ -879,6 +917,10 @@ def conv3d_chain(x, pc, stride, stages, relu=True, want_main=False):
     proj = isinstance(x, ProjectedVolume)
     if proj and (pc.k != 2 or stride != 2 or pc.cin != x.C):
         raise Sis3dUnsupported("a projected volume feeds Conv3d(C, *, k=2, s=2) only")
+    if proj and SPARSE_PROJECTION:
+        r = _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main)
+        if r is not None:
+            return r
     if not proj and not is_cl(x):
         raise _lib.Sis3dError("conv3d_chain expects a channels-last activation")
     _, cin_t, X, Y, Z = x.shape

@@ -282,6 +282,19 @@ int sis3d_conv3d_chain_projected(const int32_t *vox2pix, const float *feat_rows,
                                  int cin, const float *packed_w, const float *bias, int cout, int flags, float *out,
                                  int out_stride, int nstages, const sis3d_pw_stage *stages_host, sis3d_stream_t stream);
 
+/* sis3d_conv3d_chain_projected for the colour stem proper -- color[0] = Conv3d(128, 64, k=2, s=2, bias) + ReLU (lib/nets/backbones.py:187,214)
+ * on the view max of lib/nets/network.py:216-239, followed (c2 = 32) by the next Bottleneck's conv1 (1x1x1, 64 -> 32, + b1, ReLU) -- computed
+ * SPARSELY (csrc/proj_sparse.hip): output voxels none of whose eight input voxels is seen by a view get the constant row of a zero input
+ * (relu(bias); relu(W1 relu(bias) + b1)), the others are compacted (ascending order, no atomics) and computed 64 per workgroup.  The launch
+ * sequence does not depend on the visibility (worst-case grid, workgroups past the list exit), so it captures into a HIP graph.
+ * w_pw16: sis3d_conv_pw16_pack_weight of the (64, 8 * 128) matrix with column = tap * 128 + ci, tap = (dx * 2 + dy) * 2 + dz; w1_pw16: the
+ * same pack of (32, 64).  out / y1: rows of 64 / 32 floats per output voxel (x-major, z fastest).  X, Y, Z: the INPUT grid (even).
+ * Other channel counts -> SIS3D_EUNSUPPORTED (the dense kernel serves them). */
+size_t sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(int X, int Y, int Z);
+int sis3d_conv3d_k2s2_projected_sparse(const int32_t *vox2pix, const float *feat_rows, int nslots, int64_t npix, int X, int Y, int Z, int cin,
+                                       const float *w_pw16, const float *bias, int cout, int relu, float *out, const float *w1_pw16,
+                                       const float *b1, int c2, float *y1, void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
+
 /* The pointwise half of the Bottleneck (lib/nets/backbones.py:33-40) as ONE launch when conv2 ran on its own
  * (sis3d_conv3d_k3t16):   main  = relu(conv3(y2) + b3 + x)      1x1x1 + residual; the block output, written to `out` at
  *                                                               channel offset out_coff of rows of out_stride floats

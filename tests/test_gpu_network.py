@@ -279,7 +279,8 @@ def test_forward_from_depth_maps_vs_oracle(oracle, kill_view):
 @pytest.mark.parametrize("n_per_view,kill", [(400, ()), (3000, (1,)), (0, ())])
 def test_fused_projection_equals_materialised_volume(oracle, n_per_view, kill):
     """colour stem reading the views through the voxel->pixel table (no 226 MB volume, empty bricks skipped) ==
-    the same network on the materialised volume, bit for bit; and the lazily materialised `_imageft` is the oracle's."""
+    the same network on the materialised volume, bit for bit (dense table kernel) / within 1e-5 (sparse kernels, the default);
+    and the lazily materialised `_imageft` is the oracle's."""
     from sis3d import ops
     dims = (96, 48, 96) if n_per_view == 3000 else (64, 32, 48)
     cfg = config.scannet_benchmark_cfg()
@@ -289,15 +290,28 @@ def test_fused_projection_equals_materialised_volume(oracle, n_per_view, kill):
     data = synthetic.synth_chunk(6, dims)
     feats, i3d, i2d = synthetic.synth_views(6, n_views=4, n_per_view=n_per_view, dims=dims)
     outs = []
-    for fuse in (True, False):
-        net.fuse_projection = fuse
-        net.delete_intermediate_states()
-        p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", list(kill))
-        assert isinstance(net._image_input, ops.ProjectedVolume) == fuse
-        outs.append((net._net_conv[0].clone(), net._net_conv[1].clone(), p["rpn_cls_prob_level1"].clone(), p["rois"][0].clone(),
-                     net._imageft.clone()))
+    ops.set_sparse_projection(False)                  # the DENSE table kernel: same tiles, same summation order as the tensor path
+    try:
+        for fuse in (True, False):
+            net.fuse_projection = fuse
+            net.delete_intermediate_states()
+            p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", list(kill))
+            assert isinstance(net._image_input, ops.ProjectedVolume) == fuse
+            outs.append((net._net_conv[0].clone(), net._net_conv[1].clone(), p["rpn_cls_prob_level1"].clone(), p["rois"][0].clone(),
+                         net._imageft.clone()))
+    finally:
+        ops.set_sparse_projection(True)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    # the default route, csrc/proj_sparse.hip (only output voxels with a visible input voxel are computed; tap-major summation):
+    # the same network within fp32 summation noise, same proposals
+    net.fuse_projection = True
+    net.delete_intermediate_states()
+    p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", list(kill))
+    assert isinstance(net._image_input, ops.ProjectedVolume)
+    for got, want in ((net._net_conv[0], outs[0][0]), (net._net_conv[1], outs[0][1]), (p["rpn_cls_prob_level1"], outs[0][2])):
+        assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert p["rois"][0].shape == outs[0][3].shape and float((p["rois"][0] - outs[0][3]).abs().max()) <= 1e-3
     want = oracle.project_views_max(feats, i3d, i2d, dims, kill)
     assert torch.equal(outs[0][4].cpu(), want)
 
