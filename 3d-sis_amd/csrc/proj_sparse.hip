@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int CIN = 128, COUT = 64, KG = CIN / 16, CT = COUT / 16;
+constexpr int MAXSL = 6;                                      // view slots the tile kernel holds table entries for
 constexpr int TAP_FLOATS = CT * KG * 256;                     // one tap's weights in pw16 order: [CT][KG][64][4]
 
 struct ProjArgs {
@@ -134,7 +135,7 @@ template <int R>
 __device__ __forceinline__ float comp4(const float4 &v) { return R == 0 ? v.x : R == 1 ? v.y : R == 2 ? v.z : v.w; }
 
 template <int C2>
-__global__ __launch_bounds__(256) void proj_tile_kernel(const ProjArgs a)
+__global__ __launch_bounds__(256, 1) void proj_tile_kernel(const ProjArgs a)
 {
     __shared__ __attribute__((aligned(16))) float wl[2][TAP_FLOATS];              // two taps of weights, 32 KB each
     const int total = a.total[0];
@@ -149,58 +150,71 @@ __global__ __launch_bounds__(256) void proj_tile_kernel(const ProjArgs a)
     const int OY = a.Y / 2, OZ = a.Z / 2;
     const int oz = row % OZ, oy = (row / OZ) % OY, ox = row / (OZ * OY);
 
-    // weights of tap 0 -> LDS
-    const float4 *wg = reinterpret_cast<const float4 *>(a.w);
-    auto tap_src = [&](int tap, int i) {          // float4 index i in [0, CT*KG*64) of the tap's block -> index into the pw16 pack
-        const int ct = i / (KG * 64), rem = i % (KG * 64);
-        return ((size_t)ct * (8 * KG) + (size_t)tap * KG) * 64 + rem;
+    // one tap's weights = 32 chunks of 1 KB ([ct][g][64 lanes][16 B]); a wave moves 8 of them global -> LDS by LDS-DMA (no registers:
+    // staged through a register array the copy went through scratch memory)
+    auto stage_tap = [&](int tap, int buf) __attribute__((always_inline)) {
+        static_for<0, 8>([&](auto J) {
+            const int c = wave * 8 + decltype(J)::value, ct = c / KG, g = c % KG;
+            const float *src = a.w + (((size_t)ct * (8 * KG) + (size_t)tap * KG + g) * 64 + lane) * 4;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
+                                             (void __attribute__((address_space(3))) *)(wl[buf] + c * 256), 16, 0, 0);
+        });
     };
-    constexpr int WPT = CT * KG * 64 / 256;                                         // float4 per thread per tap: 8
-    float4 wr[WPT];
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) wr[j] = wg[tap_src(0, tid + j * 256)];
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) reinterpret_cast<float4 *>(wl[0])[tid + j * 256] = wr[j];
+    stage_tap(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     f32x4 acc[CT][2];
     static_for<0, CT>([&](auto N) { acc[decltype(N)::value][0] = acc[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // every table entry of the voxel's eight input voxels, requested at once (a lane whose tap bit is clear reads them too: no branch,
+    // no dependent chain): the per-tap gather below then costs ONE memory round trip, and it runs one tap ahead of the MFMAs
+    int pix[8][MAXSL];
     static_for<0, 8>([&](auto T) {
         constexpr int tap = decltype(T)::value, dx = tap >> 2, dy = (tap >> 1) & 1, dz = tap & 1;
-        if constexpr (tap + 1 < 8) {
-#pragma unroll
-            for (int j = 0; j < WPT; ++j) wr[j] = wg[tap_src(tap + 1, tid + j * 256)];
-        }
+        const int64_t vox = ((int64_t)(2 * oz + dz) * a.Y + (2 * oy + dy)) * a.X + (2 * ox + dx);
+        static_for<0, MAXSL>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            pix[tap][sl] = sl < a.nslots ? a.tab[(sl < a.nslots ? sl : 0) * a.nvox + vox] : -1;
+        });
+    });
+    // network.py:216-239 per voxel: max over the included views, an invisible view counts as 0
+    auto gather = [&](auto T, float4 (&xv)[KG]) __attribute__((always_inline)) {
+        constexpr int tap = decltype(T)::value;
         const bool mine = (m >> tap) & 1;
-        if (__ballot(mine) != 0ull) {                                               // wave-uniform: none of the 16 voxels sees this tap
-            float4 xv[KG];
-            static_for<0, KG>([&](auto G) { xv[decltype(G)::value] = zero4; });
-            if (mine) {
-                // network.py:216-239 per voxel: max over the included views, an invisible view counts as 0
-                const int64_t vox = ((int64_t)(2 * oz + dz) * a.Y + (2 * oy + dy)) * a.X + (2 * ox + dx);
-                int cnt = 0;
-                for (int sl = 0; sl < a.nslots; ++sl) {
-                    const int pix = a.tab[sl * a.nvox + vox];
-                    if (pix >= 0) {
-                        const float *src = a.rows + ((size_t)sl * a.npix + pix) * CIN + 4 * kq;
-                        static_for<0, KG>([&](auto G) {
-                            constexpr int g = decltype(G)::value;
-                            const float4 f = *reinterpret_cast<const float4 *>(src + 16 * g);
-                            if (cnt == 0) xv[g] = f;
-                            else xv[g] = make_float4(fmaxf(xv[g].x, f.x), fmaxf(xv[g].y, f.y), fmaxf(xv[g].z, f.z), fmaxf(xv[g].w, f.w));
-                        });
-                        ++cnt;
-                    }
-                }
-                if (cnt > 0 && cnt < a.nslots) {
-                    static_for<0, KG>([&](auto G) {
-                        constexpr int g = decltype(G)::value;
-                        xv[g] = make_float4(fmaxf(xv[g].x, 0.f), fmaxf(xv[g].y, 0.f), fmaxf(xv[g].z, 0.f), fmaxf(xv[g].w, 0.f));
-                    });
-                }
+        static_for<0, KG>([&](auto G) { xv[decltype(G)::value] = zero4; });
+        int cnt = 0;
+        static_for<0, MAXSL>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            const int px = pix[tap][sl];
+            if (mine && px >= 0) {
+                const float *src = a.rows + ((size_t)sl * a.npix + px) * CIN + 4 * kq;
+                static_for<0, KG>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    const float4 f = *reinterpret_cast<const float4 *>(src + 16 * g);
+                    xv[g] = cnt == 0 ? f : make_float4(fmaxf(xv[g].x, f.x), fmaxf(xv[g].y, f.y), fmaxf(xv[g].z, f.z), fmaxf(xv[g].w, f.w));
+                });
+                ++cnt;
             }
+        });
+        if (cnt > 0 && cnt < a.nslots) {
+            static_for<0, KG>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                xv[g] = make_float4(fmaxf(xv[g].x, 0.f), fmaxf(xv[g].y, 0.f), fmaxf(xv[g].z, 0.f), fmaxf(xv[g].w, 0.f));
+            });
+        }
+    };
+    float4 xa[KG], xb[KG];
+    gather(std::integral_constant<int, 0>{}, xa);
+
+    auto do_tap = [&](auto T, float4 (&xv)[KG], float4 (&xn)[KG]) __attribute__((always_inline)) {
+        constexpr int tap = decltype(T)::value;
+        if constexpr (tap + 1 < 8) {
+            stage_tap(tap + 1, (tap + 1) & 1);                                      // that buffer was last read during tap - 1 (barrier since)
+            gather(std::integral_constant<int, tap + 1>{}, xn);                     // in flight under this tap's MFMAs
+        }
+        if (__ballot((m >> tap) & 1) != 0ull) {                                     // wave-uniform: none of the 16 voxels sees this tap
             const float4 *wt = reinterpret_cast<const float4 *>(wl[tap & 1]) + lane;
             static_for<0, KG>([&](auto G) {
                 constexpr int g = decltype(G)::value;
@@ -216,11 +230,13 @@ __global__ __launch_bounds__(256) void proj_tile_kernel(const ProjArgs a)
             });
         }
         if constexpr (tap + 1 < 8) {
-            // the other buffer was last read during tap - 1: every wave is past it (barrier at the end of that tap)
-#pragma unroll
-            for (int j = 0; j < WPT; ++j) reinterpret_cast<float4 *>(wl[(tap + 1) & 1])[tid + j * 256] = wr[j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the next tap's weights has landed
             __syncthreads();
         }
+    };
+    static_for<0, 8>([&](auto T) {
+        if constexpr (decltype(T)::value & 1) do_tap(T, xb, xa);
+        else do_tap(T, xa, xb);
     });
 
     // ---- bias, ReLU, store; then the stage conv on the tile
@@ -280,7 +296,7 @@ extern "C" int sis3d_conv3d_k2s2_projected_sparse(const int32_t *vox2pix, const 
     if (!vox2pix || !feat_rows || !w_pw16 || !out || !workspace || nslots < 0 || npix <= 0 || X <= 0 || Y <= 0 || Z <= 0) return SIS3D_EINVAL;
     if ((X | Y | Z) & 1) return SIS3D_EINVAL;
     if (c2 < 0 || (c2 > 0 && (!w1_pw16 || !y1))) return SIS3D_EINVAL;
-    if (cin != CIN || cout != COUT || (c2 != 0 && c2 != 32)) return SIS3D_EUNSUPPORTED;
+    if (cin != CIN || cout != COUT || (c2 != 0 && c2 != 32) || nslots > MAXSL) return SIS3D_EUNSUPPORTED;
     const int64_t nout64 = (int64_t)(X / 2) * (Y / 2) * (Z / 2);
     if (nout64 >= (1 << 24)) return SIS3D_EUNSUPPORTED;                            // the list packs the row index into 24 bits
     if (workspace_bytes < sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(X, Y, Z)) return SIS3D_EWORKSPACE;
