@@ -49,7 +49,7 @@ class ChunkEngine:
             self.feats_ = [torch.zeros(self.n_views, cfg.NUM_IMAGE_CHANNELS, h, w, device=self.device) for _ in range(G)]
             self.i3d_ = [torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device) for _ in range(G)]
             self.i2d_ = [torch.zeros(self.n_views, nvox + 1, dtype=torch.int64, device=self.device) for _ in range(G)]
-            # RGB input (USE_IMAGES_GT=False): the 2D encoder (PyTorch-ROCm operators) runs inside the step, in its own captured
+            # RGB input (USE_IMAGES_GT=False): the 2D encoder (csrc/enet.hip, one launch per bottleneck) runs inside the step, in its own captured
             # graph in front of the 3D graph (falls back to eager launches if the capture of those library calls is refused)
             self.rgb = bool(cfg.USE_IMAGES and not cfg.USE_IMAGES_GT)
             if self.rgb:

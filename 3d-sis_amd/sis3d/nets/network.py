@@ -70,7 +70,7 @@ class Network(nn.Module):
             self.mask_backbone = getattr(backbones, cfg.MASK_BACKBONE)(cfg=cfg)
         if cfg.USE_IMAGES and not cfg.USE_IMAGES_GT:
             # network.py:63-64: the 2D encoder, split into its frozen and trainable halves + classifier (same attribute
-            # names = same state_dict keys).  PyTorch-ROCm operators: outside the hand-written 3D path.
+            # names = same state_dict keys).  The module tree holds the parameters; on the GPU its eval forward runs on csrc/enet.hip (image_features).
             from . import enet
             self.image_enet_fixed, self.image_enet_trainable, self.image_enet_classification = enet.create_enet_for_3d(
                 cfg.NUM_2D_CLASSES, cfg.get("PRETRAINED_ENET_PATH", ""), cfg.NUM_CLASSES)
