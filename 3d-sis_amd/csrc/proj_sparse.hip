@@ -50,13 +50,18 @@ __global__ __launch_bounds__(256) void proj_mask_kernel(const ProjArgs a)
     int m = 0;
     if (t < a.nout) {
         const int ox = t % OX, oy = (t / OX) % OY, oz = t / (OX * OY);
+        // the two dx taps of a (dy, dz) pair are neighbours in the table (x fastest, 2 ox even, nvox even): one 8-byte read for both
 #pragma unroll
-        for (int tap = 0; tap < 8; ++tap) {
-            const int dx = tap >> 2, dy = (tap >> 1) & 1, dz = tap & 1;
-            const int64_t vox = ((int64_t)(2 * oz + dz) * a.Y + (2 * oy + dy)) * a.X + (2 * ox + dx);
-            int seen = 0;
-            for (int sl = 0; sl < a.nslots; ++sl) seen |= a.tab[sl * a.nvox + vox] >= 0;
-            m |= seen << tap;
+        for (int yz = 0; yz < 4; ++yz) {
+            const int dy = yz >> 1, dz = yz & 1;
+            const int64_t vox = ((int64_t)(2 * oz + dz) * a.Y + (2 * oy + dy)) * a.X + 2 * ox;
+            int seen0 = 0, seen1 = 0;
+            for (int sl = 0; sl < a.nslots; ++sl) {
+                const int2 p = *reinterpret_cast<const int2 *>(a.tab + sl * a.nvox + vox);
+                seen0 |= p.x >= 0;
+                seen1 |= p.y >= 0;
+            }
+            m |= (seen0 << (dy * 2 + dz)) | (seen1 << (4 + dy * 2 + dz));      // tap = (dx * 2 + dy) * 2 + dz
         }
         a.mask[t] = (uint8_t)m;
     }
