@@ -368,8 +368,8 @@ int launch_bn(BnArgs &a, hipStream_t st)
     auto kern = bottleneck16_kernel<BX, BY, BZ, PL, CIO, C2>;
     // once per instantiation (function-local static), never per launch: a launch that re-sets the attribute while replays of a
     // captured graph containing the same kernel are being enqueued touches state the graph launch reads
-    static const hipError_t lds_ok = lds > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
-    if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
+    static Sis3dLdsOnce lds_once;                                   // per instantiation; granted once per device
+    if (lds > 64 * 1024 && sis3d_grant_lds(lds_once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
     return sis3d_check_launch();
 }

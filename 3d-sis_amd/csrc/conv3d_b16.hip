@@ -392,8 +392,8 @@ int launch_b16(B16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     static_assert(lds <= 160 * 1024, "LDS brick too large");
     a.nbx = cdiv(a.X, BX); a.nby = cdiv(a.Y, BY); a.nbz = cdiv(a.Z, BZ);
     auto kern = conv3d_k3b16_kernel<BX, BY, BZ, NTC, CLIP>;
-    static const hipError_t lds_ok = lds > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;     // once, not per launch
-    if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
+    static Sis3dLdsOnce lds_once;                                   // once per device, not per launch
+    if (lds > 64 * 1024 && sis3d_grant_lds(lds_once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     const int64_t nwg = ragged_blocks > 0 ? ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * ((a.ntiles + NTC - 1) / NTC);
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(256), lds, st, a);

@@ -383,8 +383,8 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     auto kern = conv3d_k3t16_kernel<BX, BY, BZ, G, RB, CLIP>;
     // once per instantiation (function-local static), never per launch: a launch that re-sets the attribute while replays of a
     // captured graph containing the same kernel are being enqueued touches state the graph launch reads
-    static const hipError_t lds_ok = lds > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
-    if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
+    static Sis3dLdsOnce lds_once;                                   // per instantiation; granted once per device
+    if (lds > 64 * 1024 && sis3d_grant_lds(lds_once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     const int64_t nwg = ragged_blocks > 0 ? ragged_blocks : (int64_t)a.nbx * a.nby * a.nbz * a.ntiles;
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(256), lds, st, a);

@@ -663,11 +663,9 @@ static int launch_wino(WinoArgs &a, int nc, int64_t nwg, int nprob, hipStream_t 
     if (nwg <= 0 || nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     const size_t lds = (size_t)lds_floats(nc) * sizeof(float);
     // once per instantiation, never per launch (see the note in conv3d_t16.hip)
-    static const hipError_t attr2 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)(lds_floats(2) * sizeof(float)));
-    static const hipError_t attr1 = hipFuncSetAttribute((const void *)conv3d_k3wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)(lds_floats(1) * sizeof(float)));
-    if (attr1 != hipSuccess || attr2 != hipSuccess) return SIS3D_ELAUNCH;
+    static Sis3dLdsOnce once2, once1;                               // once per instantiation AND device
+    if (sis3d_grant_lds(nc == 2 ? once2 : once1, nc == 2 ? (const void *)conv3d_k3wino_kernel<2> : (const void *)conv3d_k3wino_kernel<1>,
+                        (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     if (nc == 2) hipLaunchKernelGGL(conv3d_k3wino_kernel<2>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
     else hipLaunchKernelGGL(conv3d_k3wino_kernel<1>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
     return sis3d_check_launch();

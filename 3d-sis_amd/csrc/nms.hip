@@ -449,8 +449,8 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
         int rc = sis3d_check_launch();
         if (rc) return rc;
         // granted once, at the largest size any launch may ask for (never lowered by a later, smaller launch)
-        static const hipError_t lds_ok = sis3d_allow_max_lds((const void *)nms_resolve_kernel);
-        if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
+        static Sis3dLdsOnce lds_once;
+        if (sis3d_grant_lds(lds_once, (const void *)nms_resolve_kernel, 0) != SIS3D_OK) return SIS3D_ELAUNCH;
         hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), lds, st, mask, nz, nzw, n, nullptr, max_keep, keep, num_keep);
         return sis3d_check_launch();
     }
@@ -472,10 +472,10 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     if (need() > LDS_LIMIT) return SIS3D_EUNSUPPORTED;
     const size_t lds = need();
     auto kern = nms_sweep_kernel<SELECT>;
-    // once per instantiation (one process drives one GPU): not per launch, so that no attribute write can coincide with the
-    // enqueue of a captured graph that contains this kernel
-    static const hipError_t lds_ok = sis3d_allow_max_lds((const void *)kern);
-    if (lds_ok != hipSuccess) return SIS3D_ELAUNCH;
+    // once per instantiation and device: not per launch, so that no attribute write can coincide with the enqueue of a captured
+    // graph that contains this kernel
+    static Sis3dLdsOnce lds_once;
+    if (sis3d_grant_lds(lds_once, (const void *)kern, 0) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, mask, n, max_keep, keep, num_keep, boxes, level_all, scores_sorted, order,
                        rois, roi_scores, roi_levels, stage_mask, stage_meta);
     return sis3d_check_launch();
@@ -547,8 +547,8 @@ extern "C" int sis3d_scene_merge(const float *blocks, int n_chunks, int k_rows, 
     int rc = sis3d_check_launch();
     if (rc) return rc;
     const size_t sort_lds = (size_t)((T + 255) & ~255) * 8;
-    static const hipError_t rank_lds_ok = sis3d_allow_max_lds((const void *)scene_rank_kernel);     // once
-    if (rank_lds_ok != hipSuccess) return SIS3D_ELAUNCH;
+    static Sis3dLdsOnce rank_lds_once;                               // once per device
+    if (sis3d_grant_lds(rank_lds_once, (const void *)scene_rank_kernel, 0) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(scene_rank_kernel, dim3((T + 63) / 64), dim3(1024), sort_lds, st, blocks, mask, counts, k_rows, width, recs, order);
     rc = sis3d_check_launch();
     if (rc) return rc;

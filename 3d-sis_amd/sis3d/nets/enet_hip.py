@@ -96,11 +96,18 @@ class HipEncoder(object):
         return {"init": init, "blocks": [_plan_block(m) for m in e[4:]]}
 
     def __call__(self, images):
-        key = self._version()
-        if key != self._key:
-            self._plan, self._key = self._build(), key
         if not images.is_cuda:
             raise _lib.Sis3dError("enet_hip: images must be on the GPU (the product has no CPU path)")
+        # the folded weights reach the kernels as raw pointers: every parameter / buffer of the module tree must live on the images'
+        # device, or the launch would dereference host (or another GPU's) memory -- a Python error here, not a GPU fault there
+        for m in self.entries:
+            for q in list(m.parameters()) + list(m.buffers()):
+                if q.device != images.device:
+                    raise _lib.Sis3dError("enet_hip: encoder weights are on %s but the images on %s (call net.cuda() first)"
+                                          % (q.device, images.device))
+        key = (self._version(), images.device)
+        if key != self._key:
+            self._plan, self._key = self._build(), key
         L = lib()
         st = _stream()
         x = images.float().contiguous()

@@ -10,7 +10,6 @@ _roi_pool_layer, .cpu().numpy() in the mask branch -- SURVEY.md 3.1).
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..config import anchor_sizes, cfg as _default_cfg
@@ -124,7 +123,10 @@ class Network(nn.Module):
             # network.py:307-316 with USE_IMAGES: every box's crop of the scene AND of the back-projected volume
             vol = self._imageft
             if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
-                return [self.mask_backbone.forward_batched(self._scene, windows, vol)]      # r3: one launch per layer for ALL boxes
+                try:
+                    return [self.mask_backbone.forward_batched(self._scene, windows, vol)]  # r3: one launch per layer for ALL boxes
+                except ops.Sis3dUnsupported:
+                    pass                        # a layer without a ragged instantiation: the per-box launches below still serve it
             return [[self.mask_backbone(self._scene, vol, window=w) for w in windows]]
         if self.batch_masks and hasattr(self.mask_backbone, "forward_batched"):
             return [self.mask_backbone.forward_batched(self._scene, windows)]   # one launch per layer for ALL boxes
@@ -287,6 +289,8 @@ class Network(nn.Module):
         self.batch_size = 1
         self._mode = "TEST"
         dev = torch.device("cuda", torch.cuda.current_device())
+        if any(q.device != dev for q in self.parameters()):
+            self.cuda()                                    # network.py:75: the reference's forward moves the module itself
         with torch.no_grad():
             self.eval()
             scene = blobs["data"].to(dev, non_blocking=True).float()

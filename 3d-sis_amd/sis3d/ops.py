@@ -508,6 +508,26 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
 WINOGRAD = bool(int(_os.environ.get("SIS3D_WINOGRAD", "1") or 0))
 
 
+# bench.py's accounting hook: while a dict is installed, every launch of the Winograd kernel adds the ALGORITHMIC (direct-convolution)
+# FLOP count of the problems it serves, so that the bench can price a stage on the FLOPs the matrix pipe really executes
+# (algorithmic - saved, saved = wino_algorithmic * (1 - 64/216)) whatever the dispatch rule currently sends to that kernel
+FLOP_TALLY = None
+
+
+def flop_tally(on):
+    """start (True -> returns the fresh dict) / stop (False -> returns the filled dict) the Winograd FLOP accounting"""
+    global FLOP_TALLY
+    old = FLOP_TALLY
+    FLOP_TALLY = {"wino_algorithmic_flops": 0.0, "wino_launches": 0} if on else None
+    return FLOP_TALLY if on else old
+
+
+def _tally_wino(flops):
+    if FLOP_TALLY is not None:
+        FLOP_TALLY["wino_algorithmic_flops"] += float(flops)
+        FLOP_TALLY["wino_launches"] += 1
+
+
 def set_winograd(on):
     """Algorithm switch for the k3 / pad-1 convs that run on conv3d_k3t16: True (default) = layers the Winograd kernel is expected
     to win on (sis3d_conv3d_k3wino_prefer: the two rpn_net_level* convs, 58 % of the network's FLOPs) take Winograd
@@ -522,6 +542,9 @@ def packed_wino(pc):
     if getattr(pc, "_packed_wino", None) is None:
         if getattr(pc, "_w", None) is None:
             raise Sis3dUnsupported("winograd conv: no fp32 weight kept for this layer")
+        if torch.cuda.is_current_stream_capturing():
+            # the pack is a kernel + an allocation: inside a capture it would be replayed with the graph and live in the graph's pool
+            raise _lib.Sis3dError("winograd conv: first use of this layer inside a graph capture; run one eager pass (warm-up) first")
         n = lib().sis3d_conv_k3wino_packed_floats(pc.cout, pc.cin)
         if n == 0:
             raise Sis3dUnsupported("winograd conv: cin % 8 != 0")
@@ -556,6 +579,7 @@ def conv3d_k3wino(xs, pcs, relu=True, outs=None, out_coff=0):
     if rc == -4:
         raise Sis3dUnsupported("conv3d_k3wino: unsupported shape")
     check(rc, "sis3d_conv3d_k3wino")
+    _tally_wino(2.0 * n * X * Y * Z * p0.cin * p0.cout * 27)
     return outs
 
 
@@ -884,6 +908,9 @@ def set_sparse_projection(on):
     SPARSE_PROJECTION = bool(on)
 
 
+_SPARSE_WS = {}
+
+
 def _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main):
     """-> (main, [stage out]) or None when the shape is not the colour stem's (the dense kernel serves it then)"""
     if pc.cin != 128 or pc.cout != 64 or pc.packed_pw16 is None or len(stages) > 1 or any(d % 2 for d in x.dims):
@@ -897,10 +924,21 @@ def _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main):
             return None
     X, Y, Z = x.dims
     od = (X // 2, Y // 2, Z // 2)
+    # the C entry's own limits (csrc/proj_sparse.hip: MAXSL view slots, row index in 24 bits), checked BEFORE anything is allocated
+    if x.nslots > 6 or od[0] * od[1] * od[2] >= (1 << 24):
+        return None
     main = new_act(pc.cout, od, x.device)
     so = new_act(spc.cout, od, x.device) if spc is not None else None
-    wsb = lib().sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(X, Y, Z)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    # eager launches share one workspace per (grid, device, stream) -- launches on a stream are ordered; a capture gets its own from
+    # the graph's pool, because graphs captured on one stream may replay concurrently on several
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (X, Y, Z, x.device, _stream())
+    ws = None if capturing else _SPARSE_WS.get(key)
+    if ws is None:
+        ws = torch.empty(lib().sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(X, Y, Z), dtype=torch.uint8, device=x.device)
+        if not capturing:
+            _SPARSE_WS[key] = ws
+    wsb = ws.numel()
     rc = lib().sis3d_conv3d_k2s2_projected_sparse(_ptr(x.table), _ptr(x.rows), x.nslots, x.npix, X, Y, Z, pc.cin, _ptr(pc.packed_pw16),
                                                   _ptr(pc.bias), pc.cout, 1 if relu else 0, _ptr(main), _ptr(spc.packed_pw16) if spc else None,
                                                   _ptr(spc.bias) if spc else None, spc.cout if spc else 0, _ptr(so), _ptr(ws), wsb, _stream())
@@ -1236,6 +1274,7 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
         elif WINOGRAD and plan.wino and getattr(pc, "_w", None) is not None:
             check(lib().sis3d_conv3d_k3wino_ragged(_ptr(src), C, C, _ptr(packed_wino(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                    _ptr(plan.g3w), n, plan.blocks_wino, _stream()), "sis3d_conv3d_k3wino_ragged")
+            _tally_wino(2.0 * plan.voxels * C * C * 27)
         elif plan.t16 and pc.packed_t16 is not None:
             check(lib().sis3d_conv3d_k3t16_ragged(_ptr(src), C, C, _ptr(pc.packed_t16), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                   _ptr(plan.g3t), n, plan.blocks_t16, plan.brick_t16, _stream()), "sis3d_conv3d_k3t16_ragged")

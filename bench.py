@@ -268,7 +268,30 @@ def time_dominant_kernel(net, iters=50):
     return sorted(means)[len(means) // 2]
 
 
-def time_stages(net, reps=60):
+def executed_flops(algorithmic, wino_algorithmic):
+    """FLOPs the matrix pipe executes: layers on the Winograd kernel issue 64 products per 2x2x2 output block instead of 216"""
+    return algorithmic - wino_algorithmic * (1.0 - 1.0 / WINOGRAD_REDUCTION)
+
+
+def wino_accounting(net):
+    """ALGORITHMIC FLOPs of the launches that take the Winograd kernel, in the backbone proper and in backbone + RPN of one chunk:
+    one eager pass of each with ops.flop_tally on (whatever the dispatch rule sends there today is what gets counted)."""
+    import torch
+    from sis3d import ops, synthetic
+    scene = synthetic.synth_chunk(0).cuda().float()
+    out = {}
+    with torch.no_grad():
+        for name, fn in (("backbone", net.backbone_only), ("backbone_rpn", net.backbone_rpn)):
+            ops.flop_tally(True)
+            try:
+                fn(scene)
+            finally:
+                out[name] = ops.flop_tally(False)["wino_algorithmic_flops"]
+    torch.cuda.synchronize()
+    return out
+
+
+def time_stages(net, wino, reps=60):
     """ONE chunk alone on the GPU: captured graph of the backbone proper and of backbone+RPN, `reps` back-to-back replays
     on one stream bracketed by HIP events -> ms per chunk.  The difference is the RPN (convs + heads + softmax)."""
     import torch
@@ -293,53 +316,81 @@ def time_stages(net, reps=60):
         del eng
     b, full = out["backbone"], out["rpn"]
     r = max(full - b, 1e-6)
+    wb, wf = wino["backbone"], wino["backbone_rpn"]
 
-    def frac(ms, algo):
-        return {"ms": ms, "fp32_frac": algo["flops"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+    def frac(ms, algo, wino_flops):
+        ex = executed_flops(algo["flops"], wino_flops)
+        return {"ms": ms, "fp32_frac": ex / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                "executed_gflop": ex / 1e9, "algorithmic_tflops": algo["flops"] / (ms * 1e-3) / 1e12,
                 "hbm_frac": algo["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "voxels_per_s": VOXELS / (ms * 1e-3)}
-    return {"backbone": dict(frac(b, BACKBONE), algo_gflop=BACKBONE["flops"] / 1e9, algo_mb=BACKBONE["bytes"] / 1e6),
-            "rpn": dict(frac(r, RPN), algo_gflop=RPN["flops"] / 1e9, algo_mb=RPN["bytes"] / 1e6),
-            "backbone_rpn": frac(full, ALGO["backbone_rpn"]),
+    return {"backbone": dict(frac(b, BACKBONE, wb), algo_gflop=BACKBONE["flops"] / 1e9, algo_mb=BACKBONE["bytes"] / 1e6),
+            "rpn": dict(frac(r, RPN, wf - wb), algo_gflop=RPN["flops"] / 1e9, algo_mb=RPN["bytes"] / 1e6),
+            "backbone_rpn": frac(full, ALGO["backbone_rpn"], wf),
             "how": "one chunk alone: captured graph, %d back-to-back replays on one stream, HIP events; rpn = backbone_rpn - backbone; "
-                   "binding roof is fp32 MFMA (157.3 TF), hbm_frac is against 8 TB/s with the algorithmic bytes" % reps}
+                   "fp32_frac = EXECUTED MFMA FLOPs / time / 157.3 TF (layers on the Winograd kernel issue their algorithmic count / "
+                   "3.375: executed_gflop; counted per launch by ops.flop_tally in one eager pass), algorithmic_tflops = the "
+                   "direct-convolution count / time (not a fraction of the roof); hbm_frac is against 8 TB/s with the algorithmic "
+                   "bytes; the binding roof is fp32 MFMA" % reps}
+
+
+PMC_FILES = {True: ("r02_pmc_rpn_net.json", "r01_pmc_rpn_net.json"),
+             False: ("r04_pmc_rpn_net_winograd.json", "r03_pmc_rpn_net_winograd.json")}
+DOMINANT_BYTES = (6912 * 128 + 6912 * 256 + 256 * 128 * 27) * 4.0      # in + out + weights once: 14.16 MB per launch
 
 
 def pmc_traffic(direct=False):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, KB -> B).  Counters cannot be read from inside the bench."""
-    for name in (("r02_pmc_rpn_net.json", "r01_pmc_rpn_net.json") if direct else ("r03_pmc_rpn_net_winograd.json",)):
+    """(HBM bytes per launch of the dominant kernel, file it comes from): the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, KB -> B).  Counters cannot be read from inside the bench: the figure belongs to the round and the
+    kernel revision the file names, NOT to this run."""
+    for name in PMC_FILES[bool(direct)]:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["traffic_bytes_per_launch"]
+                return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def roofline_entry(kt, kt_direct, winograd):
-    """`achieved` follows the contract: ALGORITHMIC FLOPs (the direct-convolution count of SURVEY 8d, 12.23 GFLOP) / measured launch
-    time.  With the Winograd kernel the matrix pipe EXECUTES 3.375x fewer FLOPs than that, so the algorithmic rate can exceed the
-    157.3 TF peak: `executed` prices the kernel itself (issued MFMA FLOPs / time / peak = how well the pipe is used)."""
-    if not winograd:
-        return {"bound": "mfma", "kernel": "rpn_net k3 128->256 conv, direct implicit GEMM (exact fp32 MFMA, csrc/conv3d_t16.hip)",
-                "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": DOMINANT_FLOPS / kt / 1e12 / FP32_PEAK_TF, "traffic": pmc_traffic(direct=True), "launch_us": kt * 1e6}
-    ex = DOMINANT_FLOPS / WINOGRAD_REDUCTION
-    e = {"bound": "mfma", "kernel": "rpn_net k3 128->256 conv, Winograd F(2x2x2,3x3x3) in exact fp32 (binary32 adds + fp32 MFMA, "
-                                    "csrc/conv3d_wino.hip)",
-         "achieved": DOMINANT_FLOPS / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
-         "frac": DOMINANT_FLOPS / kt / 1e12 / FP32_PEAK_TF, "traffic": pmc_traffic(), "launch_us": kt * 1e6,
-         "algorithmic_gflop": DOMINANT_FLOPS / 1e9,
-         "executed": {"gflop": ex / 1e9, "achieved": ex / kt / 1e12, "frac": ex / kt / 1e12 / FP32_PEAK_TF,
-                      "what": "MFMA FLOPs the kernel issues (algorithmic / 3.375): the fraction of the fp32 matrix pipe it keeps busy"},
-         "note": "frac = algorithmic (direct-convolution) FLOPs / time / peak, per the bench contract; it may exceed 1 because the "
-                 "algorithm needs 3.375x fewer multiplications than the count it is priced on -- executed.frac is the kernel-quality figure"}
-    if kt_direct > 0:
+    """Dominant kernel against the fp32 MFMA roof.  `frac` / `achieved` / `flops_per_launch` are the FLOPs the matrix pipe EXECUTES
+    (what a roofline fraction means: <= 1 by construction).  The Winograd kernel issues 3.375x fewer multiplications than the
+    direct-convolution count of SURVEY 8d (12.23 GFLOP); that count and the rate it gives are flat sibling keys
+    (`algorithmic_*`), never a fraction."""
+    tb, tsrc = pmc_traffic(direct=not winograd)
+    red = WINOGRAD_REDUCTION if winograd else 1.0
+    ex = DOMINANT_FLOPS / red
+    e = {"bound": "mfma",
+         "kernel": ("rpn_net k3 128->256 conv, Winograd F(2x2x2,3x3x3) in exact fp32 (binary32 adds + fp32 MFMA, csrc/conv3d_wino.hip)"
+                    if winograd else "rpn_net k3 128->256 conv, direct implicit GEMM (exact fp32 MFMA, csrc/conv3d_t16.hip)"),
+         "achieved": ex / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ex / kt / 1e12 / FP32_PEAK_TF,
+         "launch_us": kt * 1e6, "flops_per_launch": ex,
+         "flops_are": "executed MFMA FLOPs (v_mfma_f32_16x16x4_f32 count x 512)",
+         "algorithmic_gflop_per_launch": DOMINANT_FLOPS / 1e9, "algorithmic_tflops": DOMINANT_FLOPS / kt / 1e12,
+         "algorithmic_speedup_vs_direct_count": red,
+         "traffic": tb, "traffic_source": tsrc, "algorithmic_bytes_per_launch": DOMINANT_BYTES,
+         "traffic_ratio": (tb / DOMINANT_BYTES) if tb else None}
+    if winograd and kt_direct > 0:
+        db, dsrc = pmc_traffic(direct=True)
         e["direct_kernel"] = {"launch_us": kt_direct * 1e6, "achieved": DOMINANT_FLOPS / kt_direct / 1e12,
-                              "frac": DOMINANT_FLOPS / kt_direct / 1e12 / FP32_PEAK_TF, "traffic": pmc_traffic(direct=True),
+                              "frac": DOMINANT_FLOPS / kt_direct / 1e12 / FP32_PEAK_TF, "traffic": db, "traffic_source": dsrc,
                               "what": "the same layer on the direct fp32 MFMA kernel (ops.set_winograd(False)), same run"}
     return e
+
+
+def fracs_above_one(obj, path=""):
+    """every key whose name contains 'frac' must be a fraction of a roof: -> list of (path, value) above 1 (tests assert it is empty)"""
+    bad = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            q = path + "." + k if path else k
+            if "frac" in k and isinstance(v, (int, float)) and v > 1.0:
+                bad.append((q, v))
+            bad += fracs_above_one(v, q)
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            bad += fracs_above_one(v, "%s[%d]" % (path, i))
+    return bad
 
 
 def cpu_model():
@@ -549,9 +600,17 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
                 ev1.record()
                 torch.cuda.synchronize()
             mh_ms = ev0.elapsed_time(ev1) / 50
+            ops_mod().flop_tally(True)
+            try:
+                with torch.no_grad():
+                    net.mask_backbone.forward_planned(e0.scenes[0], e0.mask_plan)
+            finally:
+                mw = ops_mod().flop_tally(False)["wino_algorithmic_flops"]
+            torch.cuda.synchronize()
             extra["mask_head_ms"] = mh_ms
-            extra["mask_head_tf"] = e0.mask_plan.flops / (mh_ms * 1e-3) / 1e12
-            extra["mask_head_fp32_frac"] = extra["mask_head_tf"] / FP32_PEAK_TF
+            extra["mask_head_algorithmic_tflops"] = e0.mask_plan.flops / (mh_ms * 1e-3) / 1e12
+            extra["mask_head_executed_gflop"] = executed_flops(e0.mask_plan.flops, mw) / 1e9
+            extra["mask_head_fp32_frac"] = executed_flops(e0.mask_plan.flops, mw) / (mh_ms * 1e-3) / 1e12 / FP32_PEAK_TF
             extra["mask_head_kernel"] = ("Winograd ragged launch for the four 64->64 k3 layers (%d work items)" % e0.mask_plan.blocks_wino
                                          if (ops_mod().WINOGRAD and e0.mask_plan.wino) else "direct balanced kernel, ragged")
     snap = None
@@ -689,8 +748,9 @@ def main(argv=None):
         return sc
 
     stages = None
+    wino = wino_accounting(net) if rank == 0 and workload != "images" else None
     if rank == 0 and world == 1 and workload == "backbone_rpn" and not args.no_stages and not args.no_graph:
-        stages = time_stages(net)
+        stages = time_stages(net, wino)
     side = {}
     scene_steps = args.scene_steps or max(1, min(args.steps, 20))
     cp = sc = None
@@ -749,7 +809,7 @@ def main(argv=None):
                     r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
                     r2["steps"] = args.steps
                     if stages is not None:
-                        st2 = time_stages(net)
+                        st2 = time_stages(net, {"backbone": 0.0, "backbone_rpn": 0.0})
             finally:
                 ops.set_split_bf16(False)
             diffs = {}
@@ -798,7 +858,11 @@ def main(argv=None):
             "roofline": roofline_entry(kt, kt_direct, ops.WINOGRAD),
             "step_roofline": {"hbm_frac": algo["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "hbm_gbs_algorithmic": algo["bytes"] / (ms * 1e-3) / 1e9,
-                              "fp32_frac": algo["flops"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                              **({"fp32_frac": executed_flops(algo["flops"], wino["backbone_rpn"] * nchunk_step) / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                                  "executed_gflop_per_step": executed_flops(algo["flops"], wino["backbone_rpn"] * nchunk_step) / 1e9,
+                                  "fp32_frac_is": "executed MFMA FLOPs of backbone + RPN (Winograd layers: algorithmic / 3.375) / time / 157.3 TF"}
+                                 if wino is not None else {}),
+                              "algorithmic_tflops": algo["flops"] / (ms * 1e-3) / 1e12,
                               "binding": "fp32 FLOPs (AI 163 FLOP/B >> 20 FLOP/B machine balance)"},
         }
         line.update(side)
@@ -810,6 +874,9 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        bad = fracs_above_one(line)
+        if bad:
+            line["frac_errors"] = ["%s = %.3f is not a fraction of a roof" % b for b in bad]
         emit(line)
     return 0
 

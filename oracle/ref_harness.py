@@ -32,15 +32,68 @@ import types
 import numpy as np
 import torch
 
-REF_ROOT = os.environ.get("SIS3D_REFERENCE", "/root/reference")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REF_SO = os.path.join(_HERE, "_ref", "libref_roi_pooling.so")
+_REF_TGZ = os.path.join(_HERE, "_ref", "reference_tree.tgz")     # built by `make -C oracle tree`; git-ignored, travels to the GPU box
+
+
+def _resolve_root():
+    """Where the reference lives: $SIS3D_REFERENCE, else /root/reference (the build container), else the staged archive
+    oracle/_ref/reference_tree.tgz unpacked into a per-archive temp dir (the GPU box: /root/reference does not exist there).
+    The archive is a build output of oracle/Makefile taken from the reference where it lies -- it is never unpacked into the
+    repo, never committed and never imported by the product."""
+    env = os.environ.get("SIS3D_REFERENCE")
+    if env:
+        return env, "env"
+    if os.path.isdir("/root/reference/lib/nets"):
+        return "/root/reference", "in place"
+    if os.path.isfile(_REF_TGZ):
+        import hashlib
+        import tarfile
+        import tempfile
+        with open(_REF_TGZ, "rb") as f:
+            tag = hashlib.sha256(f.read()).hexdigest()[:16]
+        root = os.path.join(tempfile.gettempdir(), "sis3d_reference_" + tag)
+        if not os.path.isdir(os.path.join(root, "lib", "nets")):
+            tmp = root + ".%d.part" % os.getpid()
+            with tarfile.open(_REF_TGZ) as t:
+                t.extractall(tmp)
+            try:
+                os.rename(tmp, root)
+            except OSError:                                    # another process won the race
+                import shutil
+                shutil.rmtree(tmp, ignore_errors=True)
+        return root, "staged archive"
+    return "/root/reference", "absent"
+
+
+REF_ROOT, REF_SOURCE = _resolve_root()
 
 _installed = False
+_cuda_originals = None
 
 
 def available():
     return os.path.isdir(os.path.join(REF_ROOT, "lib", "nets"))
+
+
+def neutralise_cuda():
+    """`.cuda()` -> identity so the reference's forward (network.py:75,191) runs on CPU: the README's MAX_VOLUME=0 path in full."""
+    global _cuda_originals
+    if _cuda_originals is None:
+        _cuda_originals = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.empty_cache, torch.cuda.synchronize)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        torch.cuda.empty_cache = lambda: None
+        torch.cuda.synchronize = lambda *a, **k: None
+
+
+def restore_cuda():
+    """undo neutralise_cuda(): the GPU test that runs the reference's caller over the HIP drop-in needs the real `.cuda()`"""
+    global _cuda_originals
+    if _cuda_originals is not None:
+        torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.empty_cache, torch.cuda.synchronize = _cuda_originals
+        _cuda_originals = None
 
 
 class _EasyDict(dict):
@@ -129,8 +182,10 @@ class RefRoIPoolCallable:
         return ref_roi_pool_c().forward(*self.a, features, rois)
 
 
-def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=False):
-    """Import the reference with stubs; returns the module namespace we need."""
+def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=False, on_cpu=True):
+    """Import the reference with stubs; returns the module namespace we need.
+    on_cpu=True (the oracle's use): `.cuda()` is neutralised so the reference's own forward runs on CPU.
+    on_cpu=False (tests/test_gpu_reference_caller.py): the real `.cuda()` stays -- the reference's caller drives the HIP drop-in."""
     global _installed
     if not available():
         raise RuntimeError("reference not available at %s" % REF_ROOT)
@@ -156,12 +211,12 @@ def install(cfg_file="experiments/cfgs/ScanNet/benchmark.yml", with_trainval=Fal
         # the two cffi extension packages (prebuilt cpython-36/sm_61 .so files are unusable)
         _stub("lib.layer_utils.roi_pooling._ext", roi_pooling=None).__path__ = []
         _stub("lib.layer_utils.nms._ext", nms=None).__path__ = []
-        # neutralise .cuda(): the reference forward calls it unconditionally
-        torch.Tensor.cuda = lambda self, *a, **k: self
-        torch.nn.Module.cuda = lambda self, *a, **k: self
-        torch.cuda.empty_cache = lambda: None
-        torch.cuda.synchronize = lambda *a, **k: None
         _installed = True
+    # neutralise .cuda(): the reference forward calls it unconditionally
+    if on_cpu:
+        neutralise_cuda()
+    else:
+        restore_cuda()
 
     if with_trainval and "reprint" not in sys.modules:
         # import-time dependencies of lib/model/trainval.py that are not installable offline

@@ -82,3 +82,21 @@ def test_launch_command_is_one_rank_per_gpu_on_loopback():
     # defaults: N = 1, `auto` = config[1] as the headline at every N with the 32-chunk overlapping scene as a side key
     a = bench.parse([])
     assert a.gpus == 1 and a.workload == "auto" and a.scene_chunks == 32 and a.scene_stride == 80.0
+
+
+def test_roofline_fractions_are_fractions():
+    """VERDICT r3 / ADVICE r3: every `*frac*` key of the bench line is executed work over a roof (<= 1); the direct-convolution
+    pricing of a Winograd launch lives in flat `algorithmic_*` siblings the driver's `parsed` record keeps."""
+    sys.path.insert(0, ROOT)
+    import bench
+    e = bench.roofline_entry(50.5e-6, 95.5e-6, True)              # round-3 timings of the dominant kernel
+    assert abs(e["frac"] - 0.456) < 2e-3 and abs(e["achieved"] - e["frac"] * e["peak"]) < 1e-9
+    assert abs(e["flops_per_launch"] * 3.375 - 2.0 * 6912 * 256 * 128 * 27) < 1.0
+    assert abs(e["algorithmic_tflops"] - 242.19) < 0.01 and e["algorithmic_speedup_vs_direct_count"] == 3.375
+    assert e["traffic_source"].startswith("profiles/") and abs(e["traffic_ratio"] - e["traffic"] / e["algorithmic_bytes_per_launch"]) < 1e-12
+    assert not isinstance(e.get("executed"), dict)                 # nothing the headline needs is nested any more
+    assert bench.fracs_above_one(e) == []
+    d = bench.roofline_entry(95.5e-6, 0.0, False)
+    assert abs(d["frac"] - 0.814) < 2e-3 and d["algorithmic_speedup_vs_direct_count"] == 1.0 and bench.fracs_above_one(d) == []
+    assert bench.fracs_above_one({"stages": {"rpn": {"fp32_frac": 1.5}}, "x": [{"hbm_frac": 0.2}]}) == [("stages.rpn.fp32_frac", 1.5)]
+    assert abs(bench.executed_flops(42.58e9, 30.57e9) - (42.58e9 - 30.57e9 * (1 - 64 / 216))) < 1.0
