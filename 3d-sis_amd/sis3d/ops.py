@@ -932,7 +932,7 @@ def _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main):
     # eager launches share one workspace per (grid, device, stream) -- launches on a stream are ordered; a capture gets its own from
     # the graph's pool, because graphs captured on one stream may replay concurrently on several
     capturing = torch.cuda.is_current_stream_capturing()
-    key = (X, Y, Z, x.device, _stream())
+    key = (X, Y, Z, x.device, int(torch.cuda.current_stream().cuda_stream))
     ws = None if capturing else _SPARSE_WS.get(key)
     if ws is None:
         ws = torch.empty(lib().sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(X, Y, Z), dtype=torch.uint8, device=x.device)
