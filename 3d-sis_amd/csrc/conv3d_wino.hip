@@ -90,6 +90,16 @@ struct WinoArgs {
     int nbx, nby, nbz;
     const WinoRagged *rag;
     int nrag;
+    // fused Bottleneck tail (template C3 > 0; lib/nets/backbones.py:33-40, 29-31): the k3 conv is Bottleneck.conv2 and its ReLU'd tile
+    // goes through conv3 (1x1x1, C3 couts) + bias + residual + ReLU -> tout, and (C2N > 0) the NEXT block's conv1 + bias + ReLU -> out2
+    const float *w3p, *b3;     // conv3: pw16-packed weights [C3/16][cout/16][64][4], bias
+    const float *res;          // the block input (residual), channels-last rows of res_stride floats
+    int res_stride;
+    float *tout;
+    int tout_stride, tout_coff;
+    const float *w1n, *b1n;    // next conv1: pw16-packed [C2N/16][C3/16][64][4], bias
+    float *out2;
+    int out2_stride;
 };
 
 // OFF: immediate byte offset of the instruction, added to BOTH the global and the LDS address (< 4096)
@@ -268,7 +278,7 @@ struct NextV {
     }
 };
 
-template <int H, int NC>
+template <int H, int NC, int C3 = 0, int C2N = 0>
 __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp, int gX, int gY, int gZ, int nby, int nbz,
                                           int64_t in_off, int64_t out_off)
 {
@@ -515,6 +525,71 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // wave-local exchange: every lane reads what other lanes of its own wave wrote
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (C3 > 0) {
+        // ---- fused Bottleneck tail, wave-local: this wave's 64 finished voxels x (16 NC = all) conv2 channels sit in `tr` as rows
+        // [cout tile][voxel row][16]; a row IS the B operand of the transposed tile GEMM of mfma16.h (lane (voxel li, kq) reads the
+        // 16 B = channels 16 g + 4 kq .. + 3), so conv3 -> (+ bias, + residual, ReLU) -> next conv1 chains through registers exactly
+        // as in pointwise.hip's pw16_kernel, on four voxel tiles of 16.  Weights: pw16 fragment order, straight from L2 (2-8 KB).
+        static_assert(NC == 2 && C3 % 16 == 0 && C2N % 16 == 0, "the tail needs every conv2 channel in the workgroup (cout = 32 = 16 NC)");
+        constexpr int NT3 = C3 / 16, NT2 = C2N / 16, NT2A = NT2 > 0 ? NT2 : 1;
+        float4 w3[NT3][2], bb3[NT3];
+        static_for<0, NT3>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            static_for<0, 2>([&](auto G) { w3[n][decltype(G)::value] = reinterpret_cast<const float4 *>(a.w3p)[(n * 2 + decltype(G)::value) * 64 + lane]; });
+            bb3[n] = a.b3 ? *reinterpret_cast<const float4 *>(a.b3 + 16 * n + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        });
+        float4 w1n[NT2A][NT3], bb1n[NT2A];
+        if constexpr (NT2 > 0) {
+            static_for<0, NT2>([&](auto N) {
+                constexpr int n = decltype(N)::value;
+                static_for<0, NT3>([&](auto G) { w1n[n][decltype(G)::value] = reinterpret_cast<const float4 *>(a.w1n)[(n * NT3 + decltype(G)::value) * 64 + lane]; });
+                bb1n[n] = a.b1n ? *reinterpret_cast<const float4 *>(a.b1n + 16 * n + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            });
+        }
+        // all four tiles' residual rows are requested before the first GEMM (one L2 round trip for the wave)
+        float4 rres[4][NT3];
+        bool okv[4];
+        size_t vox[4];
+        static_for<0, 4>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const int row = 16 * t + j;                              // voxel row (rr, tq, o) of this lane's B-operand column
+            const int o = row & 7, tq = (row >> 3) & 3, rr = row >> 5;
+            const int tl = 4 * tq + 2 * H + rr;
+            const int x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2), y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1), z = oz0 + 2 * (tl & 3) + (o & 1);
+            okv[t] = x < gX && y < gY && z < gZ;
+            vox[t] = okv[t] ? (size_t)(x * gY + y) * gZ + z : 0;
+            const float *rp = a.res + vox[t] * a.res_stride + 4 * q4;
+            static_for<0, NT3>([&](auto N) { rres[t][decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
+        });
+        static_for<0, 4>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            float4 yv[2];
+            static_for<0, 2>([&](auto G) { yv[decltype(G)::value] = *reinterpret_cast<const float4 *>(tr + ((decltype(G)::value * 64 + 16 * t + j) * 16 + 4 * q4)); });
+            f32x4 acc3[NT3];
+            gemm_t<NT3, 2>(w3, yv, acc3);
+            float4 zv[NT3];
+            static_for<0, NT3>([&](auto N) {
+                constexpr int n = decltype(N)::value;
+                float4 v;
+                v.x = acc3[n][0] + bb3[n].x + rres[t][n].x; v.y = acc3[n][1] + bb3[n].y + rres[t][n].y;
+                v.z = acc3[n][2] + bb3[n].z + rres[t][n].z; v.w = acc3[n][3] + bb3[n].w + rres[t][n].w;
+                zv[n] = relu4(v, true);
+                if (okv[t]) *reinterpret_cast<float4 *>(a.tout + vox[t] * a.tout_stride + a.tout_coff + 16 * n + 4 * q4) = zv[n];
+            });
+            if constexpr (NT2 > 0) {
+                f32x4 acc1[NT2];
+                gemm_t<NT2, NT3>(w1n, zv, acc1);
+                static_for<0, NT2>([&](auto N) {
+                    constexpr int n = decltype(N)::value;
+                    float4 v;
+                    v.x = acc1[n][0] + bb1n[n].x; v.y = acc1[n][1] + bb1n[n].y; v.z = acc1[n][2] + bb1n[n].z; v.w = acc1[n][3] + bb1n[n].w;
+                    v = relu4(v, true);
+                    if (okv[t]) *reinterpret_cast<float4 *>(a.out2 + vox[t] * a.out2_stride + 16 * n + 4 * q4) = v;
+                });
+            }
+        });
+    }
+    if (C3 == 0 || a.out[prob] != nullptr)
     static_for<0, 4 * NC>([&](auto S) {
         constexpr int sidx = decltype(S)::value;                    // 64 NC voxel rows (cc, rr, q4, o) x 4 float4 pieces / 64 lanes
         const int piece = sidx * 64 + lane, row = piece >> 2, c4 = piece & 3;
@@ -544,7 +619,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     }
 }
 
-template <int NC>
+template <int NC, int C3 = 0, int C2N = 0>
 __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -577,8 +652,8 @@ __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a
     }
     // waves (h, g): h = xi_x half, g = tile group; each wave serves every cout tile of the group
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-    if (h == 0) wino_wave<0, NC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
-    else wino_wave<1, NC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    if (h == 0) wino_wave<0, NC, C3, C2N>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    else wino_wave<1, NC, C3, C2N>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
 }
 
 // (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:
@@ -658,17 +733,23 @@ extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout
     return nprob >= 1 && wino_nc(X, Y, Z, cin, cout) > 0 ? 1 : 0;
 }
 
+template <int NC, int C3, int C2N>
+static int launch_wino_inst(const WinoArgs &a, int64_t nwg, int nprob, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)lds_floats(NC) * sizeof(float);
+    static Sis3dLdsOnce once;                                       // once per instantiation AND device
+    auto kern = conv3d_k3wino_kernel<NC, C3, C2N>;
+    if (sis3d_grant_lds(once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
+    return sis3d_check_launch();
+}
+
 static int launch_wino(WinoArgs &a, int nc, int64_t nwg, int nprob, hipStream_t st)
 {
     if (nwg <= 0 || nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
-    const size_t lds = (size_t)lds_floats(nc) * sizeof(float);
-    // once per instantiation, never per launch (see the note in conv3d_t16.hip)
-    static Sis3dLdsOnce once2, once1;                               // once per instantiation AND device
-    if (sis3d_grant_lds(nc == 2 ? once2 : once1, nc == 2 ? (const void *)conv3d_k3wino_kernel<2> : (const void *)conv3d_k3wino_kernel<1>,
-                        (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
-    if (nc == 2) hipLaunchKernelGGL(conv3d_k3wino_kernel<2>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
-    else hipLaunchKernelGGL(conv3d_k3wino_kernel<1>, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
-    return sis3d_check_launch();
+    a.w3p = a.b3 = a.res = a.w1n = a.b1n = nullptr; a.tout = a.out2 = nullptr;
+    a.res_stride = a.tout_stride = a.tout_coff = a.out2_stride = 0;
+    return nc == 2 ? launch_wino_inst<2, 0, 0>(a, nwg, nprob, st) : launch_wino_inst<1, 0, 0>(a, nwg, nprob, st);
 }
 
 extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
@@ -722,4 +803,42 @@ extern "C" int sis3d_conv3d_k3wino_ragged(const float *in, int cin, int cin_stri
     a.nbx = a.nby = a.nbz = 1;
     a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
     return launch_wino(a, 2, total_blocks, 1, as_stream(stream));
+}
+
+// ---- Bottleneck body on the Winograd kernel (lib/nets/backbones.py:17-40): conv2 = Conv3d(planes, planes, 3, padding=1) + bias + ReLU
+// by F(2x2x2, 3x3x3), then -- on the output tile, before it leaves the CU -- conv3 (1x1x1) + bias + residual + ReLU and optionally the
+// NEXT block's conv1 + bias + ReLU.  Same contract as sis3d_bottleneck16 (the direct-convolution form of the same fusion); serves the
+// planes = 32 blocks, whose 32 conv2 channels are the two cout tiles of one workgroup.  sis3d_bottleneck_wino_prefer says where it is
+// expected to win (enough 8 x 4 x 8 blocks to fill the chip: the 48 x 24 x 48 maps of geometry1 / color).
+extern "C" int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int c3, int c2n)
+{
+    if (planes != 32 || !(c3 == 32 || c3 == 64) || !(c2n == 0 || c2n == 32)) return 0;
+    if (c3 == 64 && c2n != 0) return 0;
+    return (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ) >= 200 ? 1 : 0;
+}
+
+extern "C" int sis3d_bottleneck_wino(const float *y1, int X, int Y, int Z, int planes, const float *w2_wino, const float *b2,
+                                     const float *w3_pw16, const float *b3, int c3, const float *residual, int res_stride, float *out,
+                                     int out_stride, int out_coff, const float *w1n_pw16, const float *b1n, int c2n, float *out2,
+                                     sis3d_stream_t stream)
+{
+    if (!y1 || !w2_wino || !w3_pw16 || !residual || !out || X <= 0 || Y <= 0 || Z <= 0) return SIS3D_EINVAL;
+    if (c2n < 0 || (c2n > 0 && (!w1n_pw16 || !out2))) return SIS3D_EINVAL;
+    if (planes != 32 || res_stride < c3 || out_stride < out_coff + c3 || ((res_stride | out_stride | out_coff) & 3)) return SIS3D_EUNSUPPORTED;
+    if ((int64_t)X * Y * Z * (planes > c3 ? planes : c3) > 0x7fffffffLL) return SIS3D_EUNSUPPORTED;
+    WinoArgs a;
+    for (int p = 0; p < WN_MAXP; ++p) { a.in[p] = y1; a.wp[p] = w2_wino; a.bias[p] = b2; a.out[p] = nullptr; }
+    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = planes; a.cout = planes; a.ngroups = 1; a.nk = planes / 4;
+    a.flags = SIS3D_EPI_RELU; a.out_stride = planes; a.out_coff = 0;
+    a.nbx = cdiv(X, VX); a.nby = cdiv(Y, VY); a.nbz = cdiv(Z, VZ);
+    a.rag = nullptr; a.nrag = 0;
+    a.w3p = w3_pw16; a.b3 = b3; a.res = residual; a.res_stride = res_stride; a.tout = out; a.tout_stride = out_stride; a.tout_coff = out_coff;
+    a.w1n = w1n_pw16; a.b1n = b1n; a.out2 = out2; a.out2_stride = c2n;
+    const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz;
+    if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    const hipStream_t st = as_stream(stream);
+    if (c3 == 32 && c2n == 0) return launch_wino_inst<2, 32, 0>(a, nwg, 1, st);
+    if (c3 == 32 && c2n == 32) return launch_wino_inst<2, 32, 32>(a, nwg, 1, st);
+    if (c3 == 64 && c2n == 0) return launch_wino_inst<2, 64, 0>(a, nwg, 1, st);
+    return SIS3D_EUNSUPPORTED;
 }

@@ -98,6 +98,9 @@ SIGNATURES = {
     "sis3d_bottleneck16_brick": (c_int, [c_int, c_int, c_int, c_int]),
     "sis3d_bottleneck16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp,
                                    c_int, c_vp, c_int, c_vp]),
+    "sis3d_bottleneck_wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sis3d_bottleneck_wino": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp,
+                                      c_int, c_vp, c_vp]),
     "sis3d_conv3d_planar2_ragged": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "sis3d_maxpool3d_3x3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "sis3d_conv3d_k2s2_projected_sparse_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),

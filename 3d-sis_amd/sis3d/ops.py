@@ -631,7 +631,40 @@ def conv3d_k3b16(xs, pcs, weights=None, relu=True, outs=None, out_coff=0, brick=
     return outs
 
 
+BNECK_WINO = _os.environ.get("SIS3D_BNECK_WINO", "1") != "0"     # A/B switch: planes-32 Bottleneck bodies on the Winograd kernel (default on)
 BNECK_SPLIT = bool(_os.environ.get("SIS3D_BNECK_SPLIT"))  # A/B switch: Bottleneck body as k3t16 + pointwise launches
+
+
+def bottleneck_wino(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None):
+    """Bottleneck body in one launch of the Winograd kernel (sis3d_bottleneck_wino): conv2 by F(2x2x2, 3x3x3) in exact fp32, then on
+    the output tile relu(conv3(.) + b3 + x) -> `out` and optionally the next block's conv1.  Same arguments and results as
+    bottleneck16 (which routes here where sis3d_bottleneck_wino_prefer says so); planes = 32 only -> Sis3dUnsupported otherwise."""
+    spc = stage["pc"] if stage is not None else None
+    if getattr(pc2, "_w", None) is None or pc3.packed_pw16 is None or (spc is not None and spc.packed_pw16 is None):
+        raise Sis3dUnsupported("no Winograd / pw16 pack for this Bottleneck")
+    if not is_cl(y1) or not is_cl(residual):
+        raise _lib.Sis3dError("bottleneck_wino expects channels-last activations")
+    _, pl, X, Y, Z = y1.shape
+    od = (X, Y, Z)
+    if (pc2.cin, pc2.cout, pc2.k, pc3.cin, pc3.k) != (pl, pl, 3, pl, 1) or tuple(residual.shape[2:]) != od or residual.shape[1] != pc3.cout:
+        raise _lib.Sis3dError("bottleneck_wino: layer shapes do not form a Bottleneck")
+    if spc is not None and (spc.k != 1 or spc.cin != pc3.cout or not stage.get("relu", True)):
+        raise Sis3dUnsupported("bottleneck_wino: stage must be a k=1 conv + ReLU on the block output")
+    wp = packed_wino(pc2)
+    if out is None:
+        out, out_coff = new_act(pc3.cout, od, y1.device), 0
+    elif not is_cl(out) or tuple(out.shape[2:]) != od or out_coff + pc3.cout > out.shape[1]:
+        raise _lib.Sis3dError("bottleneck_wino: bad `out`")
+    so = new_act(spc.cout, od, y1.device) if spc is not None else None
+    rc = lib().sis3d_bottleneck_wino(_ptr(y1), X, Y, Z, pl, _ptr(wp), _ptr(pc2.bias), _ptr(pc3.packed_pw16), _ptr(pc3.bias), pc3.cout,
+                                     _ptr(residual), residual.shape[1], _ptr(out), out.shape[1], int(out_coff),
+                                     _ptr(spc.packed_pw16) if spc else None, _ptr(spc.bias) if spc else None, spc.cout if spc else 0,
+                                     _ptr(so), _stream())
+    if rc == -4:
+        raise Sis3dUnsupported("no Winograd Bottleneck instantiation for planes %d, %d channels, stage %s" % (pl, pc3.cout, spc.cout if spc else 0))
+    check(rc, "sis3d_bottleneck_wino")
+    _tally_wino(2.0 * X * Y * Z * pl * pl * 27)
+    return out, so
 
 
 def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick=-1):
@@ -653,6 +686,12 @@ def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick
         raise _lib.Sis3dError("bottleneck16: layer shapes do not form a Bottleneck")
     if spc is not None and (spc.k != 1 or spc.cin != pc3.cout or not stage.get("relu", True)):
         raise Sis3dUnsupported("bottleneck16: stage must be a k=1 conv + ReLU on the block output")
+    if WINOGRAD and BNECK_WINO and brick < 0 and lib().sis3d_bottleneck_wino_prefer(X, Y, Z, pl, pc3.cout, spc.cout if spc else 0):
+        try:
+            # r4: conv2 by Winograd F(2x2x2, 3x3x3) with the 1x1x1 tail in its epilogue: the planes = 32 blocks of the 48 x 24 x 48 maps
+            return bottleneck_wino(y1, pc2, pc3, residual, out=out, out_coff=out_coff, stage=stage)
+        except Sis3dUnsupported:
+            pass
     if lib().sis3d_bottleneck16_brick(X, Y, Z, pl) < 0 and brick < 0:
         raise Sis3dUnsupported("bottleneck16: the two-launch path serves this grid")
     if out is None:

@@ -446,6 +446,18 @@ int sis3d_bottleneck16(const float *y1, int X, int Y, int Z, int planes, const f
                        const float *b3, int cio, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
                        const float *w1n_pw16, const float *b1n, int c2, float *y1n, int brick, sis3d_stream_t stream);
 
+/* The same Bottleneck body with conv2 on the Winograd kernel (csrc/conv3d_wino.hip; F(2x2x2, 3x3x3) in exact fp32: 3.375x fewer
+ * multiplications than sis3d_bottleneck16's direct convolution, same binary32 arithmetic class) and the 1x1x1 tail on the output tile
+ * in the kernel's epilogue:  y2 = relu(conv2(y1) + b2);  out = relu(conv3(y2) + b3 + x);  y1n = relu(conv1_next(out) + b1n) (c2 > 0).
+ * Replaces the cuDNN calls behind Bottleneck.forward (lib/nets/backbones.py:27-40) for planes = 32 (the workgroup's two cout tiles
+ * are all of conv2's channels).  w2_wino: sis3d_conv_k3wino_pack_weight(32, 32); w3_pw16 / w1n_pw16: sis3d_conv_pw16_pack_weight.
+ * (planes, cio, c2) instantiated: (32,32,{0,32}) (32,64,0); others -> SIS3D_EUNSUPPORTED.  sis3d_bottleneck_wino_prefer: 1 where this
+ * launch is expected to beat sis3d_bottleneck16 (>= 200 blocks of 8 x 4 x 8 voxels: the 48 x 24 x 48 maps). */
+int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int cio, int c2);
+int sis3d_bottleneck_wino(const float *y1, int X, int Y, int Z, int planes, const float *w2_wino, const float *b2, const float *w3_pw16,
+                          const float *b3, int cio, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
+                          const float *w1n_pw16, const float *b1n, int c2, float *y1n, sis3d_stream_t stream);
+
 /* nn.MaxPool3d(3,1,1) (backbones.py:206,210,220), channels-last, -inf padding.  The C output channels land at
  * [out_coff, out_coff + C) of rows of out_stride floats (out_stride = C, out_coff = 0: a plain tensor; otherwise a channel
  * range of a wider tensor = the torch.cat of backbones.py:109 done in place). */

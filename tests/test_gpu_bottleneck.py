@@ -49,7 +49,8 @@ SHAPES = [(32, 32, 32, (48, 24, 48)), (32, 32, 0, (48, 24, 48)), (32, 128, 32, (
 
 
 @pytest.mark.parametrize("planes,cio,c2,dims", SHAPES)
-def test_network_shapes_vs_torch_cpu_and_two_launch_path(ops, planes, cio, c2, dims):
+def test_network_shapes_vs_torch_cpu_and_two_launch_path(ops, planes, cio, c2, dims, monkeypatch):
+    monkeypatch.setattr(ops, "BNECK_WINO", False)                 # the direct-convolution body (the Winograd body: tests below)
     x, y1, pc2, pc3, stage, want, wantn = _case(ops, planes, cio, c2, dims, planes + cio + c2 + dims[0])
     out, y1n = ops.bottleneck16(cl(y1), pc2, pc3, cl(x), stage=stage)
     assert ops.is_cl(out) and out.shape == want.shape
@@ -100,3 +101,59 @@ def test_fused_sequential_uses_it_and_matches_split(ops, monkeypatch):
         monkeypatch.setattr(ops, "BNECK_SPLIT", True)
         split = seq(x)
     assert (fused - split).abs().max().item() <= 1e-5
+
+
+# ---- r4: the same body with conv2 on the Winograd kernel and the 1x1x1 tail in its epilogue (sis3d_bottleneck_wino)
+WINO_SHAPES = [(32, 32, 32, (48, 24, 48)), (32, 32, 0, (48, 24, 48)), (32, 64, 0, (48, 24, 48))]
+
+
+@pytest.mark.parametrize("planes,cio,c2,dims", WINO_SHAPES)
+def test_winograd_body_network_shapes(ops, planes, cio, c2, dims):
+    """vs torch-CPU (oneDNN fp32, tolerance 1e-4 = north_star), vs a float64 evaluation of the same block (2e-5 of the output scale:
+    the bound test_gpu_conv_wino.py holds the kernel to) and vs the direct-convolution body; and it IS what bottleneck16 dispatches
+    to on these grids."""
+    x, y1, pc2, pc3, stage, want, wantn = _case(ops, planes, cio, c2, dims, 11 + planes + cio + c2)
+    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, planes, cio, c2) == 1
+    out, y1n = ops.bottleneck_wino(cl(y1), pc2, pc3, cl(x), stage=stage)
+    assert ops.is_cl(out) and out.shape == want.shape
+    assert (out.cpu() - want).abs().max().item() <= TOL
+    w2, b2 = pc2._w.cpu().double(), pc2.bias.cpu().double()
+    g = torch.Generator().manual_seed(11 + planes + cio + c2)                 # re-draw the 1x1x1 weights of _case in float64
+    _ = torch.randn(1, cio, *dims, generator=g); _ = torch.randn(1, planes, *dims, generator=g)
+    w2r, w3r = _w(planes, planes, 3, g), _w(cio, planes, 1, g)
+    b2r, b3r = torch.randn(planes, generator=g) * 0.1, torch.randn(cio, generator=g) * 0.1
+    assert torch.equal(w2r.double(), w2)
+    want64 = F.relu(F.conv3d(F.relu(F.conv3d(y1.double(), w2, b2, padding=1)), w3r.double(), b3r.double()) + x.double())
+    scale = float(want64.abs().max())
+    assert (out.cpu().double() - want64).abs().max().item() <= 2e-5 * scale
+    via16, via16n = ops.bottleneck16(cl(y1), pc2, pc3, cl(x), stage=stage)   # default dispatch = this kernel
+    assert torch.equal(via16, out)
+    if c2:
+        assert (y1n.cpu() - wantn).abs().max().item() <= TOL and torch.equal(via16n, y1n)
+    else:
+        assert y1n is None and via16n is None
+
+
+@pytest.mark.parametrize("dims", [(13, 9, 11), (5, 3, 2), (16, 8, 16), (17, 4, 9)])
+@pytest.mark.parametrize("cio,c2", [(32, 32), (64, 0)])
+def test_winograd_body_partial_blocks_and_channel_range(ops, dims, cio, c2):
+    """grids that are not multiples of the 8 x 4 x 8 block (clipped tiles, zero halo), no-bias layers, output written into a channel
+    range of a wider tensor"""
+    bias = dims[0] != 5
+    x, y1, pc2, pc3, stage, want, wantn = _case(ops, 32, cio, c2, dims, 3 * dims[0] + cio, bias=bias)
+    wide = torch.full((1, cio + 96, *dims), -7.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    out, y1n = ops.bottleneck_wino(cl(y1), pc2, pc3, cl(x), out=wide, out_coff=64, stage=stage)
+    assert out is wide
+    assert (wide[:, 64:64 + cio].cpu() - want).abs().max().item() <= TOL
+    rest = torch.cat([wide[:, :64], wide[:, 64 + cio:]], 1)
+    assert float(rest.min()) == -7.0 and float(rest.max()) == -7.0
+    if c2:
+        assert (y1n.cpu() - wantn).abs().max().item() <= TOL
+
+
+def test_winograd_body_refuses_other_planes(ops):
+    x, y1, pc2, pc3, stage, want, _ = _case(ops, 64, 128, 0, (24, 12, 24), 5)
+    assert ops.lib().sis3d_bottleneck_wino_prefer(24, 12, 24, 64, 128, 0) == 0
+    with pytest.raises(ops.Sis3dUnsupported):
+        ops.bottleneck_wino(cl(y1), pc2, pc3, cl(x))
+    assert ops.lib().sis3d_bottleneck_wino_prefer(24, 12, 24, 32, 128, 32) == 0     # 27 blocks: the direct body serves the 24 x 12 x 24 maps
