@@ -64,13 +64,21 @@ constexpr int FASTCAP = 1536;                         // candidates the rank-sor
 constexpr int EPT = 40;                                // elements per thread held in registers: n <= 40960
 
 // scores [n]; out_scores [k], out_idx [k] (int64).  k <= KMAX.
+#ifdef TOPK_TIMING      // tools/topk_phases.py: 100 MHz timestamps after each phase of the fast path
+#define TOPK_TS(i) do { if (tid == 0) ts[i] = (long long)wall_clock64(); } while (0)
+#define TOPK_TS_ARG , long long *ts
+#else
+#define TOPK_TS(i) do { } while (0)
+#define TOPK_TS_ARG
+#endif
 __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict__ scores, int n, int k,
-                                                        float *__restrict__ out_scores, int64_t *__restrict__ out_idx)
+                                                        float *__restrict__ out_scores, int64_t *__restrict__ out_idx TOPK_TS_ARG)
 {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t s_prefix, s_need, s_cnt_gt, s_cnt_eq, s_bsel, s_eq_total;
     __shared__ uint64_t cand[KMAX];                    // (key << 32) | (~idx): sorting descending gives key desc, idx asc
     const int tid = threadIdx.x;
+    TOPK_TS(0);
     if (k > n) k = n;
     // the whole score vector lives in registers (independent, fully pipelined loads); every later scan is on-chip.
     // A single workgroup re-reading global memory 6 times would pay ~200 dependent L2 round trips.
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict_
         }
         __syncthreads();
     }
+    TOPK_TS(1);
     const float blo = s_lo, bhi = s_hi;
     const float bscale = (bhi > blo) ? 2047.0f / (bhi - blo) : 0.0f;
     auto bucket_of = [&](float v) -> uint32_t {
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict_
     }
     const uint32_t bt = s_bt;
     __syncthreads();
+    TOPK_TS(2);
     // ---- fast path: every element in bucket bt or above (one float compare per element -- this single workgroup's VALU time
     // over 33k elements is what the kernel costs) is compacted into LDS and ordered by a rank sort; >= k of them by construction
     {
@@ -154,6 +164,10 @@ __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict_
         }
         __syncthreads();
         const int m = (int)s_m;
+        TOPK_TS(3);
+#ifdef TOPK_TIMING
+        if (tid == 0) ts[8] = m;
+#endif
         if (m <= FASTCAP) {
             // composite keys are unique (index in the low word): rank = number of strictly larger composites.  P threads
             // share a candidate (each sweeps 1/P of the table, partial counts meet by lane shuffles)
@@ -179,6 +193,7 @@ __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict_
                     out_scores[rank] = scores[idx];
                 }
             }
+            TOPK_TS(4);
             return;
         }
         __syncthreads();
@@ -312,6 +327,16 @@ extern "C" int sis3d_topk_desc(const float *scores, int n, int k, float *out_sco
     if (n > EPT * TPB) return SIS3D_EUNSUPPORTED;        // caller falls back to a full sort
     if (n == 0 || k == 0) return SIS3D_OK;
     if (!scores || !out_scores || !out_idx) return SIS3D_EINVAL;
+#ifndef TOPK_TIMING
     hipLaunchKernelGGL(topk_desc_kernel, dim3(1), dim3(TPB), 0, as_stream(stream), scores, n, k, out_scores, out_idx);
+#endif
     return sis3d_check_launch();
 }
+
+#ifdef TOPK_TIMING
+extern "C" int sis3d_topk_desc_timing(const float *scores, int n, int k, float *out_scores, int64_t *out_idx, long long *ts, sis3d_stream_t stream)
+{
+    hipLaunchKernelGGL(topk_desc_kernel, dim3(1), dim3(TPB), 0, as_stream(stream), scores, n, k, out_scores, out_idx, ts);
+    return sis3d_check_launch();
+}
+#endif
