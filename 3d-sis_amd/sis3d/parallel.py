@@ -17,6 +17,12 @@ import torch.distributed as dist
 from .engine import RECORD_WIDTH
 
 
+# test / bench hook (SIS3D_FORCE_COLLECTIVE=1 or parallel.FORCE_COLLECTIVE = True): a world of ONE still issues the collective, so
+# that the RCCL branch of gather_blocks executes on a one-GPU box (tests/test_gpu_scene.py; bench.py's SIS3D_FORCE_DIST run)
+import os as _os
+FORCE_COLLECTIVE = bool(_os.environ.get("SIS3D_FORCE_COLLECTIVE"))
+
+
 def shard_chunks(n_chunks, rank, world):
     """chunk ids owned by `rank`: c mod W == rank, ascending"""
     return list(range(rank, n_chunks, world))
@@ -54,7 +60,7 @@ def gather_blocks(local_blocks, n_chunks, k_rows, group=None, solo=False):
     else:
         device = local_blocks[0].device if local_blocks else torch.device("cpu")
         mine = torch.stack(list(local_blocks)) if local_blocks else torch.zeros(0, bf, device=device)
-    if world == 1:
+    if world == 1 and not (live and FORCE_COLLECTIVE):
         return mine if mine.shape[0] == n_chunks else torch.cat([mine, torch.zeros(n_chunks - mine.shape[0], bf, device=device)])
     if mine.shape[0] == per_rank:
         send = mine.contiguous()
@@ -73,6 +79,17 @@ def gather_blocks(local_blocks, n_chunks, k_rows, group=None, solo=False):
 
 
 _CHUNK_ROWS = {}
+_CHUNK_IDS = {}
+
+
+def _chunk_ids(ids, device):
+    """device LongTensor of a tuple of chunk ids, built once per (tuple, device) (no per-scene pageable H2D copy)"""
+    key = (ids, str(device))
+    t = _CHUNK_IDS.get(key)
+    if t is None:
+        t = torch.tensor(list(ids), dtype=torch.long, device=device)
+        _CHUNK_IDS[key] = t
+    return t
 
 
 def _chunk_rows(n_chunks, world, per_rank, device):

@@ -293,3 +293,99 @@ def test_fused_scene_merge_equals_torch_path(oracle, n_chunks, k_rows):
     empty = torch.zeros(3, bf).cuda()
     r, k, c = ops.scene_merge(empty, k_rows, 0.1)
     assert r.shape == (0, W) and k.numel() == 0 and c.numel() == 0
+
+
+# ---- r4: one graph launch per scene share, lazy lengths, the full-table merge of a rank's share, and the RCCL branch
+def _small_net():
+    from sis3d.nets import backbones
+    cfg = config.scannet_benchmark_cfg()
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS))
+    return net.cuda().eval(), cfg
+
+
+def test_round_graph_lazy_result_and_emulated_rank_share():
+    """(a) a share of exactly one chunk per pipeline goes out as ONE graph launch (PipelinedEngines.capture_round) and gives the
+    records of the per-chunk replays bit for bit, scene after scene; (b) a lazy SceneResult resolves to the same tensors;
+    (c) SceneRunner(emulate=(r, W)) + infer(gathered=table): rank r's own chunks + the merge of the FULL gathered table equals the
+    whole-scene result, for every r -- what bench.py times as share_of_one_rank_at_8."""
+    from sis3d import parallel
+    from sis3d.scene import SceneRunner, SceneResult
+    net, cfg = _small_net()
+    dims = (48, 24, 40)
+    chunks = [(c, (40.0 * (c % 2), 0.0, 32.0 * (c // 2)), synthetic.synth_chunk(20 + c, dims).cuda()) for c in range(4)]   # overlapping
+    base = SceneRunner(net, dims, inflight=3)                    # 4 chunks on 3 pipelines: the per-chunk replays
+    recs, keep = base.infer(chunks)
+    assert recs.shape[0] > 0 and keep.numel() < recs.shape[0]    # the whole-scene NMS really suppresses across chunks
+    rnd = SceneRunner(net, dims, inflight=4)
+    for _ in range(3):
+        r2, k2 = rnd.infer(chunks)
+        assert rnd._round is not None
+        assert torch.equal(r2, recs) and torch.equal(k2, keep)
+    lz = [rnd.infer(chunks, lazy=True) for _ in range(3)]         # three scenes enqueued before the first length is read
+    assert all(isinstance(x, SceneResult) for x in lz)
+    for x in lz:
+        r3, k3 = x.resolve()
+        assert torch.equal(r3, recs) and torch.equal(k3, keep)
+    # (c) the gathered table of the whole scene, then each emulated rank of a world of 2 on its own two chunks
+    table = parallel.gather_blocks(base.run_chunks(chunks), 4, base.k_rows, solo=True).clone()
+    for r in range(2):
+        share = SceneRunner(net, dims, inflight=2, emulate=(r, 2))
+        stale = table.clone()
+        stale[r::2] = 0                                          # this rank's rows must come from its own fresh pass
+        only_mine = [(c, o, p if c % 2 == r else None) for c, o, p in chunks]
+        for lazy in (False, True):
+            out = share.infer(only_mine, gathered=stale, lazy=lazy)
+            r4, k4 = out.resolve() if lazy else out
+            assert torch.equal(r4, recs) and torch.equal(k4, keep)
+        assert share._round is not None and float(stale[r::2].abs().max()) == 0.0     # the caller's table is not written
+
+
+def test_rccl_branch_of_gather_blocks_on_one_gpu(tmp_path):
+    """parallel.gather_blocks' `nccl` branch (one all_gather_into_tensor per scene) executed on real hardware: a world of ONE under
+    RCCL with parallel.FORCE_COLLECTIVE, in a subprocess (a process group is process-wide state), against the same scene without
+    a process group.  N > 1 needs an N-GPU node (the driver's); this pins the collective's shapes / ordering / stream semantics."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_world1.py"
+    script.write_text('''
+import os, sys, torch
+import torch.distributed as dist
+sys.path[:0] = %r
+from sis3d import config, synthetic, parallel
+from sis3d.nets import backbones
+from sis3d.scene import SceneRunner
+cfg = config.scannet_benchmark_cfg()
+net = backbones.ScanNet_Backbone(cfg=cfg); net.init_modules()
+shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+net.load_state_dict(synthetic.synth_state_dict(shapes, seed=0, gains=synthetic.DEFAULT_GAINS)); net.cuda().eval()
+dims = (48, 24, 40)
+chunks = [(c, (40.0 * (c %% 2), 0.0, 32.0 * (c // 2)), synthetic.synth_chunk(20 + c, dims).cuda()) for c in range(4)]
+runner = SceneRunner(net, dims, inflight=4)
+want_r, want_k = runner.infer(chunks)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% int(sys.argv[1]), rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+parallel.FORCE_COLLECTIVE = True
+calls = []
+real = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1]
+for _ in range(3):
+    r, k = runner.infer(chunks)
+    assert torch.equal(r, want_r) and torch.equal(k, want_k)
+assert calls == [(1, 4, parallel.block_floats(runner.k_rows))] * 3, calls
+torch.cuda.synchronize(); dist.destroy_process_group()
+print("RCCL_WORLD1_OK", len(calls), tuple(want_r.shape), int(want_k.numel()))
+''' % ([p for p in sys.path if p],))
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_WORLD1_OK 3" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    from parity import report
+    report("RCCL world-of-one: gather_blocks' nccl branch ran 3 scenes, %s" % p.stdout.strip().splitlines()[-1])
