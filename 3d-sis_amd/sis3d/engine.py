@@ -284,7 +284,7 @@ class PipelinedEngines:
                 outs.append(self.engines[k].run())
         return outs if i is None else outs[0]
 
-    def capture_round(self, send):
+    def capture_round(self, send, stagger=True):
         """ONE HIP graph = one pass of EVERY pipeline: the capture stream forks into the pipelines' streams, pipeline e runs its
         detection pass on the chunk in its static buffers and copies its record block into row e of `send`, and all of them join
         the capture stream again.  A rank that owns as many chunks of a scene as it has pipelines (4 at N = 8 on the 32-chunk
@@ -298,10 +298,22 @@ class PipelinedEngines:
             with torch.no_grad():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=main):
+                    prev_ev = None
                     for e, (eng, s) in enumerate(zip(self.engines, self.streams)):
                         s.wait_stream(main)
                         with torch.cuda.stream(s):
-                            out = eng._step()
+                            if prev_ev is not None and stagger:
+                                # pipelines that start together run the same layers in lockstep and queue for the same CUs (the
+                                # Winograd launches take a CU whole); started one stage apart they fill each other's gaps, as the
+                                # free-running per-chunk replays do: pipeline e starts when pipeline e - 1 has finished level 1
+                                s.wait_event(prev_ev)
+                            ev = torch.cuda.Event()
+                            eng.net._after_level1 = ev.record
+                            try:
+                                out = eng._step()
+                            finally:
+                                eng.net._after_level1 = None
+                            prev_ev = ev
                             send[e].copy_(out["block"])
                     for s in self.streams:
                         main.wait_stream(s)

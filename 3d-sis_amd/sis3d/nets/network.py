@@ -202,6 +202,9 @@ class Network(nn.Module):
         if cfg.NUM_ANCHORS_LEVEL3 != 0:
             raise NotImplementedError("three pyramid levels are not used by any shipped config")
         l1 = self._backbone_level1()
+        hook = getattr(self, "_after_level1", None)
+        if hook is not None:
+            hook()                       # engine.PipelinedEngines.capture_round: the next pipeline of a one-launch round starts here
         l2 = self._backbone_level2(l1)
         self._net_conv = (l1, l2)
         levels = []

@@ -10,6 +10,12 @@ from . import ops, parallel
 from .engine import PipelinedEngines
 
 
+import os as _os
+# capture_round's staggered start (pipeline e waits for pipeline e - 1's level 1): measured and lost on the 4-chunk share
+# (1.357 vs 1.331 ms in the same box run, tools/r04_scene_share.sh) -- off by default, kept as an A/B switch
+ROUND_STAGGER = _os.environ.get("SIS3D_ROUND_STAGGER", "0") != "0"
+
+
 def fused_merge(blocks, k_rows, thresh, score_col, box_col, max_keep):
     """parallel.merge_scene's merge_fn on the GPU: sis3d_scene_merge for tables its sort takes (<= 8192 rows), else None"""
     if not blocks.is_cuda or blocks.shape[0] * int(k_rows) > 8192:
@@ -117,7 +123,7 @@ class SceneRunner:
         is ordered behind the graph, no host-side join"""
         if self._round is None:
             send = torch.zeros(len(mine), bf, device=dev)
-            g, main = self.pipes.capture_round(send)
+            g, main = self.pipes.capture_round(send, stagger=ROUND_STAGGER)
             self._round = (g, main, send)
         g, main, send = self._round
         cur = torch.cuda.current_stream()
