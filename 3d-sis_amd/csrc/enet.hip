@@ -56,23 +56,43 @@ __device__ __forceinline__ void gemm_acc(const float4 *__restrict__ w, const flo
     });
 }
 
+// r4: FOUR waves per workgroup (64 pixels) share one copy of the block's weights in LDS.  Round 3 ran one wave per workgroup with the
+// weights as A operands straight from L2: 68 KB streamed per 16 pixels, one exposed L2 round trip per tap (12-16 us per launch for
+// 272 MFMAs = 3.8 us of matrix work).  Now the workgroup copies conv2's taps, conv3 and the next conv1 into LDS once (<= 72 KB: two
+// workgroups per CU), and every A operand is a ds_read_b128 that the MFMAs hide; L2 weight traffic per pixel drops 4x.
+constexpr int ENET_WAVES = 4;
 template <int C, int MID, int MIDN>
-__global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
+constexpr int enet_lds_float4(int ntaps) { return 64 * (ntaps * (MID / 16) * (MID / 16) + (C / 16) * (MID / 16) + (MIDN / 16) * (C / 16)); }
+
+template <int C, int MID, int MIDN>
+__global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetBlockArgs a)
 {
     constexpr int MT = MID / 16, CT = C / 16, NT = MIDN / 16;
-    const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
-    const int p = blockIdx.x * 16 + li;
+    extern __shared__ __attribute__((aligned(16))) float4 lw[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = (blockIdx.x * ENET_WAVES + wave) * 16 + li;
     const bool live = p < a.npix;
     const int pc = live ? p : a.npix - 1;
     const int W = a.W, H = a.H;
     const int x0 = pc % W, y0 = (pc / W) % H;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- every operand that does not depend on conv2 is requested first: the weights of conv3 and of the next block's conv1 and the
-    // skip rows travel while conv2 runs, so the kernel pays one L2 round trip instead of three
-    const float4 *w3 = reinterpret_cast<const float4 *>(a.w3) + lane;
-    float4 w3v[CT][MT];
-    static_for<0, CT>([&](auto N) { static_for<0, MT>([&](auto G) { w3v[decltype(N)::value][decltype(G)::value] = w3[(decltype(N)::value * MT + decltype(G)::value) * 64]; }); });
+    // ---- the block's weights -> LDS, once per workgroup: [conv2 taps (9, or 5 + 5)][conv3][next conv1], fragment order kept
+    const int ntaps = a.kind == 0 ? 9 : 10;
+    const int n2 = (a.kind == 0 ? 9 : 5) * MT * MT * 64, n2b = a.kind == 0 ? 0 : 5 * MT * MT * 64, n3 = CT * MT * 64, n1 = NT * CT * 64;
+    float4 *l2 = lw, *l2b = lw + n2, *l3 = lw + ntaps * MT * MT * 64, *l1 = l3 + n3;
+    {
+        const float4 *g2 = reinterpret_cast<const float4 *>(a.w2), *g2b = reinterpret_cast<const float4 *>(a.w2b);
+        const float4 *g3 = reinterpret_cast<const float4 *>(a.w3), *g1 = reinterpret_cast<const float4 *>(a.w1n);
+        for (int i = tid; i < n2; i += 64 * ENET_WAVES) l2[i] = g2[i];
+        for (int i = tid; i < n2b; i += 64 * ENET_WAVES) l2b[i] = g2b[i];
+        for (int i = tid; i < n3; i += 64 * ENET_WAVES) l3[i] = g3[i];
+        if constexpr (NT > 0)
+            for (int i = tid; i < n1; i += 64 * ENET_WAVES) l1[i] = g1[i];
+    }
+
+    // ---- the skip rows travel while the weights land
     float4 skip[CT];
     if (a.pool_cin > 0) {
         // down blocks: MaxPool2d(2,2) of the input at 2H x 2W, zero channels appended up to C (enet.py's padding layer)
@@ -91,16 +111,12 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
     } else {
         static_for<0, CT>([&](auto N) { skip[decltype(N)::value] = ld4(a.x + (size_t)pc * C + 16 * decltype(N)::value + 4 * kq); });
     }
-    [[maybe_unused]] float4 w1v[NT > 0 ? NT : 1][CT];
-    if constexpr (NT > 0) {
-        const float4 *w1 = reinterpret_cast<const float4 *>(a.w1n) + lane;
-        static_for<0, NT>([&](auto N) { static_for<0, CT>([&](auto G) { w1v[decltype(N)::value][decltype(G)::value] = w1[(decltype(N)::value * CT + decltype(G)::value) * 64]; }); });
-    }
+    __syncthreads();
 
     // ---- conv2 (zero padding: taps outside the image contribute nothing)
     f32x4 acc[MT][2];
     static_for<0, MT>([&](auto N) { acc[decltype(N)::value][0] = acc[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
-    const float4 *w2 = reinterpret_cast<const float4 *>(a.w2) + lane;
+    const float4 *w2 = l2 + lane;
     const float *y1p = a.y1 + (size_t)pc * MID + 4 * kq;
     if (a.kind == 0) {
         const int d = a.dil;
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
     } else {
         // enet.py's asymmetric pair: Conv2d(mid, mid, (1,5), padding (0,2), no bias) then Conv2d(mid, mid, (5,1), padding (2,0)): the
         // row y + dy of the intermediate is rebuilt per dy (5 x 5 taps); rows outside the image are the second conv's zero padding
-        const float4 *w2b = reinterpret_cast<const float4 *>(a.w2b) + lane;
+        const float4 *w2b = l2b + lane;
         static_for<0, 5>([&](auto DY) {
             constexpr int dy = decltype(DY)::value - 2;
             const bool rowok = (unsigned)(y0 + dy) < (unsigned)H;
@@ -146,7 +162,10 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
                                    acc[n][0][3] + acc[n][1][3] + b.w), s);
     });
 
-    // ---- conv3 + skip + PReLU (operands requested at the top of the kernel)
+    // ---- conv3 + skip + PReLU (weights from LDS, skip rows requested at the top of the kernel)
+    const float4 *w3 = l3 + lane;
+    float4 w3v[CT][MT];
+    static_for<0, CT>([&](auto N) { static_for<0, MT>([&](auto G) { w3v[decltype(N)::value][decltype(G)::value] = w3[(decltype(N)::value * MT + decltype(G)::value) * 64]; }); });
     f32x4 o[CT];
     static_for<0, CT>([&](auto N) { o[decltype(N)::value] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
     static_for<0, MT>([&](auto G) {
@@ -181,6 +200,9 @@ __global__ __launch_bounds__(64) void enet_block_kernel(const EnetBlockArgs a)
 
     // ---- the next bottleneck's conv1 (1x1, C -> MIDN) + PReLU on the block output while it is in registers
     if constexpr (NT > 0) {
+        const float4 *w1 = l1 + lane;
+        float4 w1v[NT][CT];
+        static_for<0, NT>([&](auto N) { static_for<0, CT>([&](auto G) { w1v[decltype(N)::value][decltype(G)::value] = w1[(decltype(N)::value * CT + decltype(G)::value) * 64]; }); });
         f32x4 n1[NT][2];
         static_for<0, NT>([&](auto N) { n1[decltype(N)::value][0] = n1[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
         static_for<0, CT>([&](auto G) {
@@ -301,7 +323,12 @@ __global__ __launch_bounds__(256) void enet_initial_kernel(const float *__restri
 template <int C, int MID, int MIDN>
 int launch_block(const EnetBlockArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL((enet_block_kernel<C, MID, MIDN>), dim3((unsigned)cdiv(a.npix, 16)), dim3(64), 0, st, a);
+    const size_t lds = (size_t)enet_lds_float4<C, MID, MIDN>(a.kind == 0 ? 9 : 10) * sizeof(float4);
+    auto kern = enet_block_kernel<C, MID, MIDN>;
+    static Sis3dLdsOnce once;
+    if (enet_lds_float4<C, MID, MIDN>(10) * sizeof(float4) > 64 * 1024 &&
+        sis3d_grant_lds(once, (const void *)kern, (int)(enet_lds_float4<C, MID, MIDN>(10) * sizeof(float4))) != SIS3D_OK) return SIS3D_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(cdiv(a.npix, 16), ENET_WAVES)), dim3(64 * ENET_WAVES), lds, st, a);
     return sis3d_check_launch();
 }
 
