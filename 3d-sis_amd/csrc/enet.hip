@@ -13,6 +13,7 @@
 // own small kernels.  fp32 throughout; the summation order differs from MIOpen's, results agree to ~1e-6 of the feature scale.
 #include "common.h"
 #include "mfma16.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -37,6 +38,17 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) { return make_float4(
 template <int R>
 __device__ __forceinline__ float comp(const float4 &v) { return R == 0 ? v.x : R == 1 ? v.y : R == 2 ? v.z : v.w; }
 
+// inline-asm row loads with counted waits (see enet_block_kernel): 16 B per lane from a uniform base + a 32-bit byte offset
+__device__ __forceinline__ void gload16(f32x4 &dst, int byte_off, const float *base)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(f32x4 &a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+// an empty volatile asm that "modifies" a register the asm loads wrote: keeps every use of it behind the wait above
+__device__ __forceinline__ void touch(f32x4 &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ float4 as_float4(const f32x4 &v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
 // acc[ct][r & 1] += W[ct][g] * X[g]: two accumulators per output tile and the tiles interleaved, so that consecutive MFMAs never
 // wait on their own result
 template <int NT, int KG>
@@ -60,11 +72,12 @@ __device__ __forceinline__ void gemm_acc(const float4 *__restrict__ w, const flo
 // weights as A operands straight from L2: 68 KB streamed per 16 pixels, one exposed L2 round trip per tap (12-16 us per launch for
 // 272 MFMAs = 3.8 us of matrix work).  Now the workgroup copies conv2's taps, conv3 and the next conv1 into LDS once (<= 72 KB: two
 // workgroups per CU), and every A operand is a ds_read_b128 that the MFMAs hide; L2 weight traffic per pixel drops 4x.
-constexpr int ENET_WAVES = 4;
 template <int C, int MID, int MIDN>
 constexpr int enet_lds_float4(int ntaps) { return 64 * (ntaps * (MID / 16) * (MID / 16) + (C / 16) * (MID / 16) + (MIDN / 16) * (C / 16)); }
 
-template <int C, int MID, int MIDN>
+// ENET_WAVES = 1: the round-3 form (one wave per workgroup, weights as A operands straight from L2, no LDS) with the tap rows
+// prefetched; kept as an A/B switch (SIS3D_ENET_WAVES=1)
+template <int C, int MID, int MIDN, int ENET_WAVES>
 __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetBlockArgs a)
 {
     constexpr int MT = MID / 16, CT = C / 16, NT = MIDN / 16;
@@ -80,16 +93,29 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
 
     // ---- the block's weights -> LDS, once per workgroup: [conv2 taps (9, or 5 + 5)][conv3][next conv1], fragment order kept
     const int ntaps = a.kind == 0 ? 9 : 10;
-    const int n2 = (a.kind == 0 ? 9 : 5) * MT * MT * 64, n2b = a.kind == 0 ? 0 : 5 * MT * MT * 64, n3 = CT * MT * 64, n1 = NT * CT * 64;
-    float4 *l2 = lw, *l2b = lw + n2, *l3 = lw + ntaps * MT * MT * 64, *l1 = l3 + n3;
-    {
-        const float4 *g2 = reinterpret_cast<const float4 *>(a.w2), *g2b = reinterpret_cast<const float4 *>(a.w2b);
-        const float4 *g3 = reinterpret_cast<const float4 *>(a.w3), *g1 = reinterpret_cast<const float4 *>(a.w1n);
-        for (int i = tid; i < n2; i += 64 * ENET_WAVES) l2[i] = g2[i];
-        for (int i = tid; i < n2b; i += 64 * ENET_WAVES) l2b[i] = g2b[i];
-        for (int i = tid; i < n3; i += 64 * ENET_WAVES) l3[i] = g3[i];
-        if constexpr (NT > 0)
-            for (int i = tid; i < n1; i += 64 * ENET_WAVES) l1[i] = g1[i];
+    const int n2 = (a.kind == 0 ? 9 : 5) * MT * MT * 64, n3 = CT * MT * 64;
+    const float4 *l2, *l2b, *l3, *l1;
+    if constexpr (ENET_WAVES == 1) {
+        l2 = reinterpret_cast<const float4 *>(a.w2); l2b = reinterpret_cast<const float4 *>(a.w2b);
+        l3 = reinterpret_cast<const float4 *>(a.w3); l1 = reinterpret_cast<const float4 *>(a.w1n);
+    } else {
+        l2 = lw; l2b = lw + n2; l3 = lw + ntaps * MT * MT * 64; l1 = l3 + n3;
+    }
+    if constexpr (ENET_WAVES > 1) {
+        // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB fragment per instruction, no staging registers): a wave issues
+        // its share of the <= 72 fragments back to back -- ONE L2 round trip for the lot (a load / store loop through registers pays
+        // one per iteration: measured 0.57 instead of 0.37 ms per 5 views) -- and the single wait sits in front of the barrier below
+        const int f2 = (a.kind == 0 ? 9 : 5) * MT * MT, f2b = a.kind == 0 ? 0 : 5 * MT * MT, f3 = CT * MT, f1 = NT * CT;
+        const int nf = f2 + f2b + f3 + f1;
+        for (int f = wave; f < nf; f += ENET_WAVES) {
+            const float *src;
+            if (f < f2) src = a.w2 + (size_t)f * 256;
+            else if (f < f2 + f2b) src = a.w2b + (size_t)(f - f2) * 256;
+            else if (f < f2 + f2b + f3) src = a.w3 + (size_t)(f - f2 - f2b) * 256;
+            else src = a.w1n + (size_t)(f - f2 - f2b - f3) * 256;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane * 4),
+                                             (void __attribute__((address_space(3))) *)(lw + (size_t)f * 64), 16, 0, 0);
+        }
     }
 
     // ---- the skip rows travel while the weights land
@@ -111,39 +137,72 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
     } else {
         static_for<0, CT>([&](auto N) { skip[decltype(N)::value] = ld4(a.x + (size_t)pc * C + 16 * decltype(N)::value + 4 * kq); });
     }
-    __syncthreads();
+    if constexpr (ENET_WAVES > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA above (the compiler does not count LDS-DMA writes)
+        __syncthreads();
+    }
 
     // ---- conv2 (zero padding: taps outside the image contribute nothing)
     f32x4 acc[MT][2];
     static_for<0, MT>([&](auto N) { acc[decltype(N)::value][0] = acc[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
     const float4 *w2 = l2 + lane;
-    const float *y1p = a.y1 + (size_t)pc * MID + 4 * kq;
+    // The tap rows are loaded by inline asm, ALL of a 3x3 conv's nine taps (or one 5-tap row of the asymmetric pair, one row ahead)
+    // before the first MFMA: left to itself hipcc turned `ok ? load : 0` into a branch around eight single-dword loads per tap and a
+    // vmcnt(0) per tap, i.e. nine dependent L2 round trips (~1 us each) around 3.8 us of matrix work.  Addresses are clamped to the
+    // pixel itself where the tap falls outside the image, the zero is a select after the (counted) wait.
+    const int ybase = (int)(((size_t)pc * MID + 4 * kq) * 4);               // byte offset of this lane's 16 B of its own pixel row
     if (a.kind == 0) {
         const int d = a.dil;
+        f32x4 xa[9][MT];
+        bool okt[9];
         static_for<0, 9>([&](auto T) {
             constexpr int tap = decltype(T)::value, ky = tap / 3 - 1, kx = tap % 3 - 1;
             const int dy = ky * d, dx = kx * d;
-            const bool ok = (unsigned)(y0 + dy) < (unsigned)H && (unsigned)(x0 + dx) < (unsigned)W;
-            const float *src = y1p + (ok ? (ptrdiff_t)(dy * W + dx) * MID : 0);
+            okt[tap] = (unsigned)(y0 + dy) < (unsigned)H && (unsigned)(x0 + dx) < (unsigned)W;
+            const int off = ybase + (okt[tap] ? (dy * W + dx) * MID * 4 : 0);
+            static_for<0, MT>([&](auto G) { gload16(xa[tap][decltype(G)::value], off + 64 * decltype(G)::value, a.y1); });
+        });
+        wait_vm<0>(xa[0][0]);
+        static_for<0, 9 * MT>([&](auto I) { touch(xa[decltype(I)::value / MT][decltype(I)::value % MT]); });
+        static_for<0, 9>([&](auto T) {
+            constexpr int tap = decltype(T)::value;
             float4 xv[MT];
-            static_for<0, MT>([&](auto G) { const float4 v = ld4(src + 16 * decltype(G)::value); xv[decltype(G)::value] = ok ? v : zero4; });
+            static_for<0, MT>([&](auto G) { xv[decltype(G)::value] = okt[tap] ? as_float4(xa[tap][decltype(G)::value]) : zero4; });
             gemm_acc<MT, MT>(w2 + tap * (MT * MT * 64), xv, acc);
         });
     } else {
         // enet.py's asymmetric pair: Conv2d(mid, mid, (1,5), padding (0,2), no bias) then Conv2d(mid, mid, (5,1), padding (2,0)): the
         // row y + dy of the intermediate is rebuilt per dy (5 x 5 taps); rows outside the image are the second conv's zero padding
         const float4 *w2b = l2b + lane;
+        f32x4 xr[2][5][MT];
+        auto issue_row = [&](auto DY, auto B) {
+            constexpr int dy = decltype(DY)::value - 2, b = decltype(B)::value;
+            const bool rowok = (unsigned)(y0 + dy) < (unsigned)H;
+            static_for<0, 5>([&](auto DX) {
+                constexpr int dx = decltype(DX)::value - 2;
+                const bool ok = rowok && (unsigned)(x0 + dx) < (unsigned)W;
+                const int off = ybase + (ok ? (dy * W + dx) * MID * 4 : 0);
+                static_for<0, MT>([&](auto G) { gload16(xr[b][decltype(DX)::value][decltype(G)::value], off + 64 * decltype(G)::value, a.y1); });
+            });
+        };
+        issue_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 5>([&](auto DY) {
-            constexpr int dy = decltype(DY)::value - 2;
+            constexpr int dyi = decltype(DY)::value, dy = dyi - 2, b = dyi & 1;
+            if constexpr (dyi + 1 < 5) {
+                issue_row(std::integral_constant<int, dyi + 1>{}, std::integral_constant<int, (dyi + 1) & 1>{});
+                wait_vm<5 * MT>(xr[b][0][0]);                       // everything but the row just requested has landed
+            } else {
+                wait_vm<0>(xr[b][0][0]);
+            }
+            static_for<0, 5 * MT>([&](auto I) { touch(xr[b][decltype(I)::value / MT][decltype(I)::value % MT]); });
             const bool rowok = (unsigned)(y0 + dy) < (unsigned)H;
             f32x4 t[MT][2];
             static_for<0, MT>([&](auto N) { t[decltype(N)::value][0] = t[decltype(N)::value][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
             static_for<0, 5>([&](auto DX) {
                 constexpr int dx = decltype(DX)::value - 2;
                 const bool ok = rowok && (unsigned)(x0 + dx) < (unsigned)W;
-                const float *src = y1p + (ok ? (ptrdiff_t)(dy * W + dx) * MID : 0);
                 float4 xv[MT];
-                static_for<0, MT>([&](auto G) { const float4 v = ld4(src + 16 * decltype(G)::value); xv[decltype(G)::value] = ok ? v : zero4; });
+                static_for<0, MT>([&](auto G) { xv[decltype(G)::value] = ok ? as_float4(xr[b][decltype(DX)::value][decltype(G)::value]) : zero4; });
                 gemm_acc<MT, MT>(w2 + decltype(DX)::value * (MT * MT * 64), xv, t);
             });
             float4 tv[MT];
@@ -151,7 +210,7 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
                 constexpr int n = decltype(N)::value;
                 tv[n] = make_float4(t[n][0][0] + t[n][1][0], t[n][0][1] + t[n][1][1], t[n][0][2] + t[n][1][2], t[n][0][3] + t[n][1][3]);
             });
-            gemm_acc<MT, MT>(w2b + decltype(DY)::value * (MT * MT * 64), tv, acc);
+            gemm_acc<MT, MT>(w2b + dyi * (MT * MT * 64), tv, acc);
         });
     }
     float4 y2[MT];
@@ -323,12 +382,17 @@ __global__ __launch_bounds__(256) void enet_initial_kernel(const float *__restri
 template <int C, int MID, int MIDN>
 int launch_block(const EnetBlockArgs &a, hipStream_t st)
 {
+    static const int waves = [] { const char *e = getenv("SIS3D_ENET_WAVES"); return e && atoi(e) == 1 ? 1 : 4; }();      // A/B switch
+    if (waves == 1) {
+        hipLaunchKernelGGL((enet_block_kernel<C, MID, MIDN, 1>), dim3((unsigned)cdiv(a.npix, 16)), dim3(64), 0, st, a);
+        return sis3d_check_launch();
+    }
     const size_t lds = (size_t)enet_lds_float4<C, MID, MIDN>(a.kind == 0 ? 9 : 10) * sizeof(float4);
-    auto kern = enet_block_kernel<C, MID, MIDN>;
+    auto kern = enet_block_kernel<C, MID, MIDN, 4>;
     static Sis3dLdsOnce once;
     if (enet_lds_float4<C, MID, MIDN>(10) * sizeof(float4) > 64 * 1024 &&
         sis3d_grant_lds(once, (const void *)kern, (int)(enet_lds_float4<C, MID, MIDN>(10) * sizeof(float4))) != SIS3D_OK) return SIS3D_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(cdiv(a.npix, 16), ENET_WAVES)), dim3(64 * ENET_WAVES), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(cdiv(a.npix, 16), 4)), dim3(256), lds, st, a);
     return sis3d_check_launch();
 }
 
