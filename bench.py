@@ -15,7 +15,7 @@ all-gather and whole-scene NMS, `records_gathered`, `kept_after_scene_nms`, `ms_
 same scene = `single_gpu` and `speedup_vs_1gpu`).  So value(N) / value(1) compares like with like, and the strong-scaling figure
 of the collective path can be read off the `scene` key of the same lines.  `--workload scene` makes the scene the headline instead.
   backbone_rpn  BASELINE config[1]: one 96x48x96 geometry-only chunk per pipeline, HIP backbone + RPN; a step = one pass
-                over `--inflight` (default 4 here, 3 for the other workloads: the measured best of each, tools/r03_inflight.sh)
+                over `--inflight` (default 3: the measured best of every workload, tools/r04_inflight.sh)
                 independent chunks per GPU, each on its own HIP stream / captured graph, inputs resident in HBM.  Ranks share
                 nothing (scaling: weak).
   detect        config[2]: + decode / top-k / NMS / RoI pooling / classifier (+ `--masks`: mask head on a fixed
@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preheat-ms", type=float, default=250.0,
+                    help="untimed passes of the workload in front of the W warm-up steps, in ms of wall clock (clock ramp-up; 0 = off)")
     ap.add_argument("--workload", default="auto", choices=["auto", "backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
@@ -150,10 +152,11 @@ def scene_origin(c, stride):
 
 
 def default_inflight(workload):
-    """chunks in flight per GPU that measured best (profiles/r03_inflight.txt): the Winograd kernels take a CU whole (148 KB of LDS, 512
-    registers per lane), so the backbone + RPN pass gains from a fourth stream filling the CUs they leave; the passes with long
-    single-workgroup tails (detect, scene) and the image path lose with it"""
-    return 4 if workload == "backbone_rpn" else 3
+    """chunks in flight per GPU that measured best.  Round 4 (profiles/r04_inflight.txt, 200-step runs after a clock pre-heat): three
+    for every workload -- backbone + RPN 1.96 G voxels/s with 3, 1.82 with 4, 1.95 with 6; detect 1.73 / 1.53 with 3 / 4.  (Round 3
+    preferred four for backbone + RPN; with the Bottleneck bodies on the Winograd kernel, five launches per chunk take their CUs
+    whole and a fourth stream only queues behind them.)"""
+    return 3
 
 
 def chunk_pipeline_entry(value, unit, ms_per_step, chunks_per_step_per_gpu, single_ms):
@@ -500,6 +503,21 @@ def ops_mod():
     return ops
 
 
+def preheat(step, ms):
+    """untimed passes of the workload itself for `ms` of wall clock, in front of the W warm-up steps: a 20-step timed region is ~20 ms,
+    and measured from a cold start (clocks at idle: the first thing a fresh process does) the same code reads 1.39-1.77 instead of
+    1.95 G voxels/s (round 4, tools/r04_inflight.sh) -- whatever ran before the timed region decided the number.  Synchronises
+    every 16 passes so the launch queue stays shallow."""
+    import torch
+    if ms <= 0:
+        return
+    t_end = time.perf_counter() + ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+
+
 def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):
     """weak-scaling workloads: `inflight` independent chunks per GPU per step -> dict(dt, vox_per_step, single_ms, extra)"""
     import torch
@@ -532,6 +550,7 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
             else:
                 eng.load(i, data, slot=g)
     eng.prepare(warmup=2)
+    preheat(eng.run, args.preheat_ms)
     for _ in range(args.warmup):
         eng.run()
     barrier()
@@ -656,6 +675,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         return r.resolve() if lazy else r
     for _ in range(max(3, min(args.warmup, 10))):              # the first replays of freshly captured graphs cost milliseconds each
         res = done(one())
+    preheat(lambda: done(one()), args.preheat_ms / 16.0)       # a scene is 4-32 chunks: ~1/16 of the passes
     barrier()
     t0 = time.perf_counter()
     prev = None
