@@ -66,6 +66,25 @@ constexpr int NVOX = HX * HY * HZ;                              // 600 staging i
 constexpr int NTHR = 256;                                        // 4 waves, one per SIMD
 constexpr int NIT = (NVOX + NTHR - 1) / NTHR;
 
+// r4 -- MINI geometry (the ragged mask-head launches): a workgroup's 32 Winograd tiles are FOUR independent 2x2x2-tile bricks
+// ("minis": 4 x 4 x 4 output voxels, halo 6 x 6 x 6) instead of one 4x2x4-tile block, so the crops of the detected boxes
+// (9..20 voxels per side) are covered with 4-voxel granularity on every axis: the 16-box bench set needs 924 minis = 231 workgroups
+// per cout group where the 8 x 4 x 8 blocks need 304 (54 % of their voxel slots filled) -- 462 instead of 608 workgroups per layer
+// = two rounds of the chip instead of three.  LDS layout of a K-step's raw stage: [channel][mini][hx][hy][hz] with strides
+// (1352, 324, 48, 8, 1) floats: lane (tile = (mini bit, tx, ty, tz), channel kq) reads 8 B at float offset
+// kq 1352 + mb 324 + 2 tx 48 + 2 ty 8 + 2 tz, i.e. bank pair (4 kq + 2 mb + 16 tx + 8 ty + tz) mod 32 -- the 32 lanes of a
+// ds_read_b64 group on 32 distinct bank pairs, as in the block layout.  864 staging items (4 per thread instead of 3).
+template <bool MINI> struct Geo;
+template <> struct Geo<false> {
+    static constexpr int hzs = HZS, ps = PS, chs = CHS, nvox = NVOX, nit = NIT, dump = HX * PS, ms = 0;
+};
+template <> struct Geo<true> {
+    static constexpr int hzs = 8, ps = 48, ms = 324, chs = 1352, nvox = 4 * 216, nit = (4 * 216 + NTHR - 1) / NTHR, dump = 4 * 324;
+};
+template <bool MINI> constexpr int raw_stage() { return 4 * Geo<MINI>::chs; }
+template <bool MINI> constexpr int lds_floats_g(int nc) { return NRAW * raw_stage<MINI>() + NBST * nc * B_TILE; }     // MINI, NC = 2: 163,200 B
+static_assert(lds_floats_g<true>(2) * 4 <= 160 * 1024 && lds_floats_g<false>(2) == lds_floats(2), "LDS budget");
+
 // ragged batch (the mask head: one launch per layer for all detected boxes' crops): problems of different grid sizes packed back to
 // back in one activation buffer; same descriptor layout as conv3d_t16.hip / conv3d.hip's ragged launches (ops.MaskPlan)
 struct WinoRagged {
@@ -144,6 +163,16 @@ __device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c)
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_all(f32x4 (&v)[3]) { wait_vmcnt<N>(v[0], v[1], v[2]); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_all(f32x4 (&v)[4]) { wait_vmcnt<N>(v[0], v[1], v[2], v[3]); }
+
 // 1-D input transform B^T over 4 values, in place
 #define WN_BT_INPLACE(v0, v1, v2, v3) \
     do { const float t0_ = (v0) - (v2), t1_ = (v1) + (v2), t2_ = (v2) - (v1), t3_ = (v1) - (v3); \
@@ -195,7 +224,7 @@ __device__ __forceinline__ f32x2 pk_bt_hi(f32x2 a, f32x2 b)
 //   x_pair   (8):  (dy, z pair) over x                2 packed adds
 //   y_col    (4):  (i, z pair) over y                 4 packed adds, in place
 //   z_row    (8):  row (i, xi_y) over z               2 packed adds (op_sel)  -> T[i][xi_y][z pair] = the A operands of the next step
-template <int H>
+template <int H, bool MINI = false>
 struct NextV {
     f32x2 T[2][4][2];                                           // [xi_x - 2H][xi_y][xi_z pair]
     f32x2 d[2][3][2];                                           // [dy & 1][plane][lo / hi]
@@ -215,7 +244,7 @@ struct NextV {
         if constexpr (WN_EXP & 256) return;
         static_for<3 * J, 3 * J + 3>([&](auto R) {
             constexpr int p = decltype(R)::value >> 1, h = decltype(R)::value & 1, dx = p + H;
-            ds_read_b64_asm<(dx * PS + DY * HZS + 2 * h) * 4>(d[DY & 1][p][h], r.lo);
+            ds_read_b64_asm<(dx * Geo<MINI>::ps + DY * Geo<MINI>::hzs + 2 * h) * 4>(d[DY & 1][p][h], r.lo);
         });
     }
     __device__ __forceinline__ void wait_rows()
@@ -278,7 +307,7 @@ struct NextV {
     }
 };
 
-template <int H, int NC, int C3 = 0, int C2N = 0>
+template <int H, int NC, int C3 = 0, int C2N = 0, bool MINI = false>
 __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp, int gX, int gY, int gZ, int nby, int nbz,
                                           int64_t in_off, int64_t out_off)
 {
@@ -288,8 +317,26 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     if constexpr (WN_EXP & 64) ts0 = wall_clock64();       // experiment: 100 MHz timestamps of the phases, written instead of the output
     const int g = wave & 1;
     const int li = lane & 15, kq = lane >> 4;
-    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
-    const int ox0 = bx * VX, oy0 = by * VY, oz0 = bz * VZ;
+    using G_ = Geo<MINI>;
+    constexpr int NIT = G_::nit, NVOX = G_::nvox, PS = G_::ps, HZS = G_::hzs, CHS = G_::chs, RAW_STAGE = raw_stage<MINI>();
+    // block geometry: origin of the 8 x 4 x 8 block; MINI: origins of the workgroup's four 4 x 4 x 4 minis (minis 4 brick .. + 3 of the
+    // problem's nmx x nmy x nmz grid, z fastest; a mini past the end sits far outside the grid: all zeros in, nothing stored)
+    int ox0 = 0, oy0 = 0, oz0 = 0;
+    [[maybe_unused]] int mox[4], moy[4], moz[4];
+    if constexpr (MINI) {
+        const int nmy = (gY + 3) >> 2, nmz = (gZ + 3) >> 2, nm = ((gX + 3) >> 2) * nmy * nmz;
+        static_for<0, 4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int mi = 4 * brick + j;
+            const bool dead = mi >= nm;
+            mox[j] = dead ? (1 << 20) : 4 * (mi / (nmz * nmy));
+            moy[j] = dead ? (1 << 20) : 4 * ((mi / nmz) % nmy);
+            moz[j] = dead ? (1 << 20) : 4 * (mi % nmz);
+        });
+    } else {
+        const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+        ox0 = bx * VX; oy0 = by * VY; oz0 = bz * VZ;
+    }
     const float *__restrict__ p_in = a.in[prob] + in_off;
     const float *__restrict__ p_wp = a.wp[prob];
     const int nk = a.nk;
@@ -307,13 +354,25 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     static_for<0, NIT>([&](auto I) {
         constexpr int it = decltype(I)::value;
         const int v = tid + it * NTHR;
-        const int hz = v % HZ, hy = (v / HZ) % HY, hx = v / (HZ * HY);
-        const int gx = ox0 - 1 + hx, gy = oy0 - 1 + hy, gz = oz0 - 1 + hz;
+        int gx, gy, gz, lpos;
+        if constexpr (MINI) {
+            const int mj = v / 216, r = v - mj * 216;               // mini, voxel of its 6 x 6 x 6 halo brick
+            const int hz = r % 6, hy = (r / 6) % 6, hx = r / 36;
+            const int sx = mj == 0 ? mox[0] : mj == 1 ? mox[1] : mj == 2 ? mox[2] : mox[3];
+            const int sy = mj == 0 ? moy[0] : mj == 1 ? moy[1] : mj == 2 ? moy[2] : moy[3];
+            const int sz = mj == 0 ? moz[0] : mj == 1 ? moz[1] : mj == 2 ? moz[2] : moz[3];
+            gx = sx - 1 + hx; gy = sy - 1 + hy; gz = sz - 1 + hz;
+            lpos = mj * G_::ms + hx * PS + hy * HZS + hz;
+        } else {
+            const int hz = v % HZ, hy = (v / HZ) % HY, hx = v / (HZ * HY);
+            gx = ox0 - 1 + hx; gy = oy0 - 1 + hy; gz = oz0 - 1 + hz;
+            lpos = hx * PS + hy * HZS + hz;
+        }
         const bool inside = v < NVOX && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
         goff[it] = inside ? ((gx * gY + gy) * gZ + gz) * a.cin_stride : 0;
-        loff[it] = 4 * (inside ? hx * PS + hy * HZS + hz : HX * PS + (lane & 31));  // BYTES; dump: floats 1000..1031 of the 1040
+        loff[it] = 4 * (inside ? lpos : G_::dump + (lane & 31));    // BYTES; dump: 32 floats of the pad behind the last plane of a channel
         if (v < NVOX && !inside) {
-            static_for<0, NRAW * 4>([&](auto C) { raw[decltype(C)::value * CHS + hx * PS + hy * HZS + hz] = 0.f; });
+            static_for<0, NRAW * 4>([&](auto C) { raw[decltype(C)::value * CHS + lpos] = 0.f; });
         }
     });
     // In the loop the loads are inline asm: hipcc waits vmcnt(0) -- i.e. also for every LDS-DMA in flight -- at the first use of an
@@ -351,7 +410,9 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
 
     // lane (li, kq): tile li of group g = (txl, ty, tz), channel kq of the K-step
     const int txl = li >> 3, ty = (li >> 2) & 1, tz = li & 3;
-    const int rbase = kq * CHS + (2 * (2 * g + txl)) * PS + (2 * ty) * HZS + 2 * tz;
+    // MINI: tile li of group g = mini 2 g + (li >> 3), tile (tx, ty, tz) = bits 2, 1, 0 of li inside it
+    const int rbase = MINI ? kq * CHS + (2 * g + (li >> 3)) * G_::ms + (2 * ((li >> 2) & 1)) * PS + (2 * ((li >> 1) & 1)) * HZS + 2 * (li & 1)
+                           : kq * CHS + (2 * (2 * g + txl)) * PS + (2 * ty) * HZS + 2 * tz;
     const int bbase = H * 8 * 256 + lane * 4;
 
     // ---- prologue: U stages 0 and 1 and raw stages 0 and 1 all in flight together (one wait), then V of step 0
@@ -360,8 +421,8 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     f32x4 sw[NIT];
     static_for<0, NIT>([&](auto I) { load16_asm(sw[decltype(I)::value], goff[decltype(I)::value] * 4, p_in + (nk > 1 ? 4 : 0)); });
     static_for<0, NFILL>([&](auto I) { fill_b_item(I, nk > 1 ? 1 : 0, 1); });
-    wait_vmcnt<0>(sv[0], sv[1], sv[2]);
-    wait_vmcnt<0>(sw[0], sw[1], sw[2]);
+    wait_vmcnt_all<0>(sv);
+    wait_vmcnt_all<0>(sw);
     static_for<0, NIT>([&](auto I) { stage_store_item(I, 0); });
     static_for<0, NIT>([&](auto I) { sv[decltype(I)::value] = sw[decltype(I)::value]; stage_store_item(I, 1); });
     __syncthreads();
@@ -370,7 +431,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // the 35 MFMAs the loads had when they were issued at the start of the step that stores them
     if (!(WN_EXP & 2)) static_for<0, NIT>([&](auto I) { stage_load_item(I, nk > 2 ? 2 : nk - 1); });
     // V ping-pongs between two NextV objects (no register copies): step k multiplies with one while the other is being built
-    NextV<H> va, vb;
+    NextV<H, MINI> va, vb;
     static_for<0, 64>([&](auto M) { va.template unit<decltype(M)::value>(LdsRow(raw + rbase)); });
 
     // ---- main loop.  Step k: the 64 MFMAs of step k (32 xi x 2 cout tiles); behind them, in the gaps between MFMAs: the LDS-DMA of
@@ -391,7 +452,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // the next step's first operands hide behind 512 cycles of matrix work instead of idling the pipe.
     // Loads / DMA of the steps past the end are clamped to the last step (harmless duplicates, landed before the final barrier):
     // no branches in the block.
-    static_assert(NIT == 3, "the counted waits below assume three staging loads and eight DMA instructions per step");
+    static_assert(NIT == 3 || (NIT == 4 && NC == 2), "slots 41.. / 49.. hold the stores / loads of at most four staging items");
     int cur = 0;                                         // k % 3: raw stage of step k, U stage of step k
     f32x4 bq[4][NC];                                     // ring over xi quads (slot q & 3), every cout tile of the group
     auto read_b = [&](auto Q, const float *bs) {
@@ -400,7 +461,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     };
     read_b(std::integral_constant<int, 0>{}, bst + bbase);
     read_b(std::integral_constant<int, 1>{}, bst + bbase);
-    auto step = [&](int k, NextV<H> &vu, NextV<H> &vn) {
+    auto step = [&](int k, NextV<H, MINI> &vu, NextV<H, MINI> &vn) {
         const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
         const int ks = k + 2 < nk ? k + 2 : nk - 1, ks3 = k + 3 < nk ? k + 3 : nk - 1;
         const float *bs = bst + cur * B_STAGE + bbase;
@@ -430,7 +491,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
                     if constexpr (!(WN_EXP & 16)) vn.template unit<sl>(rn);
                     if constexpr (sl >= 49 && sl < 49 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_load_item(std::integral_constant<int, (sl - 49) / 2>{}, ks3);
                     if constexpr (sl >= 7 && sl < 7 + 2 * NFILL && (sl & 1) == 1 && !(WN_EXP & 1)) fill_b_item(std::integral_constant<int, (sl - 7) / 2>{}, ks, nn);
-                    if constexpr (sl == 40 && !(WN_EXP & 2)) wait_vmcnt<(WN_EXP & 512) ? 0 : NFILL>(sv[0], sv[1], sv[2]);
+                    if constexpr (sl == 40 && !(WN_EXP & 2)) wait_vmcnt_all<(WN_EXP & 512) ? 0 : NFILL>(sv);
                     if constexpr (sl >= 41 && sl < 41 + 2 * NIT && (sl & 1) == 1 && !(WN_EXP & 2)) stage_store_item(std::integral_constant<int, (sl - 41) / 2>{}, nn);
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -450,7 +511,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     if constexpr (WN_EXP & 64) ts2 = wall_clock64();
     // the clamped duplicate DMA and raw-stage loads of the last steps.  The wait names sv: the loads are asm, so hipcc does not know
     // they are still writing those registers -- without the operands it hands them to the epilogue above this line
-    wait_vmcnt<0>(sv[0], sv[1], sv[2]);
+    wait_vmcnt_all<0>(sv);
     // the MFMAs are asm: hipcc's hazard recogniser does not know that the accumulators the epilogue is about to read were written by
     // the matrix pipe a few cycles ago (an 8-pass MFMA needs up to 11 wait states before a VALU read of its result)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -596,7 +657,16 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         const int o = row & 7, tq = (row >> 3) & 3, rr = (row >> 5) & 1, cc = row >> 6;
         const float4 v = *reinterpret_cast<const float4 *>(tr + row * 16 + c4 * 4);
         const int tl = 4 * tq + 2 * H + rr;
-        const int x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2), y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1), z = oz0 + 2 * (tl & 3) + (o & 1);
+        int x, y, z;
+        if constexpr (MINI) {
+            const bool mb = (tl >> 3) & 1;                              // which of this wave's two minis (2 g, 2 g + 1)
+            const int sx = g ? (mb ? mox[3] : mox[2]) : (mb ? mox[1] : mox[0]);
+            const int sy = g ? (mb ? moy[3] : moy[2]) : (mb ? moy[1] : moy[0]);
+            const int sz = g ? (mb ? moz[3] : moz[2]) : (mb ? moz[1] : moz[0]);
+            x = sx + 2 * ((tl >> 2) & 1) + (o >> 2); y = sy + 2 * ((tl >> 1) & 1) + ((o >> 1) & 1); z = sz + 2 * (tl & 1) + (o & 1);
+        } else {
+            x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2); y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1); z = oz0 + 2 * (tl & 3) + (o & 1);
+        }
         const int co = 16 * (NC * grp + cc) + 4 * c4;
         if (x < gX && y < gY && z < gZ && (!(WN_EXP & 32) || v.x == 123.456f)) {
             float *dst = p_out + ((size_t)(x * gY + y) * gZ + z) * a.out_stride + a.out_coff + co;
@@ -619,7 +689,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     }
 }
 
-template <int NC, int C3 = 0, int C2N = 0>
+template <int NC, int C3 = 0, int C2N = 0, bool MINI = false>
 __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -652,8 +722,8 @@ __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a
     }
     // waves (h, g): h = xi_x half, g = tile group; each wave serves every cout tile of the group
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-    if (h == 0) wino_wave<0, NC, C3, C2N>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
-    else wino_wave<1, NC, C3, C2N>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    if (h == 0) wino_wave<0, NC, C3, C2N, MINI>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    else wino_wave<1, NC, C3, C2N, MINI>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
 }
 
 // (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:
@@ -733,12 +803,12 @@ extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout
     return nprob >= 1 && wino_nc(X, Y, Z, cin, cout) > 0 ? 1 : 0;
 }
 
-template <int NC, int C3, int C2N>
+template <int NC, int C3, int C2N, bool MINI = false>
 static int launch_wino_inst(const WinoArgs &a, int64_t nwg, int nprob, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)lds_floats(NC) * sizeof(float);
+    constexpr size_t lds = (size_t)lds_floats_g<MINI>(NC) * sizeof(float);
     static Sis3dLdsOnce once;                                       // once per instantiation AND device
-    auto kern = conv3d_k3wino_kernel<NC, C3, C2N>;
+    auto kern = conv3d_k3wino_kernel<NC, C3, C2N, MINI>;
     if (sis3d_grant_lds(once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
     return sis3d_check_launch();
@@ -803,6 +873,37 @@ extern "C" int sis3d_conv3d_k3wino_ragged(const float *in, int cin, int cin_stri
     a.nbx = a.nby = a.nbz = 1;
     a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
     return launch_wino(a, 2, total_blocks, 1, as_stream(stream));
+}
+
+// ---- ragged batch on MINI geometry (r4): work items = (crop, quad of 4 x 4 x 4 minis, group of two cout tiles).  Descriptor table as
+// for sis3d_conv3d_k3wino_ragged, with nbx / nby / nbz = minis per axis (ceil(extent / 4)) and block0 counting quads x groups,
+// quads = ceil(minis / 4).  sis3d_ragged_tiling_k3wino_mini gives the mini edge (4), the minis per work item (4) and the groups.
+extern "C" int sis3d_ragged_tiling_k3wino_mini(int cin, int cout, int *mini_edge, int *minis_per_item, int *ngroups)
+{
+    if (!mini_edge || !minis_per_item || !ngroups) return SIS3D_EINVAL;
+    if ((cin % 8) || cin <= 0 || cout <= 0) return SIS3D_EUNSUPPORTED;
+    *mini_edge = 4; *minis_per_item = 4;
+    *ngroups = ((cout + 15) / 16 + 1) / 2;
+    return SIS3D_OK;
+}
+
+extern "C" int sis3d_conv3d_k3wino_ragged_mini(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
+                                               int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_items,
+                                               sis3d_stream_t stream)
+{
+    if (!in || !packed_w || !out || !desc_dev || ndesc <= 0 || total_items <= 0 || cin <= 0 || cout <= 0) return SIS3D_EINVAL;
+    if ((cin % 8) || (cin_stride % 4) || cin_stride < cin || out_stride < cout) return SIS3D_EUNSUPPORTED;
+    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    if (total_items > 0x7fffffff) return SIS3D_EUNSUPPORTED;
+    WinoArgs a;
+    for (int p = 0; p < WN_MAXP; ++p) { a.in[p] = in; a.wp[p] = packed_w; a.bias[p] = bias; a.out[p] = out; }
+    a.X = a.Y = a.Z = 1; a.cin_stride = cin_stride; a.cout = cout; a.ngroups = ((cout + 15) / 16 + 1) / 2; a.nk = cin / 4;
+    a.flags = flags; a.out_stride = out_stride; a.out_coff = 0;
+    a.nbx = a.nby = a.nbz = 1;
+    a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
+    a.w3p = a.b3 = a.res = a.w1n = a.b1n = nullptr; a.tout = a.out2 = nullptr;
+    a.res_stride = a.tout_stride = a.tout_coff = a.out2_stride = 0;
+    return launch_wino_inst<2, 0, 0, true>(a, total_items, 1, as_stream(stream));
 }
 
 // ---- Bottleneck body on the Winograd kernel (lib/nets/backbones.py:17-40): conv2 = Conv3d(planes, planes, 3, padding=1) + bias + ReLU

@@ -83,6 +83,8 @@ SIGNATURES = {
     "sis3d_conv3d_k3wino": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "sis3d_ragged_tiling_k3wino": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_conv3d_k3wino_ragged": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),
+    "sis3d_conv3d_k3wino_ragged_mini": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),
+    "sis3d_ragged_tiling_k3wino_mini": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "sis3d_conv3d_k3t16_brick": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sis3d_conv3d_k3t16": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int,
                                    c_vp]),

@@ -1164,6 +1164,9 @@ def _rag_dtypes():
     return _RAG_DT
 
 
+MASK_MINI = _os.environ.get("SIS3D_MASK_MINI", "1") != "0"     # A/B switch: ragged Winograd launches on MINI geometry (default on)
+
+
 class MaskPlan:
     """Everything of a ragged mask-head batch that depends only on the crop windows: the three descriptor tables (one
     upload), the packed activation buffers and the per-box output views.  Built on the host once; `mask_head_run` then
@@ -1245,6 +1248,25 @@ class MaskPlan:
             d3w["out_off"] = voffs[:-1] * C
             self.blocks_wino = int(blw[-1])
             self.wino = self.blocks_wino >= int(_os.environ.get("SIS3D_MASK_WINO_MIN", "200"))
+        # r4: the Winograd kernel on MINI geometry (work item = four 4 x 4 x 4 minis x two cout tiles): the crops are covered with
+        # 4-voxel granularity on every axis instead of 8 x 4 x 8 blocks -- fewer work items for the same boxes (924 minis = 231 quads
+        # against 304 blocks on the 16-box bench set: two rounds of the chip per layer instead of three)
+        self.wino_mini, self.items_mini = False, 0
+        d3m = np.zeros(0, dtype=rdt)
+        tm = [ctypes.c_int() for _ in range(3)]
+        if C % 8 == 0 and MASK_MINI and lib().sis3d_ragged_tiling_k3wino_mini(C, C, *[ctypes.byref(v) for v in tm]) == 0:
+            edge, per_item, mng = (v.value for v in tm)
+            nbm = -(-ext // edge)                                         # minis per axis
+            quads = -(-nbm.prod(1) // per_item)
+            blm = np.concatenate([[0], np.cumsum(quads * mng)])
+            d3m = np.zeros(n, dtype=rdt)
+            d3m["X"], d3m["Y"], d3m["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
+            d3m["nbx"], d3m["nby"], d3m["nbz"] = nbm[:, 0], nbm[:, 1], nbm[:, 2]
+            d3m["block0"] = blm[:-1]
+            d3m["in_off"] = voffs[:-1] * C
+            d3m["out_off"] = voffs[:-1] * C
+            self.items_mini = int(blm[-1])
+            self.wino_mini = self.wino and self.items_mini < self.blocks_wino
         # the same layers on the opt-in split-bf16 kernel (csrc/conv3d_b16.hip): 3x6x6 bricks, two cout tiles per workgroup
         self.b16, self.brick_b16, self.blocks_b16 = False, 4, 0
         d3b = np.zeros(0, dtype=rdt)
@@ -1269,7 +1291,8 @@ class MaskPlan:
         self.windows = [tuple(int(v) for v in r) for r in w]
         # ONE upload for the three descriptor tables (each is a blocking pageable copy)
         parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1),
-                 d3t.view(np.uint8).reshape(-1), d3b.view(np.uint8).reshape(-1), d3w.view(np.uint8).reshape(-1)]
+                 d3t.view(np.uint8).reshape(-1), d3b.view(np.uint8).reshape(-1), d3w.view(np.uint8).reshape(-1),
+                 d3m.view(np.uint8).reshape(-1)]
         pad = [(-p.size) % 16 for p in parts]
         host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
         self.devbuf = torch.from_numpy(host).to(device)
@@ -1279,7 +1302,8 @@ class MaskPlan:
         o4 = o3 + parts[3].size + pad[3]
         self.g3, self.g1, self.gp = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:o3]
         o5 = o4 + parts[4].size + pad[4]
-        self.g3t, self.g3b, self.g3w = self.devbuf[o3:o4], self.devbuf[o4:o5], self.devbuf[o5:]
+        o6 = o5 + parts[5].size + pad[5]
+        self.g3t, self.g3b, self.g3w, self.g3m = self.devbuf[o3:o4], self.devbuf[o4:o5], self.devbuf[o5:o6], self.devbuf[o6:]
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
         self.out = torch.empty(self.voxels, NC, device=device)
@@ -1310,6 +1334,10 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
         if SPLIT_BF16 and plan.b16 and getattr(pc, "_w", None) is not None:
             check(lib().sis3d_conv3d_k3b16_ragged(_ptr(src), C, C, _ptr(packed_b16(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                   _ptr(plan.g3b), n, plan.blocks_b16, plan.brick_b16, _stream()), "sis3d_conv3d_k3b16_ragged")
+        elif WINOGRAD and plan.wino_mini and getattr(pc, "_w", None) is not None:
+            check(lib().sis3d_conv3d_k3wino_ragged_mini(_ptr(src), C, C, _ptr(packed_wino(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
+                                                        _ptr(plan.g3m), n, plan.items_mini, _stream()), "sis3d_conv3d_k3wino_ragged_mini")
+            _tally_wino(2.0 * plan.voxels * C * C * 27)
         elif WINOGRAD and plan.wino and getattr(pc, "_w", None) is not None:
             check(lib().sis3d_conv3d_k3wino_ragged(_ptr(src), C, C, _ptr(packed_wino(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                    _ptr(plan.g3w), n, plan.blocks_wino, _stream()), "sis3d_conv3d_k3wino_ragged")

@@ -390,6 +390,15 @@ int sis3d_ragged_tiling_k3wino(int cin, int cout, int *bx, int *by, int *bz, int
 int sis3d_conv3d_k3wino_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout, int flags,
                                float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks, sis3d_stream_t stream);
 
+/* The same ragged batch on MINI geometry (r4): a work item is a QUAD of 4 x 4 x 4-voxel bricks (2 x 2 x 2 Winograd tiles each, taken
+ * in z-fastest order from the crop's ceil(X/4) x ceil(Y/4) x ceil(Z/4) grid of them) x one group of two cout tiles, so a crop is
+ * covered with 4-voxel granularity on every axis instead of 8 x 4 x 8 blocks.  Descriptors as above with nbx / nby / nbz = minis per
+ * axis and block0 = work items (quads x groups, quads = ceil(minis / 4)) in front of the crop; total_items = their sum.  Same
+ * arithmetic as sis3d_conv3d_k3wino_ragged (identical results: the tiles are the same, only their grouping differs). */
+int sis3d_ragged_tiling_k3wino_mini(int cin, int cout, int *mini_edge, int *minis_per_item, int *ngroups);
+int sis3d_conv3d_k3wino_ragged_mini(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout, int flags,
+                                    float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_items, sis3d_stream_t stream);
+
 /* nprob (<= 4) INDEPENDENT convolutions of identical shape in ONE launch (different input / weights / bias /
  * residual / output pointers; host arrays of device pointers, read at call time).  Used for the two RPN levels
  * (lib/nets/network.py:539,552): their 432 workgroups each leave 80 of the 256 CUs a workgroup short, a single

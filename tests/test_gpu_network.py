@@ -216,6 +216,18 @@ def test_mask_head_batched_equals_per_box(oracle):
         worst = max(worst, float((g - single).abs().max()))
     assert worst <= 1e-5
     report("mask head, 6 crops: Winograd ragged batch vs direct per-box launches, max |diff| on the sigmoid outputs %.1e" % worst)
+    # r4: the batch above ran on MINI geometry (quads of 4 x 4 x 4 bricks); the 8 x 4 x 8-block launch computes the same tiles in another
+    # grouping -> bit-identical outputs, with fewer work items
+    assert plan.wino_mini and plan.items_mini < plan.blocks_wino
+    ops.MASK_MINI = False
+    try:
+        plan8 = ops.MaskPlan(wins, 64, cfg.NUM_CLASSES, torch.device("cuda"))
+        assert plan8.wino and not plan8.wino_mini
+        blocks = [t.clone() for t in net.mask_backbone.forward_batched(data.cuda(), wins)]
+    finally:
+        ops.MASK_MINI = True
+    assert all(torch.equal(a, b) for a, b in zip(got, blocks))
+    report("mask head, 6 crops: %d work items on 4 x 4 x 4 minis vs %d on 8 x 4 x 8 blocks, outputs bit-identical" % (plan.items_mini, plan.blocks_wino))
     assert net.mask_backbone.forward_batched(data.cuda(), []) == []
 
 
