@@ -630,8 +630,11 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
             extra["mask_head_algorithmic_tflops"] = e0.mask_plan.flops / (mh_ms * 1e-3) / 1e12
             extra["mask_head_executed_gflop"] = executed_flops(e0.mask_plan.flops, mw) / 1e9
             extra["mask_head_fp32_frac"] = executed_flops(e0.mask_plan.flops, mw) / (mh_ms * 1e-3) / 1e12 / FP32_PEAK_TF
-            extra["mask_head_kernel"] = ("Winograd ragged launch for the four 64->64 k3 layers (%d work items)" % e0.mask_plan.blocks_wino
-                                         if (ops_mod().WINOGRAD and e0.mask_plan.wino) else "direct balanced kernel, ragged")
+            mp = e0.mask_plan
+            extra["mask_head_kernel"] = (
+                ("Winograd ragged launch on 4x4x4 minis for the four 64->64 k3 layers (%d work items; %d on 8x4x8 blocks)" % (mp.items_mini, mp.blocks_wino)
+                 if getattr(mp, "wino_mini", False) else "Winograd ragged launch for the four 64->64 k3 layers (%d work items)" % mp.blocks_wino)
+                if (ops_mod().WINOGRAD and mp.wino) else "direct balanced kernel, ragged")
     snap = None
     if rank == 0 and grp == 1:
         torch.cuda.synchronize()
