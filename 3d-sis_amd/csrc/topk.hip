@@ -151,13 +151,16 @@ __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict_
         __shared__ uint64_t cand2[FASTCAP];
         if (tid == 0) s_m = 0;
         __syncthreads();
-        const float btf = (float)bt;
+        // ANY superset of {bucket_of(v) >= bt} will do (the ordering below is exact on the composite keys), so the test is ONE float
+        // compare against a threshold a whole bucket below bt's lower edge: v >= thr is implied by bucket_of(v) >= bt whatever
+        // the rounding of (v - lo) * scale; NaN passes (!(v < thr)); bt <= 1 or a degenerate range takes everything.  r4: the
+        // three-clause test this replaces cost the single workgroup 5.2 us over 33k elements (tools/topk_phases.py).
+        const float thr = (bt <= 1 || !(bscale > 0.f)) ? -__builtin_huge_valf() : blo + ((float)bt - 1.0f) / bscale;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int i = tid + j * TPB;
             const float v = val[j];
-            // bucket_of(v) >= bt  <=>  !((v - lo) * scale < bt)   (NaN and >= hi land in the top bucket; bt == 0 takes everything)
-            if (i < n && (bt == 0 || !(v < bhi) || !((v - blo) * bscale < btf))) {
+            if (i < n && !(v < thr)) {
                 const uint32_t slot = atomicAdd(&s_m, 1u);
                 if (slot < FASTCAP) cand2[slot] = ((uint64_t)order_key(v) << 32) | (uint32_t)(~(uint32_t)i);
             }
@@ -168,6 +171,33 @@ __global__ __launch_bounds__(TPB) void topk_desc_kernel(const float *__restrict_
 #ifdef TOPK_TIMING
         if (tid == 0) ts[8] = m;
 #endif
+        if (m <= 1024) {
+            // r4: bitonic network over the m candidates padded with zeros (smaller than every composite) to a power of two: 36-55
+            // steps of one compare-exchange per thread; the rank sort it replaces makes every thread sweep m / P candidates with 64-bit
+            // compares (8.7 us for m = 481 on one workgroup's VALUs)
+            int p2 = 64;
+            while (p2 < m) p2 <<= 1;
+            for (int i = m + tid; i < p2; i += TPB) cand2[i] = 0;
+            __syncthreads();
+            for (int size = 2; size <= p2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    if (tid < p2 / 2) {
+                        const int lo = 2 * tid - (tid & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool desc = ((lo & size) == 0);
+                        const uint64_t x = cand2[lo], y = cand2[hi];
+                        if ((x < y) == desc) { cand2[lo] = y; cand2[hi] = x; }
+                    }
+                    __syncthreads();           // (wave-level fences for the stride <= 64 steps were measured: no gain, the steps are LDS-latency bound)
+                }
+            for (int i = tid; i < k; i += TPB) {
+                const uint32_t idx = ~(uint32_t)(cand2[i] & 0xffffffffu);
+                out_idx[i] = (int64_t)idx;
+                out_scores[i] = scores[idx];
+            }
+            TOPK_TS(4);
+            return;
+        }
         if (m <= FASTCAP) {
             // composite keys are unique (index in the low word): rank = number of strictly larger composites.  P threads
             // share a candidate (each sweeps 1/P of the table, partial counts meet by lane shuffles)
