@@ -9,6 +9,7 @@ may contract.  No torch dependency: the library is a plain C-ABI shared object
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -47,8 +48,13 @@ def build(force=False, verbose=True):
             if verbose:
                 print(" ".join(cmd), flush=True)
             running.append((cmd, subprocess.Popen(cmd)))
-        cmd, proc = running.pop(0)
-        if proc.wait() != 0:
+        # reap whichever job ends first (waiting on the head of the list leaves the pool idle behind one slow translation unit)
+        done = [i for i, (_, p) in enumerate(running) if p.poll() is not None]
+        if not done:
+            time.sleep(0.2)
+            continue
+        cmd, proc = running.pop(done[0])
+        if proc.returncode != 0:
             for _, other in running:
                 other.kill()
             raise subprocess.CalledProcessError(proc.returncode, cmd)

@@ -14,10 +14,11 @@ def main():
     wino = "--direct" not in sys.argv
     argv = [a for a in sys.argv if a != "--direct"]
     sys.argv = argv
-    name, wgs = ("conv3d_k3wino_kernel<2>", 216) if wino else ("conv3d_k3t16_kernel<6, 6, 12", 256)
+    # r4: the template grew parameters (NC, C3, C2N, MINI): the plain k3 conv is <2, 0, 0, false>
+    names, wgs = (("conv3d_k3wino_kernel<2>", "conv3d_k3wino_kernel<2, 0, 0, false>"), 216) if wino else (("conv3d_k3t16_kernel<6, 6, 12",), 256)
     rows = []
     for r in csv.DictReader(open(sys.argv[1])):
-        if name in r["Kernel_Name"] and int(r["Grid_Size_X"]) == wgs * 256 and int(r.get("Grid_Size_Y", 1)) == 1:
+        if any(n in r["Kernel_Name"] for n in names) and int(r["Grid_Size_X"]) == wgs * 256 and int(r.get("Grid_Size_Y", 1)) == 1:
             rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     rows.sort()
     first = [d for _, d in rows[:350]]
@@ -30,7 +31,7 @@ def main():
            "batch_means_us": [sum(timed[i:i + 50]) / 50 for i in range(0, len(timed) - 49, 50)], "warm_100_mean_us": sum(first[:100]) / max(1, len(first[:100])),
            "flop_per_launch": 2.0 * 6912 * 256 * 128 * 27}
     out["tflops"] = out["flop_per_launch"] / out["timed_250_mean_us"] / 1e6 if timed else None
-    out["frac_of_157.3TF"] = out["tflops"] / 157.3 if timed else None
+    out["frac_of_157.3TF"] = out["tflops"] / 157.3 if timed and not wino else None      # a fraction of the roof only for executed FLOPs
     if wino and timed:
         out["flop_per_launch_is"] = "ALGORITHMIC (direct-convolution count); the kernel executes 1/3.375 of it on the matrix pipe"
         out["executed_tflops"] = out["tflops"] / 3.375
