@@ -155,7 +155,13 @@ __device__ __forceinline__ void ds_read_b64_asm(f32x2 &dst, unsigned addr)
 // name captured variables inside a generic lambda
 __device__ __forceinline__ void load16_asm(f32x4 &dst, int byte_off, const float *base)
 {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+    // the base is uniform, but under SGPR pressure (the C3 = 128 Bottleneck tail keeps a dozen kernel-argument pointers live) hipcc parks
+    // it in VGPRs and then hands the asm a VGPR pair for its "s" operand (an assembler error, not a readfirstlane); ask for the scalar
+    // copy explicitly -- folded away wherever the value already sits in SGPRs
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const float *sbase = (const float *)(((unsigned long long)hi << 32) | lo);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c)
@@ -168,6 +174,13 @@ __device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &
 {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_all(f32x4 (&v)[2]) { wait_vmcnt<N>(v[0], v[1]); }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_all(f32x4 (&v)[3]) { wait_vmcnt<N>(v[0], v[1], v[2]); }
 template <int N>
@@ -307,7 +320,14 @@ struct NextV {
     }
 };
 
-template <int H, int NC, int C3 = 0, int C2N = 0, bool MINI = false>
+// WC (r4): waves along the cout axis.  WC = 2 puts EIGHT waves in the workgroup -- two per SIMD -- that share one raw brick and one
+// U ring: wave (wc, h, g) takes cout tile group wc (NC tiles), xi half h, tile group g.  Its 128 NC accumulator registers fit twice in
+// a SIMD's file only with NC = 1; the input transform is then computed by both waves of a SIMD (each for its own cout tile); the idea
+// was that while one of them issues VMEM / waits at the barrier, the other keeps the matrix pipe fed.  MEASURED (tools/r04_wc.sh,
+// -DWN_WC2_EXPERIMENT, rpn_net 128 -> 256): bit-identical output, 56.5 us against 52.3 -- the per-step costs beside the MFMAs (LDS-DMA
+// and VALU issue) are costs of the SIMD, not of the wave, so a second wave hides none of them and the duplicated transform adds
+// its 8 %.  Kept as a template parameter (the default WC = 1 is the shipped kernel); not instantiated in the library.
+template <int H, int NC, int C3 = 0, int C2N = 0, bool MINI = false, int WC = 1>
 __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp, int gX, int gY, int gZ, int nby, int nbz,
                                           int64_t in_off, int64_t out_off)
 {
@@ -316,9 +336,11 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if constexpr (WN_EXP & 64) ts0 = wall_clock64();       // experiment: 100 MHz timestamps of the phases, written instead of the output
     const int g = wave & 1;
+    const int wc = WC == 1 ? 0 : (wave >> 2);              // which NC cout tiles of the workgroup's NC WC
     const int li = lane & 15, kq = lane >> 4;
     using G_ = Geo<MINI>;
-    constexpr int NIT = G_::nit, NVOX = G_::nvox, PS = G_::ps, HZS = G_::hzs, CHS = G_::chs, RAW_STAGE = raw_stage<MINI>();
+    constexpr int NTHR = 256 * WC;                          // shadows the file-level constant: threads of THIS instantiation
+    constexpr int NVOX = G_::nvox, NIT = (NVOX + NTHR - 1) / NTHR, PS = G_::ps, HZS = G_::hzs, CHS = G_::chs, RAW_STAGE = raw_stage<MINI>();
     // block geometry: origin of the 8 x 4 x 8 block; MINI: origins of the workgroup's four 4 x 4 x 4 minis (minis 4 brick .. + 3 of the
     // problem's nmx x nmy x nmz grid, z fastest; a mini past the end sits far outside the grid: all zeros in, nothing stored)
     int ox0 = 0, oy0 = 0, oz0 = 0;
@@ -342,7 +364,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     const int nk = a.nk;
 
     float *raw = lds;                                   // [NRAW][4][CHS]
-    constexpr int B_STAGE = NC * B_TILE;                // floats of one K-step's U stage: NC cout tiles
+    constexpr int B_STAGE = NC * WC * B_TILE;           // floats of one K-step's U stage: NC WC cout tiles
     float *bst = lds + NRAW * RAW_STAGE;                // [NBST][NC][16][64][4]
 
     // ---- staging plan: item = halo voxel (4 channels = one float4 of its channels-last row).  Branch-free and VALU-free (an
@@ -392,9 +414,9 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         dst[2 * CHS] = sv[it][2];
         dst[3 * CHS] = sv[it][3];
     };
-    // U stage of K-step k: 16 NC wave-instructions of 1 KB, 4 NC per wave: block n = 4 NC wave + i = (cout tile n >> 4, xi quad n & 15)
+    // U stage of K-step k: 16 NC WC wave-instructions of 1 KB, 4 NC per wave: block n = 4 NC wave + i = (cout tile n >> 4, xi quad n & 15)
     constexpr int NFILL = 4 * NC;
-    const float *wbase = p_wp + (size_t)(NC * grp) * nk * B_TILE;
+    const float *wbase = p_wp + (size_t)(NC * WC * grp) * nk * B_TILE;
     const int woff = lane * 4;
     // a wave's NFILL blocks are consecutive in the packed weights and in the stage (NFILL divides 16): one global base and one LDS
     // base (M0) per four instructions, the 1 KB steps in between as the instructions' immediate offsets
@@ -413,7 +435,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // MINI: tile li of group g = mini 2 g + (li >> 3), tile (tx, ty, tz) = bits 2, 1, 0 of li inside it
     const int rbase = MINI ? kq * CHS + (2 * g + (li >> 3)) * G_::ms + (2 * ((li >> 2) & 1)) * PS + (2 * ((li >> 1) & 1)) * HZS + 2 * (li & 1)
                            : kq * CHS + (2 * (2 * g + txl)) * PS + (2 * ty) * HZS + 2 * tz;
-    const int bbase = H * 8 * 256 + lane * 4;
+    const int bbase = wc * NC * B_TILE + H * 8 * 256 + lane * 4;
 
     // ---- prologue: U stages 0 and 1 and raw stages 0 and 1 all in flight together (one wait), then V of step 0
     static_for<0, NFILL>([&](auto I) { fill_b_item(I, 0, 0); });
@@ -452,7 +474,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // the next step's first operands hide behind 512 cycles of matrix work instead of idling the pipe.
     // Loads / DMA of the steps past the end are clamped to the last step (harmless duplicates, landed before the final barrier):
     // no branches in the block.
-    static_assert(NIT == 3 || (NIT == 4 && NC == 2), "slots 41.. / 49.. hold the stores / loads of at most four staging items");
+    static_assert(NIT == 2 || NIT == 3 || (NIT == 4 && NC == 2), "slots 41.. / 49.. hold the stores / loads of at most four staging items");
     int cur = 0;                                         // k % 3: raw stage of step k, U stage of step k
     f32x4 bq[4][NC];                                     // ring over xi quads (slot q & 3), every cout tile of the group
     auto read_b = [&](auto Q, const float *bs) {
@@ -559,7 +581,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
                 }
             });
             if constexpr ((r >> 1) != H) {               // the partner finishes this row
-                float *scr = bst + ((g * NC + cc) * 4 + r) * (8 * 64) + lane;
+                float *scr = bst + (((2 * wc + g) * NC + cc) * 4 + r) * (8 * 64) + lane;
                 static_for<0, 8>([&](auto O) { scr[decltype(O)::value * 64] = P[cc][r][decltype(O)::value]; });
             }
         });
@@ -567,14 +589,14 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     __syncthreads();
     // finish rows r = 2H, 2H + 1: + partner's partial, + bias, ReLU; transpose through LDS (second U stage) so that a lane
     // stores 16 B = four consecutive couts of one voxel: [cc][voxel = (r', tile quad q4, o)][cout 16] per wave
-    float *tr = bst + B_STAGE + wave * (NC * 2 * 4 * 8 * 16);
+    float *tr = bst + B_STAGE + wave * (NC * 2 * 4 * 8 * 16);      // B_STAGE floats = the partner scratch above (2 WC NC x 4 rows x 512)
     static_for<0, NC>([&](auto C) {
         constexpr int cc = decltype(C)::value;
-        const int co = 16 * (NC * grp + cc) + j;
+        const int co = 16 * (NC * (WC * grp + wc) + cc) + j;
         const float bv = (a.bias[prob] && co < a.cout) ? a.bias[prob][co] : 0.f;
         static_for<0, 2>([&](auto RR) {
             constexpr int rr = decltype(RR)::value, r = 2 * H + rr;
-            const float *scr = bst + ((g * NC + cc) * 4 + r) * (8 * 64) + lane;
+            const float *scr = bst + (((2 * wc + g) * NC + cc) * 4 + r) * (8 * 64) + lane;
             static_for<0, 8>([&](auto O) {
                 constexpr int o = decltype(O)::value;
                 float v = (P[cc][r][o] + scr[o * 64]) + bv;
@@ -591,7 +613,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         // [cout tile][voxel row][16]; a row IS the B operand of the transposed tile GEMM of mfma16.h (lane (voxel li, kq) reads the
         // 16 B = channels 16 g + 4 kq .. + 3), so conv3 -> (+ bias, + residual, ReLU) -> next conv1 chains through registers exactly
         // as in pointwise.hip's pw16_kernel, on four voxel tiles of 16.  Weights: pw16 fragment order, straight from L2 (2-8 KB).
-        static_assert(NC == 2 && C3 % 16 == 0 && C2N % 16 == 0, "the tail needs every conv2 channel in the workgroup (cout = 32 = 16 NC)");
+        static_assert(NC == 2 && WC == 1 && C3 % 16 == 0 && C2N % 16 == 0, "the tail needs every conv2 channel in the workgroup (cout = 32 = 16 NC)");
         constexpr int NT3 = C3 / 16, NT2 = C2N / 16, NT2A = NT2 > 0 ? NT2 : 1;
         float4 w3[NT3][2], bb3[NT3];
         static_for<0, NT3>([&](auto N) {
@@ -607,8 +629,11 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
                 bb1n[n] = a.b1n ? *reinterpret_cast<const float4 *>(a.b1n + 16 * n + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
             });
         }
-        // all four tiles' residual rows are requested before the first GEMM (one L2 round trip for the wave)
-        float4 rres[4][NT3];
+        // residual rows: all four tiles' requested before the first GEMM (one L2 round trip for the wave) while they fit the register
+        // file beside the weights (C3 <= 64: 4 x NT3 float4); the C3 = 128 blocks (NT3 = 8) keep two tiles' rows and request tile t + 1's
+        // in front of tile t's GEMMs
+        constexpr int RDEPTH = NT3 <= 4 ? 4 : 2;
+        float4 rres[RDEPTH][NT3];
         bool okv[4];
         size_t vox[4];
         static_for<0, 4>([&](auto T) {
@@ -619,11 +644,16 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
             const int x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2), y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1), z = oz0 + 2 * (tl & 3) + (o & 1);
             okv[t] = x < gX && y < gY && z < gZ;
             vox[t] = okv[t] ? (size_t)(x * gY + y) * gZ + z : 0;
-            const float *rp = a.res + vox[t] * a.res_stride + 4 * q4;
-            static_for<0, NT3>([&](auto N) { rres[t][decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
         });
+        auto load_res = [&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const float *rp = a.res + vox[t] * a.res_stride + 4 * q4;
+            static_for<0, NT3>([&](auto N) { rres[t % RDEPTH][decltype(N)::value] = *reinterpret_cast<const float4 *>(rp + 16 * decltype(N)::value); });
+        };
+        static_for<0, (RDEPTH == 4 ? 4 : 1)>([&](auto T) { load_res(T); });
         static_for<0, 4>([&](auto T) {
             constexpr int t = decltype(T)::value;
+            if constexpr (RDEPTH == 2 && t + 1 < 4) load_res(std::integral_constant<int, t + 1>{});
             float4 yv[2];
             static_for<0, 2>([&](auto G) { yv[decltype(G)::value] = *reinterpret_cast<const float4 *>(tr + ((decltype(G)::value * 64 + 16 * t + j) * 16 + 4 * q4)); });
             f32x4 acc3[NT3];
@@ -632,8 +662,9 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
             static_for<0, NT3>([&](auto N) {
                 constexpr int n = decltype(N)::value;
                 float4 v;
-                v.x = acc3[n][0] + bb3[n].x + rres[t][n].x; v.y = acc3[n][1] + bb3[n].y + rres[t][n].y;
-                v.z = acc3[n][2] + bb3[n].z + rres[t][n].z; v.w = acc3[n][3] + bb3[n].w + rres[t][n].w;
+                constexpr int ts = t % RDEPTH;
+                v.x = acc3[n][0] + bb3[n].x + rres[ts][n].x; v.y = acc3[n][1] + bb3[n].y + rres[ts][n].y;
+                v.z = acc3[n][2] + bb3[n].z + rres[ts][n].z; v.w = acc3[n][3] + bb3[n].w + rres[ts][n].w;
                 zv[n] = relu4(v, true);
                 if (okv[t]) *reinterpret_cast<float4 *>(a.tout + vox[t] * a.tout_stride + a.tout_coff + 16 * n + 4 * q4) = zv[n];
             });
@@ -667,7 +698,7 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         } else {
             x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2); y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1); z = oz0 + 2 * (tl & 3) + (o & 1);
         }
-        const int co = 16 * (NC * grp + cc) + 4 * c4;
+        const int co = 16 * (NC * (WC * grp + wc) + cc) + 4 * c4;
         if (x < gX && y < gY && z < gZ && (!(WN_EXP & 32) || v.x == 123.456f)) {
             float *dst = p_out + ((size_t)(x * gY + y) * gZ + z) * a.out_stride + a.out_coff + co;
             if (co + 3 < a.cout && (((a.out_stride | a.out_coff) & 3) == 0)) {
@@ -689,8 +720,8 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     }
 }
 
-template <int NC, int C3 = 0, int C2N = 0, bool MINI = false>
-__global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a)
+template <int NC, int C3 = 0, int C2N = 0, bool MINI = false, int WC = 1>
+__global__ __launch_bounds__(NTHR * WC, 1) void conv3d_k3wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // work list: cout group major, block minor; every XCD (block b runs on XCD b % 8, private L2) takes one contiguous range
@@ -720,10 +751,11 @@ __global__ __launch_bounds__(NTHR, 1) void conv3d_k3wino_kernel(const WinoArgs a
         grp = wid / nbr;
         brick = wid - grp * nbr;
     }
-    // waves (h, g): h = xi_x half, g = tile group; each wave serves every cout tile of the group
-    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-    if (h == 0) wino_wave<0, NC, C3, C2N, MINI>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
-    else wino_wave<1, NC, C3, C2N, MINI>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    // waves (wc, h, g): h = xi_x half, g = tile group, wc = cout tile group (WC = 2: waves w and w + 4 share a SIMD); each wave serves
+    // NC cout tiles
+    const int h = __builtin_amdgcn_readfirstlane((threadIdx.x >> 7) & 1);
+    if (h == 0) wino_wave<0, NC, C3, C2N, MINI, WC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    else wino_wave<1, NC, C3, C2N, MINI, WC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
 }
 
 // (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:
@@ -788,14 +820,34 @@ extern "C" int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, 
 // >= ~200 (block, cout group) items to fill the chip -- with two cout tiles per wave if that still gives 200 (the input
 // transform is shared by both), else with one -- and a channel loop long enough to amortise ~10 us of prologue + output
 // transform.  Measured (tools/wino_bench.cpp, us, direct -> Winograd): rpn_net 128->256 @24x12x24: 102 -> 58 (pair 194 -> 112).
+#include <atomic>
+static std::atomic<int> g_shared_chip{0};       // sis3d_conv3d_k3wino_set_shared_chip
+
 static int wino_nc(int X, int Y, int Z, int cin, int cout)
 {
     if (X <= 0 || Y <= 0 || Z <= 0 || cin < 64 || cout < 64 || (cin % 8)) return 0;
     const int64_t blocks = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ);
     const int nt = (cout + 15) / 16;
     if (blocks * ((nt + 1) / 2) >= 200) return 2;
-    if (blocks * nt >= 200 && cin >= 128) return 1;
+    // shared chip (several chunks in flight): what counts is CU-time, not the launch's own duration.  A Winograd workgroup of two
+    // cout tiles does the work of ~6.75 direct-kernel workgroups' MFMAs, so even a layer with only ~50 work items (the 64 -> 64
+    // convs of geometry2's Bottlenecks: 27 blocks x 2 cout pairs) costs the chip less on this kernel -- 54 CUs x ~27 us against
+    // 256 x ~15 -- although alone it takes longer than the direct kernel's 17 us (env SIS3D_WINO_SHARED_MIN: work items needed)
+    static const int shared_min = [] { const char *e = getenv("SIS3D_WINO_SHARED_MIN"); return e ? atoi(e) : 48; }();
+    if (g_shared_chip.load(std::memory_order_relaxed) && blocks * ((nt + 1) / 2) >= shared_min) return 2;
+    if (blocks * nt >= 200 && cin >= 128) {
+        // one cout tile per workgroup fills the chip when the launch has it alone (geometry2[0]: 216 work items, 34 us; on a shared
+        // chip the rule above has already given it two: 108 work items x ~50 us, tools/r04_exp1.sh: 1.958 -> 1.992 G voxels/s with
+        // three chunks in flight, one chunk alone 0.295 -> 0.308 ms)
+        return 1;
+    }
     return 0;
+}
+
+extern "C" int sis3d_conv3d_k3wino_set_shared_chip(int on)
+{
+    g_shared_chip.store(on ? 1 : 0, std::memory_order_relaxed);
+    return SIS3D_OK;
 }
 
 extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob)
@@ -803,22 +855,28 @@ extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout
     return nprob >= 1 && wino_nc(X, Y, Z, cin, cout) > 0 ? 1 : 0;
 }
 
-template <int NC, int C3, int C2N, bool MINI = false>
+template <int NC, int C3, int C2N, bool MINI = false, int WC = 1>
 static int launch_wino_inst(const WinoArgs &a, int64_t nwg, int nprob, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)lds_floats_g<MINI>(NC) * sizeof(float);
+    constexpr size_t lds = (size_t)lds_floats_g<MINI>(NC * WC) * sizeof(float);
     static Sis3dLdsOnce once;                                       // once per instantiation AND device
-    auto kern = conv3d_k3wino_kernel<NC, C3, C2N, MINI>;
+    auto kern = conv3d_k3wino_kernel<NC, C3, C2N, MINI, WC>;
     if (sis3d_grant_lds(once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR * WC), lds, st, a);
     return sis3d_check_launch();
 }
 
-static int launch_wino(WinoArgs &a, int nc, int64_t nwg, int nprob, hipStream_t st)
+// nc = cout tiles per WAVE, wc = waves along cout (cout tiles per workgroup = nc wc)
+static int launch_wino(WinoArgs &a, int nc, int wc, int64_t nwg, int nprob, hipStream_t st)
 {
     if (nwg <= 0 || nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     a.w3p = a.b3 = a.res = a.w1n = a.b1n = nullptr; a.tout = a.out2 = nullptr;
     a.res_stride = a.tout_stride = a.tout_coff = a.out2_stride = 0;
+#ifdef WN_WC2_EXPERIMENT    // measured and left out of the library (r4): 56.5 us against 52.3 on rpn_net, bit-identical output -- see wino_wave
+    if (wc == 2) return nc == 1 ? launch_wino_inst<1, 0, 0, false, 2>(a, nwg, nprob, st) : SIS3D_EUNSUPPORTED;
+#else
+    if (wc != 1) return SIS3D_EUNSUPPORTED;
+#endif
     return nc == 2 ? launch_wino_inst<2, 0, 0>(a, nwg, nprob, st) : launch_wino_inst<1, 0, 0>(a, nwg, nprob, st);
 }
 
@@ -840,11 +898,17 @@ extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, in
     static const int force_nc = [] { const char *e = getenv("SIS3D_WINO_NC"); return e ? atoi(e) : 0; }();      // tuning hook
     int nc = force_nc == 1 || force_nc == 2 ? force_nc : wino_nc(X, Y, Z, cin, cout);
     if (nc == 0) nc = 2;                                 // called directly on a layer the dispatch rule would not send here
-    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ngroups = ((cout + 15) / 16 + nc - 1) / nc; a.nk = cin / 4;
+    // two cout tiles per workgroup either as one wave with two tiles (nc 2, wc 1) or as two waves per SIMD with one each (nc 1, wc 2)
+    int wc = 1;
+#ifdef WN_WC2_EXPERIMENT
+    static const int force_wc = [] { const char *e = getenv("SIS3D_WINO_WC"); return e ? atoi(e) : 0; }();      // tuning hook
+    if (nc == 2 && force_wc == 2) { nc = 1; wc = 2; }
+#endif
+    a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ngroups = ((cout + 15) / 16 + nc * wc - 1) / (nc * wc); a.nk = cin / 4;
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
     a.nbx = cdiv(X, VX); a.nby = cdiv(Y, VY); a.nbz = cdiv(Z, VZ);
     a.rag = nullptr; a.nrag = 0;
-    return launch_wino(a, nc, (int64_t)a.nbx * a.nby * a.nbz * a.ngroups, nprob, as_stream(stream));
+    return launch_wino(a, nc, wc, (int64_t)a.nbx * a.nby * a.nbz * a.ngroups, nprob, as_stream(stream));
 }
 
 // ---- ragged batch: every detected box's mask-head crop (lib/nets/network.py:303-317, backbones.py:243-249) through ONE launch per k3
@@ -872,7 +936,7 @@ extern "C" int sis3d_conv3d_k3wino_ragged(const float *in, int cin, int cin_stri
     a.flags = flags; a.out_stride = out_stride; a.out_coff = 0;
     a.nbx = a.nby = a.nbz = 1;
     a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
-    return launch_wino(a, 2, total_blocks, 1, as_stream(stream));
+    return launch_wino(a, 2, 1, total_blocks, 1, as_stream(stream));
 }
 
 // ---- ragged batch on MINI geometry (r4): work items = (crop, quad of 4 x 4 x 4 minis, group of two cout tiles).  Descriptor table as
@@ -903,7 +967,11 @@ extern "C" int sis3d_conv3d_k3wino_ragged_mini(const float *in, int cin, int cin
     a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
     a.w3p = a.b3 = a.res = a.w1n = a.b1n = nullptr; a.tout = a.out2 = nullptr;
     a.res_stride = a.tout_stride = a.tout_coff = a.out2_stride = 0;
+#ifdef WN_DEV_PLAIN_ONLY
+    return SIS3D_EUNSUPPORTED;
+#else
     return launch_wino_inst<2, 0, 0, true>(a, total_items, 1, as_stream(stream));
+#endif
 }
 
 // ---- Bottleneck body on the Winograd kernel (lib/nets/backbones.py:17-40): conv2 = Conv3d(planes, planes, 3, padding=1) + bias + ReLU
@@ -913,9 +981,14 @@ extern "C" int sis3d_conv3d_k3wino_ragged_mini(const float *in, int cin, int cin
 // expected to win (enough 8 x 4 x 8 blocks to fill the chip: the 48 x 24 x 48 maps of geometry1 / color).
 extern "C" int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int c3, int c2n)
 {
-    if (planes != 32 || !(c3 == 32 || c3 == 64) || !(c2n == 0 || c2n == 32)) return 0;
-    if (c3 == 64 && c2n != 0) return 0;
-    return (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ) >= 200 ? 1 : 0;
+    if (planes != 32 || !(c3 == 32 || c3 == 64 || c3 == 128) || !(c2n == 0 || c2n == 32)) return 0;
+    if (c3 != 32 && c2n != 0) return 0;
+    const int64_t blocks = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ);
+    // shared chip (sis3d_conv3d_k3wino_set_shared_chip): CU-time counts, not the launch's own duration -- the Bottleneck(128, 32) bodies
+    // of the 24 x 12 x 24 maps as 27 fat work items instead of 256 thin ones (see wino_nc)
+    if (g_shared_chip.load(std::memory_order_relaxed) && blocks >= 24) return 1;
+    if (c3 == 128) return 0;
+    return blocks >= 200 ? 1 : 0;
 }
 
 extern "C" int sis3d_bottleneck_wino(const float *y1, int X, int Y, int Z, int planes, const float *w2_wino, const float *b2,
@@ -938,8 +1011,14 @@ extern "C" int sis3d_bottleneck_wino(const float *y1, int X, int Y, int Z, int p
     const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz;
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     const hipStream_t st = as_stream(stream);
+#ifndef WN_DEV_PLAIN_ONLY                                   // (development builds of tools/wino_bench.cpp compile the plain kernels only)
     if (c3 == 32 && c2n == 0) return launch_wino_inst<2, 32, 0>(a, nwg, 1, st);
     if (c3 == 32 && c2n == 32) return launch_wino_inst<2, 32, 32>(a, nwg, 1, st);
     if (c3 == 64 && c2n == 0) return launch_wino_inst<2, 64, 0>(a, nwg, 1, st);
+    // (128, 32) is not instantiated: with both weight sets of the tail live hipcc copies the kernel arguments to scratch and spills 43
+    // registers (and the kernel faulted); the caller runs the next block's conv1 as its own pointwise launch instead (ops.bottleneck16)
+    if (c3 == 128 && c2n == 0) return launch_wino_inst<2, 128, 0>(a, nwg, 1, st);
+#endif
+    (void)st;
     return SIS3D_EUNSUPPORTED;
 }

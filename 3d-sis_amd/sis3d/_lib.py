@@ -78,6 +78,7 @@ SIGNATURES = {
     "sis3d_conv_k3t16_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3t16_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d_k3wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sis3d_conv3d_k3wino_set_shared_chip": (c_int, [c_int]),
     "sis3d_conv_k3wino_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3wino_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d_k3wino": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp]),

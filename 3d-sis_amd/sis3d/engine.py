@@ -256,6 +256,7 @@ class PipelinedEngines:
     def prepare(self, warmup=2):
         # the brick choice is made at launch (= capture) time: set the cap for the captures, restore afterwards
         ops.lib().sis3d_conv3d_k3t16_set_brick_cap(self._brick_cap)
+        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1 if len(self.engines) >= 2 else 0)
         try:
             for e, s in zip(self.engines, self.streams):
                 with torch.cuda.stream(s):
@@ -263,6 +264,7 @@ class PipelinedEngines:
             torch.cuda.synchronize()
         finally:
             ops.lib().sis3d_conv3d_k3t16_set_brick_cap(0)
+            ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
         return self
 
     def load(self, i, *a, **kw):
@@ -294,6 +296,7 @@ class PipelinedEngines:
         main = torch.cuda.Stream()
         main.wait_stream(torch.cuda.current_stream())
         ops.lib().sis3d_conv3d_k3t16_set_brick_cap(self._brick_cap)
+        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1 if len(self.engines) >= 2 else 0)
         try:
             with torch.no_grad():
                 g = torch.cuda.CUDAGraph()
@@ -320,6 +323,7 @@ class PipelinedEngines:
             torch.cuda.synchronize()
         finally:
             ops.lib().sis3d_conv3d_k3t16_set_brick_cap(0)
+            ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
         return g, main
 
     def join(self):

@@ -692,6 +692,16 @@ def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick
             return bottleneck_wino(y1, pc2, pc3, residual, out=out, out_coff=out_coff, stage=stage)
         except Sis3dUnsupported:
             pass
+    elif WINOGRAD and BNECK_WINO and brick < 0 and spc is not None and out is None and spc.packed_pw16 is not None and \
+            lib().sis3d_bottleneck_wino_prefer(X, Y, Z, pl, pc3.cout, 0):
+        # shared chip, Bottleneck(128, 32) of the 24 x 12 x 24 maps: the body on the Winograd kernel (27 work items) and the NEXT block's
+        # conv1 as its own pointwise launch -- the kernel has no instantiation that holds both 128-channel weight sets of the tail
+        try:
+            main, _ = bottleneck_wino(y1, pc2, pc3, residual)
+            so, _ = conv3d_pw16(main, spc, relu=True)
+            return main, so
+        except Sis3dUnsupported:
+            pass
     if lib().sis3d_bottleneck16_brick(X, Y, Z, pl) < 0 and brick < 0:
         raise Sis3dUnsupported("bottleneck16: the two-launch path serves this grid")
     if out is None:

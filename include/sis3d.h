@@ -377,6 +377,10 @@ int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int Y, int Z, 
 /* 1 when the Winograd kernel is expected to beat sis3d_conv3d_k3t16 on this layer (enough (block, cout pair) work items to fill
  * the chip; measured table in csrc/conv3d_wino.hip), else 0: the host-side dispatch rule */
 int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob);
+/* process-wide hint (r4), like sis3d_conv3d_k3t16_set_brick_cap: on != 0 says that launches made from now on share the chip with
+ * other streams' kernels (several chunks in flight), so layers that would take ONE cout tile per workgroup to fill the chip alone
+ * (geometry2[0]) take two -- fewer, longer work items, less CU-time.  Results are identical either way. */
+int sis3d_conv3d_k3wino_set_shared_chip(int on);
 size_t sis3d_conv_k3wino_packed_floats(int cout, int cin);
 int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
 int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,

@@ -15,7 +15,8 @@ def main():
     argv = [a for a in sys.argv if a != "--direct"]
     sys.argv = argv
     # r4: the template grew parameters (NC, C3, C2N, MINI): the plain k3 conv is <2, 0, 0, false>
-    names, wgs = (("conv3d_k3wino_kernel<2>", "conv3d_k3wino_kernel<2, 0, 0, false>"), 216) if wino else (("conv3d_k3t16_kernel<6, 6, 12",), 256)
+    names, wgs = (("conv3d_k3wino_kernel<2>", "conv3d_k3wino_kernel<2, 0, 0, false>", "conv3d_k3wino_kernel<2, 0, 0, false, 1>"), 216) if wino \
+        else (("conv3d_k3t16_kernel<6, 6, 12",), 256)
     rows = []
     for r in csv.DictReader(open(sys.argv[1])):
         if any(n in r["Kernel_Name"] for n in names) and int(r["Grid_Size_X"]) == wgs * 256 and int(r.get("Grid_Size_Y", 1)) == 1:

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "sis3d.h"
 
@@ -16,7 +17,9 @@ int main(int argc, char **argv)
     int nprob = argc > 6 ? atoi(argv[6]) : 1;
     size_t nin = (size_t)X * Y * Z * cin, nout = (size_t)X * Y * Z * cout, nw = (size_t)cout * cin * 27;
     std::vector<float> h(nin > nw ? nin : nw);
-    srand(1);
+    // own generator: the HIP runtime's threads call rand() too, so srand / rand are not reproducible here
+    unsigned long long rs = 88172645463325252ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (int)((rs >> 20) % 2001); };
     float *in[4], *out[4], *wp[4], *w, *bias;
     const float *cin_p[4], *cwp[4], *cb[4];
     hipMalloc(&w, nw * 4);
@@ -25,9 +28,9 @@ int main(int argc, char **argv)
     size_t np = sis3d_conv_k3wino_packed_floats(cout, cin);
     for (int p = 0; p < nprob; ++p) {
         hipMalloc(&in[p], nin * 4); hipMalloc(&out[p], nout * 4); hipMalloc(&wp[p], np * 4);
-        for (size_t i = 0; i < nin; ++i) { float v = (rand() % 2001 - 1000) * 1e-3f; h[i] = v > 0 ? v : 0; }
+        for (size_t i = 0; i < nin; ++i) { float v = (rnd() - 1000) * 1e-3f; h[i] = v > 0 ? v : 0; }
         hipMemcpy(in[p], h.data(), nin * 4, hipMemcpyHostToDevice);
-        for (size_t i = 0; i < nw; ++i) h[i] = (rand() % 2001 - 1000) * 5e-5f;
+        for (size_t i = 0; i < nw; ++i) h[i] = (rnd() - 1000) * 5e-5f;
         hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice);
         if (sis3d_conv_k3wino_pack_weight(w, cout, cin, wp[p], nullptr)) return 1;
         cin_p[p] = in[p]; cwp[p] = wp[p]; cb[p] = bias;
@@ -50,6 +53,14 @@ int main(int argc, char **argv)
     double fl = 2.0 * X * Y * Z * cout * (double)cin * 27 * nprob;
     printf("WN_EXP=%d %d->%d %dx%dx%d x%d: %.1f us  (%.1f TF algorithmic, %.1f TF executed)\n", WN_EXP, cin, cout, X, Y, Z, nprob, best * 1e3,
            fl / best / 1e9, fl / 3.375 / best / 1e9);
+    {   // order-sensitive checksum of problem 0's output: equal between variants that promise bit-identical results (SIS3D_WINO_WC=1 / 2)
+        std::vector<float> o(nout);
+        hipMemcpy(o.data(), out[0], nout * 4, hipMemcpyDeviceToHost);
+        unsigned long long hsh = 1469598103934665603ull;
+        double sum = 0;
+        for (size_t i = 0; i < nout; ++i) { unsigned u; memcpy(&u, &o[i], 4); hsh = (hsh ^ u) * 1099511628211ull; sum += o[i]; }
+        printf("  output checksum %016llx  sum %.6f  first %g %g %g %g  in0 %g %g\n", hsh, sum, o[0], o[1], o[1000], o[nout - 1], h[0], h[1]);
+    }
     if (WN_EXP & 64) {          // phase timestamps (ns) written by thread 0 of every workgroup in place of the output
         hipMemset(out[0], 0, nout * 4);
         launch();
