@@ -588,13 +588,32 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
         extra.update(eng.engines[0].mask_stats())
     single_ms = None
     if rank == 0:
-        # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose)
+        # latency of ONE chunk on an otherwise idle GPU (single stream, serialised on purpose).  Its own engine, captured the way a
+        # caller with one chunk would (no shared-chip hint): the pipelines above took the dispatch for several chunks in flight --
+        # fewer, fatter Winograd work items -- which is slower when a chunk has the chip alone
+        torch.cuda.synchronize()
+        if nfl >= 2 and grp == 1 and not args.no_graph and not (workload == "images" and (args.rgb or from_depth)):
+            from sis3d.engine import ChunkEngine
+            solo = ChunkEngine(net, stage=stage, **kw)
+            src = eng.engines[0]
+            solo.scenes[0].copy_(src.scenes[0])
+            if solo.use_images:
+                solo.feats_[0].copy_(src.feats_[0]); solo.i3d_[0].copy_(src.i3d_[0]); solo.i2d_[0].copy_(src.i2d_[0])
+            solo.prepare(warmup=2)
+            one = solo.run
+        else:
+            solo, one = None, (lambda: eng.run(0))
+        for _ in range(5):
+            one()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(50):
-            eng.run(0)
+            one()
             torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 50 * 1e3
+        extra["single_chunk_latency_is"] = ("one chunk with the chip to itself, on an engine captured for that case (sis3d.engine.ChunkEngine)"
+                                            if solo is not None else "pipeline 0's graph replayed alone")
+        del solo
         if masks and eng.engines[0].mask_plan is not None:
             # the mask head alone on the same fixed detection set (one chunk, nothing else on the GPU): captured graph of the six
             # ragged launches, HIP events around 50 replays -> mask_head_ms / mask_head_tf (algorithmic FLOPs / time)
