@@ -95,6 +95,8 @@ def parse(argv=None):
                     "(csrc/enet.hip, own captured graph) runs inside the timed step (BASELINE config[3] from pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE) over the "
+                    "dominant kernel at the end of an N = 1 run; `roofline.traffic` then is the committed figure of profiles/")
     ap.add_argument("--no-split-line", action="store_true", help="skip the separately reported split-bf16 measurement")
     ap.add_argument("--no-side-workloads", action="store_true", help="time only the headline workload (no chunk_pipeline / scene side keys)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -276,21 +278,27 @@ def executed_flops(algorithmic, wino_algorithmic):
     return algorithmic - wino_algorithmic * (1.0 - 1.0 / WINOGRAD_REDUCTION)
 
 
-def wino_accounting(net):
+def wino_accounting(net, shared=False):
     """ALGORITHMIC FLOPs of the launches that take the Winograd kernel, in the backbone proper and in backbone + RPN of one chunk:
-    one eager pass of each with ops.flop_tally on (whatever the dispatch rule sends there today is what gets counted)."""
+    one eager pass of each with ops.flop_tally on (whatever the dispatch rule sends there today is what gets counted).  shared: count
+    under the shared-chip dispatch (sis3d_conv3d_k3wino_set_shared_chip), which is what pipelines of several chunks in flight capture --
+    more layers take the Winograd kernel there, so fewer FLOPs are executed."""
     import torch
     from sis3d import ops, synthetic
     scene = synthetic.synth_chunk(0).cuda().float()
     out = {}
-    with torch.no_grad():
-        for name, fn in (("backbone", net.backbone_only), ("backbone_rpn", net.backbone_rpn)):
-            ops.flop_tally(True)
-            try:
-                fn(scene)
-            finally:
-                out[name] = ops.flop_tally(False)["wino_algorithmic_flops"]
-    torch.cuda.synchronize()
+    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1 if shared else 0)
+    try:
+        with torch.no_grad():
+            for name, fn in (("backbone", net.backbone_only), ("backbone_rpn", net.backbone_rpn)):
+                ops.flop_tally(True)
+                try:
+                    fn(scene)
+                finally:
+                    out[name] = ops.flop_tally(False)["wino_algorithmic_flops"]
+        torch.cuda.synchronize()
+    finally:
+        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
     return out
 
 
@@ -353,6 +361,43 @@ def pmc_traffic(direct=False):
         except Exception:
             continue
     return None, None
+
+
+def live_pmc_traffic(timeout_s=90):
+    """HBM bytes per launch of the dominant kernel measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE -- each in its
+    own pass, with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over 40 eager launches of the rpn_net layer (tools/wino_pmc.py), as
+    child processes of rank 0 after the timed regions.  -> (bytes | None, dict describing the collection)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, {"error": "rocprofv3 not found"}
+    vals, info = {}, {"tool": "rocprofv3 --kernel-trace --pmc <counter> -- python tools/wino_pmc.py rpn", "launches": 40}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sis3d_pmc_", dir="/tmp")
+        try:
+            subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                            os.path.join(ROOT, "tools", "wino_pmc.py"), "rpn"], cwd="/tmp", env=env, timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            v = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k3wino" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+                        v.append(float(r["Counter_Value"]))
+            if not v:
+                return None, dict(info, error="no %s rows for the Winograd kernel" % ctr)
+            v.sort()
+            vals[ctr] = v[len(v) // 2]
+        except Exception as e:
+            return None, dict(info, error="%s pass: %s: %s" % (ctr, type(e).__name__, e))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    info.update({"FETCH_SIZE_KB_median": vals["FETCH_SIZE"], "WRITE_SIZE_KB_median": vals["WRITE_SIZE"],
+                 "formula": "2 x FETCH_SIZE (gfx950: the counter takes 64 B per 128 B request) + WRITE_SIZE, KB -> B"})
+    return int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024), info
 
 
 def roofline_entry(kt, kt_direct, winograd):
@@ -816,7 +861,10 @@ def main(argv=None):
         return sc
 
     stages = None
-    wino = wino_accounting(net) if rank == 0 and workload != "images" else None
+    wino = wino_accounting(net) if rank == 0 and workload != "images" else None                  # one chunk alone (stages)
+    # the step's own accounting: pipelines of >= 2 chunks in flight capture the shared-chip dispatch
+    nfl_step = max(1, args.inflight)
+    wino_step = wino_accounting(net, shared=(nfl_step >= 2 and not args.no_graph)) if wino is not None else None
     if rank == 0 and world == 1 and workload == "backbone_rpn" and not args.no_stages and not args.no_graph:
         stages = time_stages(net, wino)
     side = {}
@@ -931,16 +979,26 @@ def main(argv=None):
             "roofline": roofline_entry(kt, kt_direct, ops.WINOGRAD),
             "step_roofline": {"hbm_frac": algo["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "hbm_gbs_algorithmic": algo["bytes"] / (ms * 1e-3) / 1e9,
-                              **({"fp32_frac": executed_flops(algo["flops"], wino["backbone_rpn"] * nchunk_step) / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
-                                  "executed_gflop_per_step": executed_flops(algo["flops"], wino["backbone_rpn"] * nchunk_step) / 1e9,
-                                  "fp32_frac_is": "executed MFMA FLOPs of backbone + RPN (Winograd layers: algorithmic / 3.375) / time / 157.3 TF"}
-                                 if wino is not None else {}),
+                              **({"fp32_frac": executed_flops(algo["flops"], wino_step["backbone_rpn"] * nchunk_step) / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                                  "executed_gflop_per_step": executed_flops(algo["flops"], wino_step["backbone_rpn"] * nchunk_step) / 1e9,
+                                  "fp32_frac_is": "executed MFMA FLOPs of backbone + RPN (Winograd layers: algorithmic / 3.375; counted under the "
+                                                  "dispatch regime the step's pipelines captured) / time / 157.3 TF"}
+                                 if wino_step is not None else {}),
                               "algorithmic_tflops": algo["flops"] / (ms * 1e-3) / 1e12,
                               "binding": "fp32 FLOPs (AI 163 FLOP/B >> 20 FLOP/B machine balance)"},
         }
         line.update(side)
         if stages is not None:
             line["stages"] = stages
+        if world == 1 and ops.WINOGRAD and not args.no_live_pmc and not args.no_graph:
+            # the dominant kernel's HBM traffic measured by this run's own counter passes; the committed figure stays beside it
+            tb, how = live_pmc_traffic()
+            r = line["roofline"]
+            r["traffic_committed"], r["traffic_committed_source"] = r["traffic"], r["traffic_source"]
+            if tb:
+                r["traffic"], r["traffic_source"] = tb, "live: PMC passes of this run"
+                r["traffic_ratio"] = tb / DOMINANT_BYTES
+            r["traffic_live"] = how
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(workload, sd, cfg, args.cpu_seconds)
     if use_dist:
