@@ -117,6 +117,24 @@ def test_maxpool3(ops):
     assert torch.equal(ops.maxpool3(cl(x2)).cpu(), F.max_pool3d(x2, 3, 1, 1))
 
 
+@pytest.mark.parametrize("dims,c", [((24, 12, 24), 128), ((13, 9, 11), 64), ((7, 20, 31), 32), ((48, 24, 48), 64)])
+def test_maxpool3_separable_lds_form(ops, dims, c):
+    """r4: the brick / LDS form (csrc/pool_misc.hip maxpool3_lds_kernel) on grids that are not multiples of its 6^3 brick, into a channel
+    range of a wider tensor, incl. -inf / equal values: bit-identical to nn.MaxPool3d(3,1,1) (backbones.py:206,210,220) and to the
+    tap-by-tap kernel"""
+    g = torch.Generator().manual_seed(dims[0] + c)
+    x = torch.randn(1, c, *dims, generator=g)
+    x[0, :, 0, 0, 0] = float("-inf")
+    x[0, 1] = 0.25
+    want = F.max_pool3d(x, 3, 1, 1)
+    assert torch.equal(ops.maxpool3(cl(x)).cpu(), want)
+    wide = torch.full((1, c + 32, *dims), -7.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    assert ops.maxpool3(cl(x), wide, 16) is wide
+    assert torch.equal(wide[:, 16:16 + c].cpu(), want)
+    rest = torch.cat([wide[:, :16], wide[:, 16 + c:]], 1)
+    assert float(rest.min()) == -7.0 and float(rest.max()) == -7.0
+
+
 def test_layout_helpers(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(1, 19, 13, 20, 11, generator=g)
