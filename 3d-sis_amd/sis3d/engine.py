@@ -239,7 +239,11 @@ class PipelinedEngines:
     (a 432-workgroup launch leaves 80 CUs one workgroup short) and every dependent kernel boundary drains the
     chip.  Captured graphs replaying on separate streams fill each other's gaps: backbone+RPN 0.60 ms per chunk
     alone, 0.466 with two, 0.449 with three in flight; the detect pass (long single-workgroup tail kernels) gains
-    11 % from the third stream; a fourth loses again."""
+    11 % from the third stream; a fourth loses again.
+    r4: "a fourth loses" was HIP's default of 4 hardware queues -- the pipelines' streams, the capture streams and the null stream share
+    them round-robin, so a fourth pipeline serialises behind another one.  With GPU_MAX_HW_QUEUES >= 6 in the environment (read when the
+    HIP runtime initialises; bench.py sets 8) four pipelines are the best count for every workload (backbone + RPN 2.16 -> 2.28 G voxels/s,
+    detect 1.86 -> 2.02 G; five and six lose on any queue count: profiles/r04_hw_queues.txt)."""
 
     def __init__(self, net, n=2, brick_cap=None, **kw):
         """brick_cap: cap (voxels) on the k3 kernel's brick for the graphs captured here; default 108 when n >= 2 (small

@@ -15,7 +15,7 @@ all-gather and whole-scene NMS, `records_gathered`, `kept_after_scene_nms`, `ms_
 same scene = `single_gpu` and `speedup_vs_1gpu`).  So value(N) / value(1) compares like with like, and the strong-scaling figure
 of the collective path can be read off the `scene` key of the same lines.  `--workload scene` makes the scene the headline instead.
   backbone_rpn  BASELINE config[1]: one 96x48x96 geometry-only chunk per pipeline, HIP backbone + RPN; a step = one pass
-                over `--inflight` (default 3: the measured best of every workload, tools/r04_inflight.sh)
+                over `--inflight` (default 4 on the 8 hardware queues this script asks HIP for, tools/r04_hwq.sh)
                 independent chunks per GPU, each on its own HIP stream / captured graph, inputs resident in HBM.  Ranks share
                 nothing (scaling: weak).
   detect        config[2]: + decode / top-k / NMS / RoI pooling / classifier (+ `--masks`: mask head on a fixed
@@ -44,6 +44,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
+# HIP gives a process 4 hardware queues by default and maps its streams onto them round-robin: the pipelines' streams, the capture /
+# side streams and the null stream then share queues, and a FOURTH chunk in flight serialises behind another one (round 4,
+# tools/r04_hwq.sh, same box: 4 in flight 1.80 G voxels/s on 4 queues, 2.28 G on >= 6; 3 in flight 2.16 G on either).  Read by the HIP
+# runtime when it initialises, i.e. before torch is imported anywhere below; an integrator sets the same variable in his launcher.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 VOXELS = 96 * 48 * 96
 # algorithmic work per chunk
@@ -79,7 +84,7 @@ def parse(argv=None):
     ap.add_argument("--workload", default="auto", choices=["auto", "backbone_rpn", "detect", "images", "scene"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="independent chunks in flight per GPU (HIP streams); 0 = the "
-                    "measured best: 4 for backbone_rpn, 3 for detect / images / scene")
+                    "measured best: 4 with GPU_MAX_HW_QUEUES >= 6 (this script sets 8 unless the variable is already set), else 3")
     ap.add_argument("--masks", action="store_true", help="detect: also run the mask head (config[2] in full) on a fixed "
                     "deterministic detection set; scene: mask the detections that survive the whole-scene NMS, each on the "
                     "chunk / rank that produced it")
@@ -153,12 +158,18 @@ def scene_origin(c, stride):
     return (float(stride) * (c % 4), 0.0, float(stride) * (c // 4))
 
 
+def hw_queues():
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
 def default_inflight(workload):
-    """chunks in flight per GPU that measured best.  Round 4 (profiles/r04_inflight.txt, 200-step runs after a clock pre-heat): three
-    for every workload -- backbone + RPN 1.96 G voxels/s with 3, 1.82 with 4, 1.95 with 6; detect 1.73 / 1.53 with 3 / 4.  (Round 3
-    preferred four for backbone + RPN; with the Bottleneck bodies on the Winograd kernel, five launches per chunk take their CUs
-    whole and a fourth stream only queues behind them.)"""
-    return 3
+    """chunks in flight per GPU that measured best (profiles/r04_hw_queues.txt, 200-step runs after a clock pre-heat, same box): FOUR on
+    >= 6 hardware queues for every workload -- backbone + RPN 2.28 G voxels/s (3: 2.16, 5: 2.00, 6: 1.94), detect 2.02 (3: 1.86),
+    images 1.60 (3: 1.50) -- and three on HIP's default of 4 queues, where a fourth stream shares a queue with another one (1.80 G)."""
+    return 4 if hw_queues() >= 6 else 3
 
 
 def chunk_pipeline_entry(value, unit, ms_per_step, chunks_per_step_per_gpu, single_ms):
@@ -723,7 +734,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     if emulate is not None:
         gr, gw = emulate
     n_local = len(range(gr, n_chunks, gw))
-    nfl = inflight or (args.inflight if args.inflight > 0 else (n_local if n_local <= 4 else 3))
+    nfl = inflight or (args.inflight if args.inflight > 0 else (n_local if n_local <= 4 else default_inflight("scene")))
     runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph, inflight=max(1, nfl), solo=(group == "solo"), emulate=emulate)
     chunks = []
     for c in range(n_chunks):
@@ -974,6 +985,7 @@ def main(argv=None):
                            " (the same workload at every N; the `scene` key of this line is the config[4] figure)" if both and workload != "scene"
                            else ""),
                        "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world,
+                       "hw_queues": hw_queues(),
                        **({"TEST_HOOK": "all ranks share GPU 0, gloo instead of RCCL: functional run, not a measurement"} if share else {}),
                        "chunks_per_step_per_gpu": nchunk_step, "single_chunk_latency_ms": res["single_ms"], **res["extra"]},
             "roofline": roofline_entry(kt, kt_direct, ops.WINOGRAD),
