@@ -77,7 +77,9 @@ constexpr int enet_lds_float4(int ntaps) { return 64 * (ntaps * (MID / 16) * (MI
 
 // ENET_WAVES = 1: the round-3 form (one wave per workgroup, weights as A operands straight from L2, no LDS) with the tap rows
 // prefetched; kept as an A/B switch (SIS3D_ENET_WAVES=1)
-template <int C, int MID, int MIDN, int ENET_WAVES>
+// ASYM: the block's conv2 is the asymmetric 1x5 -> 5x1 pair (a.kind == 1); a template parameter so that only ONE of the two tap-row
+// register sets exists in an instantiation
+template <int C, int MID, int MIDN, int ENET_WAVES, bool ASYM>
 __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetBlockArgs a)
 {
     constexpr int MT = MID / 16, CT = C / 16, NT = MIDN / 16;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- the block's weights -> LDS, once per workgroup: [conv2 taps (9, or 5 + 5)][conv3][next conv1], fragment order kept
-    const int ntaps = a.kind == 0 ? 9 : 10;
-    const int n2 = (a.kind == 0 ? 9 : 5) * MT * MT * 64, n3 = CT * MT * 64;
+    constexpr int ntaps = ASYM ? 10 : 9;
+    constexpr int n2 = (ASYM ? 5 : 9) * MT * MT * 64, n3 = CT * MT * 64;
     const float4 *l2, *l2b, *l3, *l1;
     if constexpr (ENET_WAVES == 1) {
         l2 = reinterpret_cast<const float4 *>(a.w2); l2b = reinterpret_cast<const float4 *>(a.w2b);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
         // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB fragment per instruction, no staging registers): a wave issues
         // its share of the <= 72 fragments back to back -- ONE L2 round trip for the lot (a load / store loop through registers pays
         // one per iteration: measured 0.57 instead of 0.37 ms per 5 views) -- and the single wait sits in front of the barrier below
-        const int f2 = (a.kind == 0 ? 9 : 5) * MT * MT, f2b = a.kind == 0 ? 0 : 5 * MT * MT, f3 = CT * MT, f1 = NT * CT;
+        constexpr int f2 = (ASYM ? 5 : 9) * MT * MT, f2b = ASYM ? 5 * MT * MT : 0, f3 = CT * MT, f1 = NT * CT;
         const int nf = f2 + f2b + f3 + f1;
         for (int f = wave; f < nf; f += ENET_WAVES) {
             const float *src;
@@ -137,6 +139,42 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
     } else {
         static_for<0, CT>([&](auto N) { skip[decltype(N)::value] = ld4(a.x + (size_t)pc * C + 16 * decltype(N)::value + 4 * kq); });
     }
+    // r4 (second half): everything else the launch reads from memory is requested HERE, in the same L2 round trip as the weights and
+    // the skip rows: the biases / PReLU slopes of the three stages (they used to be loaded where they are used: three exposed round
+    // trips of ~0.7 us each on a 14 us launch) and the tap rows of conv2 (they used to go out behind the barrier: a second round trip)
+    float4 pb2[MT], ps2[MT], pb3[CT], ps3[CT];
+    static_for<0, MT>([&](auto N) { pb2[decltype(N)::value] = ld4(a.b2 + 16 * decltype(N)::value + 4 * kq); ps2[decltype(N)::value] = ld4(a.s2 + 16 * decltype(N)::value + 4 * kq); });
+    static_for<0, CT>([&](auto N) { pb3[decltype(N)::value] = ld4(a.b3 + 16 * decltype(N)::value + 4 * kq); ps3[decltype(N)::value] = ld4(a.s3 + 16 * decltype(N)::value + 4 * kq); });
+    constexpr int NTA = NT > 0 ? NT : 1;
+    float4 pb1[NTA], ps1[NTA];
+    if constexpr (NT > 0)
+        static_for<0, NT>([&](auto N) { pb1[decltype(N)::value] = ld4(a.b1n + 16 * decltype(N)::value + 4 * kq); ps1[decltype(N)::value] = ld4(a.s1n + 16 * decltype(N)::value + 4 * kq); });
+    const int ybase = (int)(((size_t)pc * MID + 4 * kq) * 4);               // byte offset of this lane's 16 B of its own pixel row
+    f32x4 xa[ASYM ? 1 : 9][MT];
+    bool okt[9];
+    f32x4 xr[ASYM ? 2 : 1][5][MT];
+    [[maybe_unused]] auto issue_row = [&](auto DY, auto B) {
+        constexpr int dy = decltype(DY)::value - 2, b = decltype(B)::value;
+        const bool rowok = (unsigned)(y0 + dy) < (unsigned)H;
+        static_for<0, 5>([&](auto DX) {
+            constexpr int dx = decltype(DX)::value - 2;
+            const bool ok = rowok && (unsigned)(x0 + dx) < (unsigned)W;
+            const int off = ybase + (ok ? (dy * W + dx) * MID * 4 : 0);
+            static_for<0, MT>([&](auto G) { gload16(xr[b][decltype(DX)::value][decltype(G)::value], off + 64 * decltype(G)::value, a.y1); });
+        });
+    };
+    if constexpr (!ASYM) {
+        const int d = a.dil;
+        static_for<0, 9>([&](auto T) {
+            constexpr int tap = decltype(T)::value, ky = tap / 3 - 1, kx = tap % 3 - 1;
+            const int dy = ky * d, dx = kx * d;
+            okt[tap] = (unsigned)(y0 + dy) < (unsigned)H && (unsigned)(x0 + dx) < (unsigned)W;
+            const int off = ybase + (okt[tap] ? (dy * W + dx) * MID * 4 : 0);
+            static_for<0, MT>([&](auto G) { gload16(xa[tap][decltype(G)::value], off + 64 * decltype(G)::value, a.y1); });
+        });
+    } else {
+        issue_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    }
     if constexpr (ENET_WAVES > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA above (the compiler does not count LDS-DMA writes)
         __syncthreads();
@@ -150,18 +188,7 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
     // before the first MFMA: left to itself hipcc turned `ok ? load : 0` into a branch around eight single-dword loads per tap and a
     // vmcnt(0) per tap, i.e. nine dependent L2 round trips (~1 us each) around 3.8 us of matrix work.  Addresses are clamped to the
     // pixel itself where the tap falls outside the image, the zero is a select after the (counted) wait.
-    const int ybase = (int)(((size_t)pc * MID + 4 * kq) * 4);               // byte offset of this lane's 16 B of its own pixel row
-    if (a.kind == 0) {
-        const int d = a.dil;
-        f32x4 xa[9][MT];
-        bool okt[9];
-        static_for<0, 9>([&](auto T) {
-            constexpr int tap = decltype(T)::value, ky = tap / 3 - 1, kx = tap % 3 - 1;
-            const int dy = ky * d, dx = kx * d;
-            okt[tap] = (unsigned)(y0 + dy) < (unsigned)H && (unsigned)(x0 + dx) < (unsigned)W;
-            const int off = ybase + (okt[tap] ? (dy * W + dx) * MID * 4 : 0);
-            static_for<0, MT>([&](auto G) { gload16(xa[tap][decltype(G)::value], off + 64 * decltype(G)::value, a.y1); });
-        });
+    if constexpr (!ASYM) {
         wait_vm<0>(xa[0][0]);
         static_for<0, 9 * MT>([&](auto I) { touch(xa[decltype(I)::value / MT][decltype(I)::value % MT]); });
         static_for<0, 9>([&](auto T) {
@@ -174,18 +201,6 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
         // enet.py's asymmetric pair: Conv2d(mid, mid, (1,5), padding (0,2), no bias) then Conv2d(mid, mid, (5,1), padding (2,0)): the
         // row y + dy of the intermediate is rebuilt per dy (5 x 5 taps); rows outside the image are the second conv's zero padding
         const float4 *w2b = l2b + lane;
-        f32x4 xr[2][5][MT];
-        auto issue_row = [&](auto DY, auto B) {
-            constexpr int dy = decltype(DY)::value - 2, b = decltype(B)::value;
-            const bool rowok = (unsigned)(y0 + dy) < (unsigned)H;
-            static_for<0, 5>([&](auto DX) {
-                constexpr int dx = decltype(DX)::value - 2;
-                const bool ok = rowok && (unsigned)(x0 + dx) < (unsigned)W;
-                const int off = ybase + (ok ? (dy * W + dx) * MID * 4 : 0);
-                static_for<0, MT>([&](auto G) { gload16(xr[b][decltype(DX)::value][decltype(G)::value], off + 64 * decltype(G)::value, a.y1); });
-            });
-        };
-        issue_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 5>([&](auto DY) {
             constexpr int dyi = decltype(DY)::value, dy = dyi - 2, b = dyi & 1;
             if constexpr (dyi + 1 < 5) {
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
     float4 y2[MT];
     static_for<0, MT>([&](auto N) {
         constexpr int n = decltype(N)::value;
-        const float4 b = ld4(a.b2 + 16 * n + 4 * kq), s = ld4(a.s2 + 16 * n + 4 * kq);
+        const float4 b = pb2[n], s = ps2[n];
         y2[n] = prelu4(make_float4(acc[n][0][0] + acc[n][1][0] + b.x, acc[n][0][1] + acc[n][1][1] + b.y, acc[n][0][2] + acc[n][1][2] + b.z,
                                    acc[n][0][3] + acc[n][1][3] + b.w), s);
     });
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
     float4 ov[CT];
     static_for<0, CT>([&](auto N) {
         constexpr int n = decltype(N)::value;
-        const float4 b = ld4(a.b3 + 16 * n + 4 * kq), s = ld4(a.s3 + 16 * n + 4 * kq);
+        const float4 b = pb3[n], s = ps3[n];
         ov[n] = prelu4(make_float4((o[n][0] + b.x) + skip[n].x, (o[n][1] + b.y) + skip[n].y, (o[n][2] + b.z) + skip[n].z, (o[n][3] + b.w) + skip[n].w), s);
     });
     if (live) {
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(64 * ENET_WAVES) void enet_block_kernel(const EnetB
         if (live) {
             static_for<0, NT>([&](auto N) {
                 constexpr int n = decltype(N)::value;
-                const float4 b = ld4(a.b1n + 16 * n + 4 * kq), s = ld4(a.s1n + 16 * n + 4 * kq);
+                const float4 b = pb1[n], s = ps1[n];
                 *reinterpret_cast<float4 *>(a.y1n + (size_t)pc * MIDN + 16 * n + 4 * kq) =
                     prelu4(make_float4(n1[n][0][0] + n1[n][1][0] + b.x, n1[n][0][1] + n1[n][1][1] + b.y, n1[n][0][2] + n1[n][1][2] + b.z,
                                        n1[n][0][3] + n1[n][1][3] + b.w), s);
@@ -379,21 +394,26 @@ __global__ __launch_bounds__(256) void enet_initial_kernel(const float *__restri
     for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
 
-template <int C, int MID, int MIDN>
-int launch_block(const EnetBlockArgs &a, hipStream_t st)
+template <int C, int MID, int MIDN, bool ASYM>
+int launch_block_k(const EnetBlockArgs &a, hipStream_t st)
 {
     static const int waves = [] { const char *e = getenv("SIS3D_ENET_WAVES"); return e && atoi(e) == 1 ? 1 : 4; }();      // A/B switch
     if (waves == 1) {
-        hipLaunchKernelGGL((enet_block_kernel<C, MID, MIDN, 1>), dim3((unsigned)cdiv(a.npix, 16)), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((enet_block_kernel<C, MID, MIDN, 1, ASYM>), dim3((unsigned)cdiv(a.npix, 16)), dim3(64), 0, st, a);
         return sis3d_check_launch();
     }
-    const size_t lds = (size_t)enet_lds_float4<C, MID, MIDN>(a.kind == 0 ? 9 : 10) * sizeof(float4);
-    auto kern = enet_block_kernel<C, MID, MIDN, 4>;
+    constexpr size_t lds = (size_t)enet_lds_float4<C, MID, MIDN>(ASYM ? 10 : 9) * sizeof(float4);
+    auto kern = enet_block_kernel<C, MID, MIDN, 4, ASYM>;
     static Sis3dLdsOnce once;
-    if (enet_lds_float4<C, MID, MIDN>(10) * sizeof(float4) > 64 * 1024 &&
-        sis3d_grant_lds(once, (const void *)kern, (int)(enet_lds_float4<C, MID, MIDN>(10) * sizeof(float4))) != SIS3D_OK) return SIS3D_ELAUNCH;
+    if (lds > 64 * 1024 && sis3d_grant_lds(once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(cdiv(a.npix, 16), 4)), dim3(256), lds, st, a);
     return sis3d_check_launch();
+}
+
+template <int C, int MID, int MIDN>
+int launch_block(const EnetBlockArgs &a, hipStream_t st)
+{
+    return a.kind == 0 ? launch_block_k<C, MID, MIDN, false>(a, st) : launch_block_k<C, MID, MIDN, true>(a, st);
 }
 
 } // namespace
