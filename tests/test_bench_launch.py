@@ -100,3 +100,20 @@ def test_roofline_fractions_are_fractions():
     assert abs(d["frac"] - 0.814) < 2e-3 and d["algorithmic_speedup_vs_direct_count"] == 1.0 and bench.fracs_above_one(d) == []
     assert bench.fracs_above_one({"stages": {"rpn": {"fp32_frac": 1.5}}, "x": [{"hbm_frac": 0.2}]}) == [("stages.rpn.fp32_frac", 1.5)]
     assert abs(bench.executed_flops(42.58e9, 30.57e9) - (42.58e9 - 30.57e9 * (1 - 64 / 216))) < 1.0
+
+
+def test_hardware_queues_and_chunks_in_flight(monkeypatch):
+    """r4: bench.py asks HIP for 8 hardware queues before torch is imported (a fourth pipeline otherwise shares a queue with another
+    stream) and keeps FOUR chunks in flight on them -- three when the caller pinned HIP's default of 4 (profiles/r04_hw_queues.txt)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert os.environ.get("GPU_MAX_HW_QUEUES")                      # set (or already present) as soon as bench is imported
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert bench.hw_queues() == 8 and all(bench.default_inflight(w) == 4 for w in ("backbone_rpn", "detect", "images", "scene"))
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert bench.hw_queues() == 4 and bench.default_inflight("backbone_rpn") == 3
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
+    assert bench.hw_queues() == 4
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('os.environ.setdefault("GPU_MAX_HW_QUEUES"') < src.index("def parse(")        # before anything can import torch
+    assert "\nimport torch" not in src.split("def parse(")[0]
