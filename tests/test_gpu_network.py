@@ -163,6 +163,55 @@ def test_full_forward_masks(oracle, golden):
         assert float((dict(zip(wins, masks))[owins[i]].cpu() - ref_m).abs().max()) <= TOL
 
 
+@pytest.mark.parametrize("name,use_images", [("e2e_geometry_full", False), ("e2e_images_small", True)])
+def test_forward_under_the_shared_chip_dispatch(oracle, golden, name, use_images):
+    """r4: the dispatch that pipelines of several chunks in flight capture (sis3d_conv3d_k3wino_set_shared_chip: geometry2[0] with two cout
+    tiles per Winograd workgroup, the 64 -> 64 convs and the Bottleneck(128,32) bodies on the Winograd kernel) -- i.e. the kernels that set the
+    bench headline -- against the oracle and the reference's own fixture at the same tolerances and the same 0-near-tie rule as the default
+    dispatch, and against the default dispatch itself (levels within 2e-5 of their scale)"""
+    from sis3d import ops
+    g = golden(name)
+    dims = tuple(int(v) for v in g["dims"])
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES = use_images
+    net, sd = build(cfg)
+    data = synthetic.synth_chunk(int(g["chunk_id"]), dims)
+    feats = i3d = i2d = None
+    if use_images:
+        feats, i3d, i2d = synthetic.synth_views(int(g["chunk_id"]), n_views=int(g["n_views"]), n_per_view=int(g["n_per_view"]), dims=dims)
+    net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
+    d1, d2 = [t.clone() for t in net._net_conv]
+    ops.flop_tally(True)
+    net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
+    base = ops.flop_tally(False)["wino_launches"]
+    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1)
+    try:
+        ops.flop_tally(True)
+        p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
+        shared = ops.flop_tally(False)["wino_launches"]
+    finally:
+        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
+    if dims == (96, 48, 96):
+        assert shared > base, (shared, base)                   # more layers really took the Winograd kernel
+    o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data, feats, i3d, i2d)
+    l1, l2 = net._net_conv
+    assert (l1.cpu() - o["level1"]).abs().max() <= TOL and (l2.cpu() - o["level2"]).abs().max() <= TOL
+    assert (l1 - d1).abs().max().item() <= 2e-5 * float(d1.abs().max()) and (l2 - d2).abs().max().item() <= 2e-5 * float(d2.abs().max())
+    for lv in (1, 2):
+        for k in ("rpn_cls_score_level%d", "rpn_cls_prob_level%d", "rpn_bbox_pred_level%d"):
+            assert (p[k % lv].cpu() - o[k % lv]).abs().max() <= TOL, k % lv
+    check_proposals(p, o, name + " (shared-chip dispatch)")    # asserts 0 near-ties
+    assert p["rois"][0].shape[0] == g["rois"].shape[0]
+    assert np.abs(p["rois"][0].cpu().numpy() - g["rois"]).max() <= 1e-3
+    assert np.abs(p["roi_scores"][0].cpu().numpy() - g["roi_scores"]).max() <= TOL
+    assert np.array_equal(p["level_inds"][0].cpu().numpy(), g["level_inds"])
+    assert np.array_equal(p["cls_pred"].cpu().numpy(), g["cls_pred"])
+    assert np.abs(p["cls_score"].cpu().numpy() - g["cls_score"]).max() <= TOL
+    assert np.abs(p["bbox_pred"].cpu().numpy() - g["bbox_pred"]).max() <= TOL
+    report("%s under the shared-chip dispatch (%d Winograd launches instead of %d): %d rois / scores / levels / cls_pred / cls_score / "
+           "bbox_pred equal to the reference fixture row for row" % (name, shared, base, g["rois"].shape[0]))
+
+
 def test_config4_full_size_vs_oracle(oracle):
     """BASELINE config 4 at 96x48x96 (feature maps handed in, USE_IMAGES_GT): RPN maps, logits, proposals vs the oracle"""
     cfg = config.scannet_benchmark_cfg()
