@@ -47,6 +47,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef WN_EXP
 #define WN_EXP 0
 #endif
+// XCD work order of the eight-cout-group layers: 1 = two groups x half of the blocks per XCD, 0 = one group x all blocks (r3)
+#ifndef WN_XCD_PAIRS
+#define WN_XCD_PAIRS 1
+#endif
+static constexpr bool XCD_PAIRS = WN_XCD_PAIRS != 0;
 
 namespace {
 
@@ -750,6 +755,18 @@ __global__ __launch_bounds__(NTHR * WC, 1) void conv3d_k3wino_kernel(const WinoA
         const int nbr = a.nbx * a.nby * a.nbz;
         grp = wid / nbr;
         brick = wid - grp * nbr;
+        // r4: with exactly eight cout groups (rpn_net: one per XCD under the rule above) an XCD takes TWO groups x HALF of the blocks
+        // instead: its L2 then holds 2/8 of U (2.1 MB) and about half of the activation map (1.9 MB) instead of 1/8 and the whole map
+        // (1.05 + 3.5 MB) -- less fetched per launch, same work per XCD.  Pair p = XCDs 2p, 2p + 1; the pair's 2 nbr items in the order
+        // (group 2p, first half), (2p + 1, first half), (2p, second half), (2p + 1, second half), cut in two equal runs.
+        if (XCD_PAIRS && a.ngroups == 8 && (int)gridDim.x == 8 * nbr) {
+            const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;                 // idx in [0, nbr)
+            const int p = xcd >> 1, j = (xcd & 1) * nbr + idx, hb = (nbr + 1) >> 1;
+            if (j < hb) { grp = 2 * p; brick = j; }
+            else if (j < 2 * hb) { grp = 2 * p + 1; brick = j - hb; }
+            else if (j < hb + nbr) { grp = 2 * p; brick = j - hb; }
+            else { grp = 2 * p + 1; brick = j - nbr; }
+        }
     }
     // waves (wc, h, g): h = xi_x half, g = tile group, wc = cout tile group (WC = 2: waves w and w + 4 share a SIMD); each wave serves
     // NC cout tiles
