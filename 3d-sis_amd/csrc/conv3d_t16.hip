@@ -391,7 +391,6 @@ int launch_t16(T16Args &a, int nprob, hipStream_t st, int64_t ragged_blocks = 0)
     return sis3d_check_launch();
 }
 
-std::atomic<int> g_brick_cap{0};          // sis3d_conv3d_k3t16_set_brick_cap
 
 struct Brick { int bx, by, bz; };
 constexpr Brick BRICKS[] = {{6, 6, 12}, {6, 6, 6}, {3, 6, 6}, {3, 3, 6}, {4, 4, 4}, {4, 4, 8}, {4, 8, 8}};
@@ -435,20 +434,13 @@ extern "C" int sis3d_conv3d_k3t16_set_trace(void *buf, int capacity_blocks)
     return SIS3D_OK;
 }
 
-extern "C" int sis3d_conv3d_k3t16_set_brick_cap(int max_voxels)
+extern "C" int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob, int max_voxels)
 {
-    if (max_voxels < 0) return SIS3D_EINVAL;
-    g_brick_cap.store(max_voxels, std::memory_order_relaxed);
-    return SIS3D_OK;
-}
-
-extern "C" int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob)
-{
-    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nprob < 1) return SIS3D_EINVAL;
+    if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || nprob < 1 || max_voxels < 0) return SIS3D_EINVAL;
     // tuning hook: SIS3D_K3_MAXVOX caps the brick volume (smaller bricks = less LDS / fewer registers per workgroup, so
     // workgroups of other streams' kernels can share the CU)
     static const int env_maxvox = [] { const char *e = getenv("SIS3D_K3_MAXVOX"); return e ? atoi(e) : -1; }();
-    const int maxvox = env_maxvox >= 0 ? env_maxvox : g_brick_cap.load(std::memory_order_relaxed);
+    const int maxvox = env_maxvox >= 0 ? env_maxvox : max_voxels;       // the cap is the caller's (an argument since r5: no library state)
     int best = -1;
     int64_t bc = -1;
     for (int i = 0; i < NBRICKS; ++i) {
@@ -477,7 +469,7 @@ extern "C" int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int
     a.X = X; a.Y = Y; a.Z = Z; a.cin_stride = cin_stride; a.cout = cout; a.ntiles = (cout + 15) / 16; a.nq = cin / CK;
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
     a.rag = nullptr; a.nrag = 0;
-    if (brick < 0) brick = sis3d_conv3d_k3t16_brick(X, Y, Z, cin, cout, nprob);
+    if (brick < 0) brick = sis3d_conv3d_k3t16_brick(X, Y, Z, cin, cout, nprob, 0);
     hipStream_t st = as_stream(stream);
     switch (brick) {
     case 0: return launch_t16<6, 6, 12>(a, nprob, st);

@@ -837,10 +837,9 @@ extern "C" int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, 
 // >= ~200 (block, cout group) items to fill the chip -- with two cout tiles per wave if that still gives 200 (the input
 // transform is shared by both), else with one -- and a channel loop long enough to amortise ~10 us of prologue + output
 // transform.  Measured (tools/wino_bench.cpp, us, direct -> Winograd): rpn_net 128->256 @24x12x24: 102 -> 58 (pair 194 -> 112).
-#include <atomic>
-static std::atomic<int> g_shared_chip{0};       // sis3d_conv3d_k3wino_set_shared_chip
-
-static int wino_nc(int X, int Y, int Z, int cin, int cout)
+// shared_chip: the caller's dispatch regime (an argument since r5 -- no library state: launches / captures of the two regimes may run
+// concurrently from different threads)
+static int wino_nc(int X, int Y, int Z, int cin, int cout, bool shared_chip)
 {
     if (X <= 0 || Y <= 0 || Z <= 0 || cin < 64 || cout < 64 || (cin % 8)) return 0;
     const int64_t blocks = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ);
@@ -851,7 +850,7 @@ static int wino_nc(int X, int Y, int Z, int cin, int cout)
     // convs of geometry2's Bottlenecks: 27 blocks x 2 cout pairs) costs the chip less on this kernel -- 54 CUs x ~27 us against
     // 256 x ~15 -- although alone it takes longer than the direct kernel's 17 us (env SIS3D_WINO_SHARED_MIN: work items needed)
     static const int shared_min = [] { const char *e = getenv("SIS3D_WINO_SHARED_MIN"); return e ? atoi(e) : 48; }();
-    if (g_shared_chip.load(std::memory_order_relaxed) && blocks * ((nt + 1) / 2) >= shared_min) return 2;
+    if (shared_chip && blocks * ((nt + 1) / 2) >= shared_min) return 2;
     if (blocks * nt >= 200 && cin >= 128) {
         // one cout tile per workgroup fills the chip when the launch has it alone (geometry2[0]: 216 work items, 34 us; on a shared
         // chip the rule above has already given it two: 108 work items x ~50 us, tools/r04_exp1.sh: 1.958 -> 1.992 G voxels/s with
@@ -861,15 +860,9 @@ static int wino_nc(int X, int Y, int Z, int cin, int cout)
     return 0;
 }
 
-extern "C" int sis3d_conv3d_k3wino_set_shared_chip(int on)
+extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob, int shared_chip)
 {
-    g_shared_chip.store(on ? 1 : 0, std::memory_order_relaxed);
-    return SIS3D_OK;
-}
-
-extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob)
-{
-    return nprob >= 1 && wino_nc(X, Y, Z, cin, cout) > 0 ? 1 : 0;
+    return nprob >= 1 && wino_nc(X, Y, Z, cin, cout, shared_chip != 0) > 0 ? 1 : 0;
 }
 
 template <int NC, int C3, int C2N, bool MINI = false, int WC = 1>
@@ -904,8 +897,10 @@ extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, in
     if (nprob < 1 || nprob > WN_MAXP || !ins || !packed_ws || !outs) return SIS3D_EINVAL;
     if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || cin_stride < cin || (cin_stride % 4)) return SIS3D_EINVAL;
     if ((cin % 8) || out_stride < out_coff + cout) return SIS3D_EUNSUPPORTED;        // K-steps of 4 channels, taken two at a time
-    if (flags & ~SIS3D_EPI_RELU) return SIS3D_EUNSUPPORTED;
+    if (flags & ~(SIS3D_EPI_RELU | SIS3D_DISPATCH_SHARED_CHIP)) return SIS3D_EUNSUPPORTED;
     if ((int64_t)X * Y * Z * cin_stride > 0x7fffffffLL) return SIS3D_EUNSUPPORTED;      // 32-bit element offsets in the staging plan
+    const bool shared_chip = (flags & SIS3D_DISPATCH_SHARED_CHIP) != 0;
+    flags &= ~SIS3D_DISPATCH_SHARED_CHIP;
     WinoArgs a;
     for (int p = 0; p < WN_MAXP; ++p) {
         const int s = p < nprob ? p : 0;
@@ -913,7 +908,7 @@ extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, in
         a.in[p] = ins[s]; a.wp[p] = packed_ws[s]; a.bias[p] = biases ? biases[s] : nullptr; a.out[p] = outs[s];
     }
     static const int force_nc = [] { const char *e = getenv("SIS3D_WINO_NC"); return e ? atoi(e) : 0; }();      // tuning hook
-    int nc = force_nc == 1 || force_nc == 2 ? force_nc : wino_nc(X, Y, Z, cin, cout);
+    int nc = force_nc == 1 || force_nc == 2 ? force_nc : wino_nc(X, Y, Z, cin, cout, shared_chip);
     if (nc == 0) nc = 2;                                 // called directly on a layer the dispatch rule would not send here
     // two cout tiles per workgroup either as one wave with two tiles (nc 2, wc 1) or as two waves per SIMD with one each (nc 1, wc 2)
     int wc = 1;
@@ -996,14 +991,14 @@ extern "C" int sis3d_conv3d_k3wino_ragged_mini(const float *in, int cin, int cin
 // NEXT block's conv1 + bias + ReLU.  Same contract as sis3d_bottleneck16 (the direct-convolution form of the same fusion); serves the
 // planes = 32 blocks, whose 32 conv2 channels are the two cout tiles of one workgroup.  sis3d_bottleneck_wino_prefer says where it is
 // expected to win (enough 8 x 4 x 8 blocks to fill the chip: the 48 x 24 x 48 maps of geometry1 / color).
-extern "C" int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int c3, int c2n)
+extern "C" int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int c3, int c2n, int shared_chip)
 {
     if (planes != 32 || !(c3 == 32 || c3 == 64 || c3 == 128) || !(c2n == 0 || c2n == 32)) return 0;
     if (c3 != 32 && c2n != 0) return 0;
     const int64_t blocks = (int64_t)cdiv(X, VX) * cdiv(Y, VY) * cdiv(Z, VZ);
-    // shared chip (sis3d_conv3d_k3wino_set_shared_chip): CU-time counts, not the launch's own duration -- the Bottleneck(128, 32) bodies
+    // shared chip (the caller's regime, see sis3d_conv3d_k3wino_prefer): CU-time counts, not the launch's own duration -- the Bottleneck(128, 32) bodies
     // of the 24 x 12 x 24 maps as 27 fat work items instead of 256 thin ones (see wino_nc)
-    if (g_shared_chip.load(std::memory_order_relaxed) && blocks >= 24) return 1;
+    if (shared_chip && blocks >= 24) return 1;
     if (c3 == 128) return 0;
     return blocks >= 200 ? 1 : 0;
 }

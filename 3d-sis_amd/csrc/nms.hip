@@ -106,7 +106,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(const float *
 //  * the matrix is staged into LDS when it fits (n <= ~1400), else read from L2; the candidates' level / score are staged
 //    up front so the select variant never waits on a dependent global load inside the serial part.
 constexpr size_t SWEEP_LDS_MASK_MAX = 120 * 1024;
-std::atomic<int> g_nms_path{0};          // sis3d_nms_set_path: 0 = by size, 1 = sweep, 2 = resolve
 
 template <bool SELECT>
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t *__restrict__ mask, int n, int max_keep,
@@ -426,9 +425,9 @@ __global__ __launch_bounds__(1024) void scene_rank_kernel(const float *__restric
 template <bool INDIRECT, bool SELECT>
 int launch_nms(const float *boxes, const int64_t *order, const float *level_all, const float *scores_sorted, int n,
                float thresh, int max_keep, int64_t *keep, int32_t *num_keep, float *rois, float *roi_scores,
-               float *roi_levels, void *ws, size_t ws_bytes, hipStream_t st)
+               float *roi_levels, void *ws, size_t ws_bytes, hipStream_t st, int path = 0)
 {
-    if (n < 0 || !keep || !num_keep) return SIS3D_EINVAL;
+    if (n < 0 || !keep || !num_keep || path < 0 || path > 2) return SIS3D_EINVAL;
     if (SELECT && max_keep <= 0) return SIS3D_EINVAL;
     const int cb = (n + 63) / 64;
     const size_t mask_bytes = (size_t)n * cb * 8;
@@ -436,7 +435,6 @@ int launch_nms(const float *boxes, const int64_t *order, const float *level_all,
     const size_t nz_bytes = (size_t)n * nzw * 8;
     if (n > 0 && (ws_bytes < mask_bytes || !ws)) return SIS3D_EWORKSPACE;          // n * ceil(n/64) * 8: what the sweep paths need
     uint64_t *mask = (uint64_t *)ws;
-    const int path = g_nms_path.load(std::memory_order_relaxed);
     if (!SELECT && n > 0 && (path == 2 || (path == 0 && mask_bytes > SWEEP_LDS_MASK_MAX))) {
         // only this path reads the non-zero-word bitmap behind the matrix: sis3d_nms_workspace_bytes(n) covers both
         if (ws_bytes < mask_bytes + nz_bytes) return SIS3D_EWORKSPACE;
@@ -490,18 +488,11 @@ extern "C" size_t sis3d_nms_workspace_bytes(int n)
     return (size_t)n * cb * 8 + (size_t)n * ((cb + 63) / 64) * 8;      // bit matrix + non-zero-word bitmap (resolve path)
 }
 
-extern "C" int sis3d_nms_set_path(int path)
-{
-    if (path < 0 || path > 2) return SIS3D_EINVAL;
-    g_nms_path.store(path, std::memory_order_relaxed);
-    return SIS3D_OK;
-}
-
 extern "C" int sis3d_nms(const float *boxes, int n, float thresh, int max_keep, int64_t *keep, int32_t *num_keep, void *ws,
-                         size_t ws_bytes, sis3d_stream_t stream)
+                         size_t ws_bytes, int path, sis3d_stream_t stream)
 {
     return launch_nms<false, false>(boxes, nullptr, nullptr, nullptr, n, thresh, max_keep, keep, num_keep, nullptr, nullptr,
-                                    nullptr, ws, ws_bytes, as_stream(stream));
+                                    nullptr, ws, ws_bytes, as_stream(stream), path);
 }
 
 extern "C" int sis3d_nms_mask(const float *boxes, int n, float thresh, uint64_t *mask, sis3d_stream_t stream)

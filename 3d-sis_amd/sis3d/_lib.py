@@ -13,8 +13,7 @@ SIGNATURES = {
     "sis3d_strerror": (ctypes.c_char_p, [c_int]),
     "sis3d_last_hip_error": (ctypes.c_char_p, []),
     "sis3d_nms_workspace_bytes": (c_sz, [c_int]),
-    "sis3d_nms_set_path": (c_int, [c_int]),
-    "sis3d_nms": (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sis3d_nms": (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "sis3d_scene_merge_workspace_bytes": (c_sz, [c_int, c_int]),
     "sis3d_scene_merge": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_nms_mask": (c_int, [c_vp, c_int, c_f32, c_vp, c_vp]),
@@ -67,7 +66,6 @@ SIGNATURES = {
                                           c_int, c_int, c_vp, c_int, c_vp]),
     "sis3d_rpn_heads": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int,
                                 c_int, c_vp]),
-    "sis3d_conv3d_k3t16_set_brick_cap": (c_int, [c_int]),
     "sis3d_conv3d_k3t16_set_trace": (c_int, [c_vp, c_int]),
     "sis3d_conv_k3b16_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3b16_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
@@ -77,8 +75,7 @@ SIGNATURES = {
     "sis3d_conv3d_k3b16": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     "sis3d_conv_k3t16_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3t16_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
-    "sis3d_conv3d_k3wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "sis3d_conv3d_k3wino_set_shared_chip": (c_int, [c_int]),
+    "sis3d_conv3d_k3wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sis3d_conv_k3wino_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3wino_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d_k3wino": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp]),
@@ -86,7 +83,7 @@ SIGNATURES = {
     "sis3d_conv3d_k3wino_ragged": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),
     "sis3d_conv3d_k3wino_ragged_mini": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),
     "sis3d_ragged_tiling_k3wino_mini": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
-    "sis3d_conv3d_k3t16_brick": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sis3d_conv3d_k3t16_brick": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sis3d_conv3d_k3t16": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int,
                                    c_vp]),
     "sis3d_project_views_prepare": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
@@ -101,7 +98,7 @@ SIGNATURES = {
     "sis3d_bottleneck16_brick": (c_int, [c_int, c_int, c_int, c_int]),
     "sis3d_bottleneck16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp,
                                    c_int, c_vp, c_int, c_vp]),
-    "sis3d_bottleneck_wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sis3d_bottleneck_wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sis3d_bottleneck_wino": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp,
                                       c_int, c_vp, c_vp]),
     "sis3d_conv3d_planar2_ragged": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_int, c_vp, c_int, c_vp]),

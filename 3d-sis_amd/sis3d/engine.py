@@ -16,7 +16,7 @@ RECORD_WIDTH = ops.RECORD_WIDTH     # proposal box (6), rpn score, level, class 
 
 class ChunkEngine:
     def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1,
-                 mask_boxes=0):
+                 mask_boxes=0, shared_chip=False, brick_cap=0):
         """stage: 'backbone' (the two pyramid levels only), 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect'
         (+ proposals, RoI pooling, classifier).
         from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
@@ -30,7 +30,11 @@ class ChunkEngine:
         a FIXED detection set: with seeded weights no class probability passes CLASS_THRESH, so the first `mask_boxes`
         post-NMS RoIs of the chunk loaded at prepare() time stand in as detections; their crop
         windows (box rounded half-to-even, clipped, non-degenerate: trainval.py:702-712,742-745) are read back ONCE before
-        the capture.  `mask_stats()` reports the crop volumes and the mask-head FLOPs."""
+        the capture.  `mask_stats()` reports the crop volumes and the mask-head FLOPs.
+        shared_chip / brick_cap: the engine's DISPATCH REGIME (ops.dispatch_regime): every launch this engine makes -- warm-up, capture
+        and eager passes alike -- is dispatched for a chip shared with other chunks' kernels / with the direct k3 kernel's brick capped.
+        An attribute of the engine, passed to the library per call: engines of different regimes can be prepared concurrently."""
+        self.shared_chip, self.brick_cap = bool(shared_chip), int(brick_cap)
         self.mask_boxes = int(mask_boxes)
         self.mask_plan = None
         self.net, self.dims, self.stage, self.use_graph = net, tuple(dims), stage, use_graph
@@ -92,6 +96,10 @@ class ChunkEngine:
         return d
 
     def _step(self):
+        with ops.dispatch_regime(self.shared_chip, self.brick_cap):
+            return self._step_body()
+
+    def _step_body(self):
         net = self.net
         if self.rgb and (self.graph is None and not torch.cuda.is_current_stream_capturing()):
             self._encode_views()
@@ -232,6 +240,46 @@ class ChunkEngine:
         return self.out
 
 
+def hw_queues():
+    """hardware queues HIP gives this process (GPU_MAX_HW_QUEUES, read by the runtime when it initialises; HIP's default is 4)"""
+    import os
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
+_QUEUE_WARNED = set()
+
+
+def check_hw_queues(n_pipelines, strict=None):
+    """r5: n pipelines need n + 2 hardware queues (their streams + the capture / copy stream + the null stream); on fewer, HIP maps
+    streams onto queues round-robin and a pipeline silently serialises behind another one (measured: four in flight 1.80 G voxels/s
+    on 4 queues, 2.28 G on 8 -- profiles/r04_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it cannot be
+    fixed up here: warn once per count (RuntimeWarning), or raise with SIS3D_STRICT_HW_QUEUES=1 / strict=True.  `import sis3d` sets
+    GPU_MAX_HW_QUEUES=8 itself when it is imported before torch has initialised HIP and the variable is unset (sis3d/__init__.py)."""
+    import os
+    import warnings
+    # up to three pipelines run as well on HIP's default of four queues (measured: 2.16 G voxels/s on either count)
+    have, need = hw_queues(), (int(n_pipelines) + 2 if n_pipelines >= 4 else 4)
+    if n_pipelines < 2 or have >= need:
+        return True
+    msg = ("sis3d: %d chunk pipelines want GPU_MAX_HW_QUEUES >= %d, this process has %d (HIP default 4): pipelines will share hardware "
+           "queues and serialise -- export GPU_MAX_HW_QUEUES=8 before the process starts (or use <= %d pipelines)"
+           % (n_pipelines, need, have, max(1, have - 1)))
+    if strict or (strict is None and os.environ.get("SIS3D_STRICT_HW_QUEUES", "0") not in ("", "0")):
+        raise ops._lib.Sis3dError(msg)
+    if n_pipelines not in _QUEUE_WARNED:
+        _QUEUE_WARNED.add(n_pipelines)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return False
+
+
+def default_pipelines():
+    """chunk pipelines per GPU that measured best: four on >= 6 hardware queues, three on HIP's default of four"""
+    return 4 if hw_queues() >= 6 else 3
+
+
 class PipelinedEngines:
     """N ChunkEngines on N HIP streams sharing one set of weights: independent chunks in flight concurrently.
 
@@ -250,25 +298,21 @@ class PipelinedEngines:
         bricks = several workgroups per CU, so the pipelines' kernels interleave), none for a single pipeline"""
         cap = (108 if n >= 2 else 0) if brick_cap is None else int(brick_cap)
         self._brick_cap = cap
+        check_hw_queues(n)
         self.streams = [torch.cuda.Stream() for _ in range(n)]
         self.engines = []
         for s in self.streams:
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.engines.append(ChunkEngine(net, **kw))
+                # the dispatch regime of pipelines that share the chip is a property of their engines (r5: per-call arguments of the
+                # library, not a process-wide switch toggled around the captures)
+                self.engines.append(ChunkEngine(net, shared_chip=(n >= 2), brick_cap=cap, **kw))
 
     def prepare(self, warmup=2):
-        # the brick choice is made at launch (= capture) time: set the cap for the captures, restore afterwards
-        ops.lib().sis3d_conv3d_k3t16_set_brick_cap(self._brick_cap)
-        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1 if len(self.engines) >= 2 else 0)
-        try:
-            for e, s in zip(self.engines, self.streams):
-                with torch.cuda.stream(s):
-                    e.prepare(warmup)
-            torch.cuda.synchronize()
-        finally:
-            ops.lib().sis3d_conv3d_k3t16_set_brick_cap(0)
-            ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
+        for e, s in zip(self.engines, self.streams):
+            with torch.cuda.stream(s):
+                e.prepare(warmup)
+        torch.cuda.synchronize()
         return self
 
     def load(self, i, *a, **kw):
@@ -280,6 +324,85 @@ class PipelinedEngines:
         for t in a:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(s)                         # keep the allocator from recycling them under the copy
+
+    # ---- streamed inputs (r5).  The reference's forward owns the upload (`blobs['data'].cuda()`, lib/nets/network.py:191): a chunk
+    # arrives in HOST memory.  feed(i, host) enqueues its H2D copy on a dedicated copy stream into one of pipeline i's two staging
+    # buffers; run_fed(i) makes pipeline i's stream wait for that copy, moves the grid into the static buffer its captured graph
+    # reads (a 3.5 MB device copy, or sis3d_tsdf_encode when the host hands over the raw 1.77 MB SDF block of a .chunk file:
+    # lib/datasets/dataset.py:54-70), releases the staging buffer and replays the graph.  Fed one chunk ahead, the upload of chunk
+    # k + 1 runs under the compute of chunk k; nothing on the host waits.
+    def enable_feed(self, mode="grid", truncated=3.0):
+        """mode 'grid': hosts hand over the encoded (1,2,X,Y,Z) float32 grid, as the reference's dataloader does; 'sdf': the raw
+        float32 SDF block in file order (x fastest), encoded on the device.  Host tensors must be pinned."""
+        if mode not in ("grid", "sdf"):
+            raise ValueError("feed mode must be 'grid' or 'sdf'")
+        if any(e.group != 1 or e.use_images for e in self.engines):
+            raise ops._lib.Sis3dError("streamed inputs: geometry-only engines of one chunk per graph")
+        self._feed_mode, self._feed_trunc = mode, float(truncated)
+        self.copy_stream = torch.cuda.Stream()
+        self._feed = []
+        for e in self.engines:
+            X, Y, Z = e.dims
+            shape = (1, 2, X, Y, Z) if mode == "grid" else (X * Y * Z,)
+            self._feed.append({"stage": [torch.empty(shape, device=e.device) for _ in range(2)],
+                               "ready": [torch.cuda.Event() for _ in range(2)], "free": [torch.cuda.Event() for _ in range(2)],
+                               "tag": [None, None], "used": [False, False], "fed": 0, "run": 0})
+        return self
+
+    def feed(self, i, host):
+        """enqueue the upload of one chunk for pipeline i (at most two outstanding per pipeline) -> False if both staging buffers
+        hold chunks that have not been run yet (nothing is enqueued then)"""
+        f = self._feed[i]
+        if f["fed"] - f["run"] >= 2:
+            return False
+        if host.is_cuda or not host.is_pinned():
+            raise ops._lib.Sis3dError("feed: the chunk must sit in pinned host memory (an upload from pageable memory blocks the host)")
+        s = f["fed"] & 1
+        cs = self.copy_stream
+        if f["used"][s]:
+            cs.wait_event(f["free"][s])                   # the chunk this buffer held has been moved into the static buffer
+        with torch.cuda.stream(cs):
+            f["stage"][s].copy_(host.view(f["stage"][s].shape), non_blocking=True)
+            f["ready"][s].record(cs)
+        f["tag"][s], f["used"][s] = host.data_ptr(), True
+        f["fed"] += 1
+        return True
+
+    def is_fed(self, i, host):
+        """is an upload of THIS host tensor outstanding on pipeline i (fed, not yet consumed)?"""
+        f = self._feed[i]
+        return any(f["tag"][k & 1] == host.data_ptr() for k in range(f["run"], f["fed"]))
+
+    def pending(self, i):
+        """chunks fed to pipeline i and not yet consumed"""
+        f = self._feed[i]
+        return f["fed"] - f["run"]
+
+    def consume(self, i, stream):
+        """on `stream`: wait for the upload of the next chunk pipeline i was fed, move it into the pipeline's static input buffer
+        (device copy, or the TSDF encoding of a raw SDF block) and hand the staging buffer back to the copy stream"""
+        f = self._feed[i]
+        if f["fed"] == f["run"]:
+            raise ops._lib.Sis3dError("streamed inputs: nothing was fed to pipeline %d" % i)
+        s = f["run"] & 1
+        e = self.engines[i]
+        with torch.cuda.stream(stream), torch.no_grad():
+            stream.wait_event(f["ready"][s])
+            if self._feed_mode == "grid":
+                e.scenes[0].copy_(f["stage"][s], non_blocking=True)
+            else:
+                ops.tsdf_encode(f["stage"][s], e.dims, self._feed_trunc, "abs", None, out=e.scenes[0])
+            f["free"][s].record(stream)
+        f["run"] += 1
+
+    def run_fed(self, i, host=None):
+        """run pipeline i on the next chunk it was fed (host given and nothing outstanding: fed now) -> the static output dict"""
+        if host is not None and self.pending(i) == 0:
+            self.feed(i, host)
+        st = self.streams[i]
+        self.consume(i, st)
+        with torch.cuda.stream(st):
+            return self.engines[i].run()
 
     def run(self, i=None):
         """replay engine i (or all of them) on its own stream; returns the static output dict(s)"""
@@ -297,37 +420,33 @@ class PipelinedEngines:
         scene) then issues ONE graph launch per scene: the chunks start together instead of one host launch (~30-40 us of
         hipGraphLaunch + copies) apart, and whatever follows on the launch stream (the collective, the whole-scene merge) is
         ordered behind all of them without a host-side join.  -> (graph, capture stream)"""
+        if any(eng.group != 1 for eng in self.engines):
+            raise ops._lib.Sis3dError("capture_round: engines of one chunk per graph only (group == 1)")
         main = torch.cuda.Stream()
         main.wait_stream(torch.cuda.current_stream())
-        ops.lib().sis3d_conv3d_k3t16_set_brick_cap(self._brick_cap)
-        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1 if len(self.engines) >= 2 else 0)
-        try:
-            with torch.no_grad():
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=main):
-                    prev_ev = None
-                    for e, (eng, s) in enumerate(zip(self.engines, self.streams)):
-                        s.wait_stream(main)
-                        with torch.cuda.stream(s):
-                            if prev_ev is not None and stagger:
-                                # pipelines that start together run the same layers in lockstep and queue for the same CUs (the
-                                # Winograd launches take a CU whole); started one stage apart they fill each other's gaps, as the
-                                # free-running per-chunk replays do: pipeline e starts when pipeline e - 1 has finished level 1
-                                s.wait_event(prev_ev)
-                            ev = torch.cuda.Event()
-                            eng.net._after_level1 = ev.record
-                            try:
-                                out = eng._step()
-                            finally:
-                                eng.net._after_level1 = None
-                            prev_ev = ev
-                            send[e].copy_(out["block"])
-                    for s in self.streams:
-                        main.wait_stream(s)
-            torch.cuda.synchronize()
-        finally:
-            ops.lib().sis3d_conv3d_k3t16_set_brick_cap(0)
-            ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
+        with torch.no_grad():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=main):
+                prev_ev = None
+                for e, (eng, s) in enumerate(zip(self.engines, self.streams)):
+                    s.wait_stream(main)
+                    with torch.cuda.stream(s):
+                        if prev_ev is not None and stagger:
+                            # pipelines that start together run the same layers in lockstep and queue for the same CUs (the
+                            # Winograd launches take a CU whole); started one stage apart they fill each other's gaps, as the
+                            # free-running per-chunk replays do: pipeline e starts when pipeline e - 1 has finished level 1
+                            s.wait_event(prev_ev)
+                        ev = torch.cuda.Event()
+                        eng.net._after_level1 = ev.record
+                        try:
+                            out = eng._step()
+                        finally:
+                            eng.net._after_level1 = None
+                        prev_ev = ev
+                        send[e].copy_(out["block"])
+                for s in self.streams:
+                    main.wait_stream(s)
+        torch.cuda.synchronize()
         return g, main
 
     def join(self):

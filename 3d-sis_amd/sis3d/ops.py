@@ -14,6 +14,35 @@ from ._lib import check, lib
 CL3D = torch.channels_last_3d
 
 EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_RPN_HEAD = 1, 2, 4, 8
+DISPATCH_SHARED_CHIP = 0x100          # include/sis3d.h SIS3D_DISPATCH_SHARED_CHIP
+
+
+# ---- dispatch regime (r5): which FORM the k3 convolutions take is a property of the caller -- a launch that has the chip to itself
+# takes the form that finishes soonest, launches made while other chunks' kernels are in flight take the form that costs the fewest
+# CU-microseconds.  It travels to the library as per-call ARGUMENTS (the flag above, sis3d_*_prefer's
+# shared_chip, sis3d_conv3d_k3t16_brick's max_voxels); on this side it is a THREAD-LOCAL value set by `dispatch_regime(...)`, so two
+# threads that capture different regimes at the same time do not see each other's setting and nothing has to be reset afterwards.
+import contextlib as _contextlib
+import threading as _threading
+
+_REGIME = _threading.local()
+
+
+def regime():
+    """(shared_chip: bool, brick_cap: int voxels, 0 = none) of the calling thread"""
+    return getattr(_REGIME, "value", (False, 0))
+
+
+@_contextlib.contextmanager
+def dispatch_regime(shared_chip=False, brick_cap=0):
+    """launches made by THIS thread inside the block are dispatched for a shared chip (several chunks in flight) / with the k3 direct
+    kernel's brick capped at `brick_cap` voxels; the previous regime of the thread is restored on exit (nesting is fine)"""
+    old = regime()
+    _REGIME.value = (bool(shared_chip), int(brick_cap))
+    try:
+        yield
+    finally:
+        _REGIME.value = old
 
 
 def _stream():
@@ -33,8 +62,9 @@ def _ptr(t):
 
 
 # ---------------------------------------------------------------------- NMS --
-def nms_raw(dets, thresh, max_keep=0):
-    """-> (keep int64 [n], num_keep int32 [1]) on the device; no host sync."""
+def nms_raw(dets, thresh, max_keep=0, path=0):
+    """-> (keep int64 [n], num_keep int32 [1]) on the device; no host sync.  path: 0 = algorithm by size, 1 = one-workgroup sweep,
+    2 = sparse suppressor table + parallel resolve (same keep list; the parity tests force both)."""
     dets = _dev(dets, "dets").contiguous()
     if dets.dim() != 2 or dets.shape[1] != 6:
         raise _lib.Sis3dError("dets must be (N,6)")
@@ -43,20 +73,15 @@ def nms_raw(dets, thresh, max_keep=0):
     num = torch.empty(1, dtype=torch.int32, device=dets.device)      # written by the sweep kernel on every path
     wsb = lib().sis3d_nms_workspace_bytes(n)
     ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dets.device)
-    check(lib().sis3d_nms(_ptr(dets), n, float(thresh), int(max_keep), _ptr(keep), _ptr(num), _ptr(ws), wsb, _stream()), "sis3d_nms")
+    check(lib().sis3d_nms(_ptr(dets), n, float(thresh), int(max_keep), _ptr(keep), _ptr(num), _ptr(ws), wsb, int(path), _stream()), "sis3d_nms")
     return keep, num
 
 
-def nms_set_path(path):
-    """0 = choose by size, 1 = one-workgroup sweep, 2 = sparse suppressor table + parallel resolve (same keep list)"""
-    check(lib().sis3d_nms_set_path(int(path)), "sis3d_nms_set_path")
-
-
-def nms(dets, thresh, max_keep=0):
+def nms(dets, thresh, max_keep=0, path=0):
     """lib/layer_utils/nms_wrapper.py:7-16 semantics: LongTensor (K,) of kept indices on dets' device.
     The result length is data dependent -> one 4-byte D2H read (the reference copies the whole
     bit matrix and sweeps on the host)."""
-    keep, num = nms_raw(dets, thresh, max_keep)
+    keep, num = nms_raw(dets, thresh, max_keep, path)
     return keep[:int(num.item())].contiguous()
 
 
@@ -314,15 +339,20 @@ def compute_projection(depths, view_params, volume_dims, image_dims, intrinsic, 
 TSDF_MODES = {"abs": 0, "flip": 1, "log": 2}
 
 
-def tsdf_encode(sdf, dims, truncated=3.0, mode="abs", max_height=None, channels_last=True):
+def tsdf_encode(sdf, dims, truncated=3.0, mode="abs", max_height=None, channels_last=True, out=None):
     """raw sdf grid in file order (flat, x fastest; numel X*Y*Z, cuda) -> network input, logical (1,2,X,Yout,Z)
-    (dataset.py:54-70 + the max-height crop :196-211)."""
+    (dataset.py:54-70 + the max-height crop :196-211).  out: a contiguous planar (1,2,X,Yout,Z) buffer to write into (the static
+    input buffer of a chunk pipeline: engine.PipelinedEngines.run_fed)."""
     sdf = _dev(sdf, "sdf").contiguous()
     X, Y, Z = (int(v) for v in dims)
     if sdf.numel() != X * Y * Z:
         raise _lib.Sis3dError("tsdf_encode: sdf has %d elements, dims say %d" % (sdf.numel(), X * Y * Z))
     Yo = Y if max_height is None else min(Y, int(max_height))
-    if channels_last:
+    if out is not None:
+        if tuple(out.shape) != (1, 2, X, Yo, Z) or not out.is_contiguous() or not out.is_cuda or out.dtype != torch.float32:
+            raise _lib.Sis3dError("tsdf_encode: `out` must be a contiguous float32 (1,2,%d,%d,%d) cuda tensor" % (X, Yo, Z))
+        st = (X * Yo * Z, Yo * Z, Z, 1)
+    elif channels_last:
         out = new_act(2, (X, Yo, Z), sdf.device)
         st = (1, Yo * Z * 2, Z * 2, 2)
     else:
@@ -481,7 +511,7 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     if SPLIT_BF16 and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs):
         return conv3d_k3b16(xs, pcs, None, relu=relu, outs=outs, out_coff=out_coff)
     if WINOGRAD and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs) and \
-            lib().sis3d_conv3d_k3wino_prefer(X, Y, Z, p0.cin, p0.cout, n):
+            lib().sis3d_conv3d_k3wino_prefer(X, Y, Z, p0.cin, p0.cout, n, int(regime()[0])):
         try:
             return conv3d_k3wino(xs, pcs, relu=relu, outs=outs, out_coff=out_coff)
         except Sis3dUnsupported:
@@ -496,8 +526,12 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     wps = arr(*[pc.packed_t16.data_ptr() for pc in pcs])
     bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
     os_ = arr(*[o.data_ptr() for o in outs])
+    if brick is None:
+        brick = K3_BRICK
+        if brick < 0 and regime()[1] > 0:              # the thread's regime caps the brick: ask for the choice under that cap
+            brick = lib().sis3d_conv3d_k3t16_brick(X, Y, Z, p0.cin, p0.cout, n, regime()[1])
     rc = lib().sis3d_conv3d_k3t16(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, EPI_RELU if relu else 0, os_, outs[0].shape[1],
-                                  int(out_coff), K3_BRICK if brick is None else int(brick), _stream())
+                                  int(out_coff), int(brick), _stream())
     if rc == -4:
         raise Sis3dUnsupported("conv3d_k3t16: unsupported shape")
     check(rc, "sis3d_conv3d_k3t16")
@@ -511,21 +545,22 @@ WINOGRAD = bool(int(_os.environ.get("SIS3D_WINOGRAD", "1") or 0))
 # bench.py's accounting hook: while a dict is installed, every launch of the Winograd kernel adds the ALGORITHMIC (direct-convolution)
 # FLOP count of the problems it serves, so that the bench can price a stage on the FLOPs the matrix pipe really executes
 # (algorithmic - saved, saved = wino_algorithmic * (1 - 64/216)) whatever the dispatch rule currently sends to that kernel
-FLOP_TALLY = None
+_TALLY = _threading.local()         # per thread, like the dispatch regime: a thread counts its own launches
 
 
 def flop_tally(on):
-    """start (True -> returns the fresh dict) / stop (False -> returns the filled dict) the Winograd FLOP accounting"""
-    global FLOP_TALLY
-    old = FLOP_TALLY
-    FLOP_TALLY = {"wino_algorithmic_flops": 0.0, "wino_launches": 0} if on else None
-    return FLOP_TALLY if on else old
+    """start (True -> returns the fresh dict) / stop (False -> returns the filled dict) the Winograd FLOP accounting of the
+    calling thread"""
+    old = getattr(_TALLY, "value", None)
+    _TALLY.value = {"wino_algorithmic_flops": 0.0, "wino_launches": 0} if on else None
+    return _TALLY.value if on else old
 
 
 def _tally_wino(flops):
-    if FLOP_TALLY is not None:
-        FLOP_TALLY["wino_algorithmic_flops"] += float(flops)
-        FLOP_TALLY["wino_launches"] += 1
+    t = getattr(_TALLY, "value", None)
+    if t is not None:
+        t["wino_algorithmic_flops"] += float(flops)
+        t["wino_launches"] += 1
 
 
 def set_winograd(on):
@@ -574,7 +609,8 @@ def conv3d_k3wino(xs, pcs, relu=True, outs=None, out_coff=0):
     wps = arr(*[w.data_ptr() for w in wps_t])
     bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
     os_ = arr(*[o.data_ptr() for o in outs])
-    rc = lib().sis3d_conv3d_k3wino(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, EPI_RELU if relu else 0, os_, outs[0].shape[1],
+    flags = (EPI_RELU if relu else 0) | (DISPATCH_SHARED_CHIP if regime()[0] else 0)
+    rc = lib().sis3d_conv3d_k3wino(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, flags, os_, outs[0].shape[1],
                                    int(out_coff), _stream())
     if rc == -4:
         raise Sis3dUnsupported("conv3d_k3wino: unsupported shape")
@@ -686,14 +722,14 @@ def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick
         raise _lib.Sis3dError("bottleneck16: layer shapes do not form a Bottleneck")
     if spc is not None and (spc.k != 1 or spc.cin != pc3.cout or not stage.get("relu", True)):
         raise Sis3dUnsupported("bottleneck16: stage must be a k=1 conv + ReLU on the block output")
-    if WINOGRAD and BNECK_WINO and brick < 0 and lib().sis3d_bottleneck_wino_prefer(X, Y, Z, pl, pc3.cout, spc.cout if spc else 0):
+    if WINOGRAD and BNECK_WINO and brick < 0 and lib().sis3d_bottleneck_wino_prefer(X, Y, Z, pl, pc3.cout, spc.cout if spc else 0, int(regime()[0])):
         try:
             # r4: conv2 by Winograd F(2x2x2, 3x3x3) with the 1x1x1 tail in its epilogue: the planes = 32 blocks of the 48 x 24 x 48 maps
             return bottleneck_wino(y1, pc2, pc3, residual, out=out, out_coff=out_coff, stage=stage)
         except Sis3dUnsupported:
             pass
     elif WINOGRAD and BNECK_WINO and brick < 0 and spc is not None and out is None and spc.packed_pw16 is not None and \
-            lib().sis3d_bottleneck_wino_prefer(X, Y, Z, pl, pc3.cout, 0):
+            lib().sis3d_bottleneck_wino_prefer(X, Y, Z, pl, pc3.cout, 0, int(regime()[0])):
         # shared chip, Bottleneck(128, 32) of the 24 x 12 x 24 maps: the body on the Winograd kernel (27 work items) and the NEXT block's
         # conv1 as its own pointwise launch -- the kernel has no instantiation that holds both 128-channel weight sets of the tail
         try:

@@ -14,6 +14,8 @@ import os as _os
 # capture_round's staggered start (pipeline e waits for pipeline e - 1's level 1): measured and lost on the 4-chunk share
 # (1.357 vs 1.331 ms in the same box run, tools/r04_scene_share.sh) -- off by default, kept as an A/B switch
 ROUND_STAGGER = _os.environ.get("SIS3D_ROUND_STAGGER", "0") != "0"
+# lazy results: the whole-scene merge on its own stream (A/B switch; on by default since r5)
+MERGE_STREAM = _os.environ.get("SIS3D_MERGE_STREAM", "1") != "0"
 
 
 def fused_merge(blocks, k_rows, thresh, score_col, box_col, max_keep):
@@ -28,13 +30,26 @@ class SceneResult(object):
     one 8-byte readback and slices; a pipelined caller launches the next scene first and resolves this one afterwards, so the
     host never stands between two scenes."""
 
-    def __init__(self, recs, order, keep, counts, k_rows, with_chunk_ids):
+    def __init__(self, recs, order, keep, counts, k_rows, with_chunk_ids, done=None):
         self.recs, self.order, self.keep, self.counts = recs, order, keep, counts
         self.k_rows, self.with_chunk_ids = int(k_rows), bool(with_chunk_ids)
+        self._done = done               # event on the merge stream (the tables are written there, not on the caller's stream)
         self._out = None
+
+    @classmethod
+    def resolved(cls, out):
+        """an eager result behind the lazy interface: `infer(lazy=True)` ALWAYS returns a SceneResult, also on the paths that had to
+        read lengths on the host already (masks, tables beyond the fused merge's 8192 rows, CPU tables)"""
+        r = cls(None, None, None, None, 1, False)
+        r._out = tuple(out)
+        return r
 
     def resolve(self):
         if self._out is None:
+            if self._done is not None:
+                self._done.synchronize()
+                # later work of the caller's stream that touches the tables is ordered behind the merge
+                torch.cuda.current_stream().wait_event(self._done)
             total, kept = self.counts.tolist()
             out = (self.recs[:total], self.keep[:kept])
             if self.with_chunk_ids:
@@ -59,6 +74,8 @@ class SceneRunner:
         self._origins = {}
         self._send = None
         self._round = None          # (graph, stream, send buffer): one launch for a share of exactly len(engines) chunks
+        self._round_ok, self._round_error = True, None
+        self._merge_stream = None
 
     def mask_fn(self, payload, windows, classes, values=False):
         """mask head of one chunk's surviving detections: one ragged launch per layer for all its boxes, then the predicted
@@ -96,20 +113,30 @@ class SceneRunner:
         mine = parallel.shard_chunks(len(chunks), rank, world)
         bf = parallel.block_floats(self.k_rows)
         dev = self.pipes.engines[0].device
-        if self.use_graph and len(mine) == len(self.pipes.engines) and all(not isinstance(chunks[c][2], (tuple, list)) for c in mine):
-            return self._run_round(chunks, mine, bf, dev)
+        streamed = self._streamed(chunks, mine)
+        if self.use_graph and len(mine) == len(self.pipes.engines) and all(not isinstance(chunks[c][2], (tuple, list)) for c in mine) \
+                and self.prepare_round():
+            return self._run_round(chunks, mine, bf, dev, streamed)
         if self._send is None or self._send.shape[0] != len(mine):
             self._send = torch.zeros(max(1, len(mine)), bf, device=dev)
         send = self._send
+        n = len(self.pipes.engines)
         with torch.no_grad():
             for j, c in enumerate(mine):
                 cid, origin, payload = chunks[c]
-                e = j % len(self.pipes.engines)
-                if isinstance(payload, (tuple, list)):
+                e = j % n
+                eng = self.pipes.engines[e]
+                if streamed:
+                    # host chunks (pinned): uploaded on the copy stream one chunk ahead of the pipeline that consumes them
+                    if not self.pipes.is_fed(e, payload):
+                        self.pipes.feed(e, payload)
+                    self.pipes.consume(e, self.pipes.streams[e])
+                    if j + n < len(mine):
+                        self.pipes.feed(e, chunks[mine[j + n]][2])
+                elif isinstance(payload, (tuple, list)):
                     self.pipes.load(e, *payload)
                 else:
                     self.pipes.load(e, payload)
-                eng = self.pipes.engines[e]
                 with torch.cuda.stream(self.pipes.streams[e]):
                     eng.origins[0].copy_(self._origin(origin), non_blocking=True)
                     out = eng.run()
@@ -117,25 +144,68 @@ class SceneRunner:
             self.pipes.join()
         return send[:len(mine)]
 
-    def _run_round(self, chunks, mine, bf, dev):
+    def _streamed(self, chunks, mine):
+        """True when every chunk of this rank's share arrives as a pinned HOST grid: the double-buffered upload path
+        (PipelinedEngines.feed / consume) serves it; the feeder is set up on first use"""
+        if not mine:
+            return False
+        ok = all(torch.is_tensor(chunks[c][2]) and not chunks[c][2].is_cuda and chunks[c][2].is_pinned() for c in mine)
+        if ok and not hasattr(self.pipes, "_feed"):
+            self.pipes.enable_feed("grid")
+        return ok
+
+    def prefetch(self, chunks, group=None):
+        """start uploading the first chunk of every pipeline of a scene whose chunks sit in pinned host memory -- call it right after
+        infer() of the PREVIOUS scene has been enqueued: the uploads then run under that scene's compute (the copy stream waits only
+        for the staging buffers, not for the pipelines)"""
+        rank, world = self._rank_world(group)
+        mine = parallel.shard_chunks(len(chunks), rank, world)
+        if not self._streamed(chunks, mine):
+            return 0
+        n, fed = len(self.pipes.engines), 0
+        for j, c in enumerate(mine[:n]):
+            if self.pipes.pending(j % n) == 0 and self.pipes.feed(j % n, chunks[c][2]):
+                fed += 1
+        return fed
+
+    def prepare_round(self):
+        """capture the one-launch round graph now (outside any timed or pipelined call): a share of exactly one chunk per pipeline
+        then costs ONE graph launch per scene.  On failure the per-chunk path keeps serving (returns False)."""
+        if self._round is None and self.use_graph and self._round_ok:
+            bf = parallel.block_floats(self.k_rows)
+            dev = self.pipes.engines[0].device
+            try:
+                torch.cuda.synchronize()
+                send = torch.zeros(len(self.pipes.engines), bf, device=dev)
+                g, main = self.pipes.capture_round(send, stagger=ROUND_STAGGER)
+                self._round = (g, main, send)
+            except Exception as e:                      # a capture that fails must not take inference down: per-chunk graphs serve
+                self._round_ok = False
+                self._round_error = "%s: %s" % (type(e).__name__, e)
+        return self._round is not None
+
+    def _run_round(self, chunks, mine, bf, dev, streamed=False):
         """the share is exactly one chunk per pipeline: inputs copied into the static buffers on ONE stream, then ONE graph launch
         (PipelinedEngines.capture_round) runs all of them and leaves their record blocks in the send buffer; the caller's stream
         is ordered behind the graph, no host-side join"""
-        if self._round is None:
-            send = torch.zeros(len(mine), bf, device=dev)
-            g, main = self.pipes.capture_round(send, stagger=ROUND_STAGGER)
-            self._round = (g, main, send)
         g, main, send = self._round
         cur = torch.cuda.current_stream()
         main.wait_stream(cur)
+        if streamed:
+            for e, c in enumerate(mine):
+                if not self.pipes.is_fed(e, chunks[c][2]):
+                    self.pipes.feed(e, chunks[c][2])
         with torch.no_grad(), torch.cuda.stream(main):
             for e, c in enumerate(mine):
                 cid, origin, payload = chunks[c]
                 eng = self.pipes.engines[e]
-                eng._copy(eng.scenes[0], payload)
+                if streamed:
+                    self.pipes.consume(e, main)
+                else:
+                    eng._copy(eng.scenes[0], payload)
+                    if payload.is_cuda:
+                        payload.record_stream(main)
                 eng.origins[0].copy_(self._origin(origin), non_blocking=True)
-                if payload.is_cuda:
-                    payload.record_stream(main)
             g.replay()
         cur.wait_stream(main)
         return send
@@ -146,7 +216,8 @@ class SceneRunner:
         every rank; with_masks adds this rank's {position in keep: (scene window, mask)} (parallel.scene_masks).
         gathered: a (n_chunks, block_floats) table standing in for the collective's result -- this rank's fresh rows are written
         over its own chunks' rows and the merge runs on the FULL table (bench.py: what one rank of an N-rank run does, minus
-        the collective itself).  lazy: return a SceneResult (lengths still on the device) instead of resolving it."""
+        the collective itself).  lazy: ALWAYS return a SceneResult -- lengths still on the device where the fused merge serves
+        the table, already resolved otherwise (with_masks, > 8192 rows, CPU tables) -- whose resolve() gives the eager tuple."""
         thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
         n_chunks = len(chunks)
         with torch.no_grad():
@@ -158,12 +229,30 @@ class SceneRunner:
             else:
                 blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group, solo=self.solo)
             if lazy and not with_masks and blocks.is_cuda and blocks.shape[0] * self.k_rows <= 8192:
+                if MERGE_STREAM:
+                    # r5: the merge of scene k runs on its own stream, ordered behind the gathered table only, so the stream that
+                    # launches scene k + 1's detection graphs does not queue behind ~85 us of one-to-64-workgroup merge kernels
+                    if self._merge_stream is None:
+                        self._merge_stream = torch.cuda.Stream()
+                    ms = self._merge_stream
+                    ms.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(ms):
+                        recs, order, keep, counts = ops.scene_merge_raw(blocks, self.k_rows, thresh, 6, 0, max_keep)
+                        done = torch.cuda.Event()
+                        done.record(ms)
+                    blocks.record_stream(ms)
+                    if blocks.data_ptr() == local.data_ptr():
+                        # a world of one: the table IS this rank's send buffer, which the next scene's graphs overwrite --
+                        # they must wait for the merge (no overlap to be had; with a gathered / received table there is)
+                        torch.cuda.current_stream().wait_event(done)
+                    return SceneResult(recs, order, keep, counts, self.k_rows, False, done=done)
                 recs, order, keep, counts = ops.scene_merge_raw(blocks, self.k_rows, thresh, 6, 0, max_keep)
                 return SceneResult(recs, order, keep, counts, self.k_rows, False)
             if not with_masks:
-                return parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, merge_fn=fused_merge)
+                out = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, merge_fn=fused_merge)
+                return SceneResult.resolved(out) if lazy else out
             recs, keep, cids = parallel.merge_scene(blocks, self.k_rows, ops.nms, thresh, max_keep=max_keep, with_chunk_ids=True,
                                                     merge_fn=fused_merge)
             fn = (lambda p, w, k: self.mask_fn(p, w, k, values=True)) if mask_values else self.mask_fn
             masks = parallel.scene_masks(recs, keep, cids, chunks, fn, float(self.net.cfg.CLASS_THRESH), group, solo=self.solo)
-            return recs, keep, masks
+            return SceneResult.resolved((recs, keep, masks)) if lazy else (recs, keep, masks)

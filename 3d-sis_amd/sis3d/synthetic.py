@@ -28,6 +28,15 @@ def synth_chunk(chunk_id=0, dims=CHUNK_DIMS, truncated=3.0):
     return data
 
 
+def synth_sdf(chunk_id=0, dims=CHUNK_DIMS):
+    """the raw signed-distance block behind synth_chunk(chunk_id), flat in .chunk FILE order (x fastest, then y, then z:
+    datagen/SceneSampler/main.cpp:348-415): what a reader hands to ops.tsdf_encode / a pipeline fed in 'sdf' mode;
+    encoding it (dataset.py:54-70) gives synth_chunk(chunk_id) bit for bit"""
+    g = torch.Generator().manual_seed(1234 + int(chunk_id))
+    tsdf = 2.0 * torch.randn(*dims, generator=g)
+    return tsdf.permute(2, 1, 0).contiguous().view(-1)
+
+
 def synth_state_dict(shapes, seed=0, gains=None):
     """shapes: {name: shape}; gains: {substring: factor} applied to matching names."""
     out = {}

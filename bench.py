@@ -102,7 +102,11 @@ def parse(argv=None):
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE) over the "
                     "dominant kernel at the end of an N = 1 run; `roofline.traffic` then is the committed figure of profiles/")
-    ap.add_argument("--no-split-line", action="store_true", help="skip the separately reported split-bf16 measurement")
+    ap.add_argument("--split-line", action="store_true", help="also time the opt-in split-bf16 variant of the k3 convs (separately "
+                    "reported, never the headline; off by default since r5: it does not beat the exact-fp32 path in throughput)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the streamed-input variants (fresh chunks from pinned host memory)")
+    ap.add_argument("--no-side-configs", action="store_true", help="N = 1 default run: skip the detect / detect_masks / images / "
+                    "images_rgb sub-objects (BASELINE configs[2], [3])")
     ap.add_argument("--no-side-workloads", action="store_true", help="time only the headline workload (no chunk_pipeline / scene side keys)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # launch / rendezvous logic under gloo, no GPU
@@ -292,24 +296,20 @@ def executed_flops(algorithmic, wino_algorithmic):
 def wino_accounting(net, shared=False):
     """ALGORITHMIC FLOPs of the launches that take the Winograd kernel, in the backbone proper and in backbone + RPN of one chunk:
     one eager pass of each with ops.flop_tally on (whatever the dispatch rule sends there today is what gets counted).  shared: count
-    under the shared-chip dispatch (sis3d_conv3d_k3wino_set_shared_chip), which is what pipelines of several chunks in flight capture --
+    under the shared-chip dispatch (ops.dispatch_regime(shared_chip=True)), which is what pipelines of several chunks in flight capture --
     more layers take the Winograd kernel there, so fewer FLOPs are executed."""
     import torch
     from sis3d import ops, synthetic
     scene = synthetic.synth_chunk(0).cuda().float()
     out = {}
-    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1 if shared else 0)
-    try:
-        with torch.no_grad():
-            for name, fn in (("backbone", net.backbone_only), ("backbone_rpn", net.backbone_rpn)):
-                ops.flop_tally(True)
-                try:
-                    fn(scene)
-                finally:
-                    out[name] = ops.flop_tally(False)["wino_algorithmic_flops"]
-        torch.cuda.synchronize()
-    finally:
-        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
+    with torch.no_grad(), ops.dispatch_regime(shared_chip=shared, brick_cap=(108 if shared else 0)):
+        for name, fn in (("backbone", net.backbone_only), ("backbone_rpn", net.backbone_rpn)):
+            ops.flop_tally(True)
+            try:
+                fn(scene)
+            finally:
+                out[name] = ops.flop_tally(False)["wino_algorithmic_flops"]
+    torch.cuda.synchronize()
     return out
 
 
@@ -463,14 +463,103 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_threads_rule():
+    """ONE stated rule for the CPU baseline's thread count (the 16/32/64/128 sweep moved the figure 2x between
+    boxes): the physical cores of one socket of the host, capped at 64 -- oneDNN's 3D convolutions on a 0.1-GFLOP/voxel chunk stop
+    scaling there, SMT siblings and the second socket only add contention.  SIS3D_CPU_THREADS overrides."""
+    env = os.environ.get("SIS3D_CPU_THREADS")
+    if env:
+        return max(1, int(env)), "SIS3D_CPU_THREADS"
+    cores = os.cpu_count() or 1
+    try:
+        phys, sockets = set(), set()
+        with open("/proc/cpuinfo") as f:
+            pid = cid = None
+            for ln in f:
+                if ln.startswith("physical id"):
+                    pid = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    cid = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                        sockets.add(pid)
+                    pid = cid = None
+        if phys:
+            per_socket = max(1, len(phys) // max(1, len(sockets)))
+            return min(64, per_socket), "physical cores of one socket (%d sockets x %d cores, %d logical), capped at 64" % (
+                len(sockets), per_socket, cores)
+    except Exception:
+        pass
+    return min(64, max(1, cores // 2)), "half of the logical CPUs, capped at 64 (no /proc/cpuinfo topology)"
+
+
+def _median_runs(fn, budget_s, min_runs=10, max_runs=200):
+    """median wall time of fn over >= min_runs runs (one untimed warm-up), stopping after budget_s once min_runs are in"""
+    fn()
+    ts, t_end = [], time.time() + budget_s
+    while len(ts) < min_runs or (time.time() < t_end and len(ts) < max_runs):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], len(ts), ts[0], ts[-1]
+
+
+def cpu_baseline_reference(workload, sd, cfg, seconds, threads):
+    """BASELINE config[0]: the REFERENCE's own `Network.forward(blobs, 'TEST', [])` (lib/nets/network.py:187-317) timed in place on
+    the host cores -- the README's MAX_VOLUME=0 CPU path in full (`.cuda()` neutralised, the reference's own roi_pooling.c for
+    RoIPoolFunction: oracle/ref_harness.py), same seeded weights and the same synthetic chunk as the GPU run.  Runs from
+    /root/reference in the build container and from the staged archive oracle/_ref/reference_tree.tgz on the GPU box (verified
+    against tests/golden/reference_tree.sha256 by ref_harness).  -> dict | None (reference not available)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import ref_harness as rh
+    except Exception:
+        return None
+    if not rh.available() or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_roi_pooling.so")):
+        return None
+    from sis3d import synthetic
+    use_images = workload == "images"
+    ns = rh.install()
+    try:
+        net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=False)
+        missing = [k for k in net.state_dict() if k not in sd]
+        if missing:
+            return {"error": "reference net has parameters the synthetic checkpoint lacks: %s" % missing[:3]}
+        net.load_state_dict({k: sd[k] for k in net.state_dict()})
+        data = synthetic.synth_chunk(0)
+        if use_images:
+            feats, i3d, i2d = synthetic.synth_views(0)
+            blobs = rh.make_blobs(data, feats, i3d, i2d)
+        else:
+            blobs = rh.make_blobs(data)
+        torch.set_num_threads(threads)
+        per, n, lo, hi = _median_runs(lambda: rh.forward(ns, net, blobs), seconds)
+        rois = int(net._predictions["rois"][0].shape[0]) if "rois" in net._predictions else None
+    finally:
+        rh.restore_cuda()
+    return {"value": VOXELS / per, "unit": "voxels/s", "cores": threads, "kind": "reference", "runs": n,
+            "ms_per_chunk_median": per * 1e3, "ms_per_chunk_min_max": [lo * 1e3, hi * 1e3], "rois": rois,
+            "reference_from": rh.REF_SOURCE,
+            "what": "the reference's unmodified Network.forward TEST branch (backbone + RPN + proposal_layer/cpu_nms + RoI pooling (its own "
+                    "roi_pooling.c) + classifier), torch-CPU operators, on one 96x48x96 synthetic chunk"}
+
+
 def cpu_baseline(workload, sd, cfg, seconds):
-    """The oracle (torch-CPU operators, as the reference's MAX_VOLUME=0 path) on the host cores: the workload's forward at the
-    best thread count of a short sweep (the headline `value`) and at 1 thread, plus a per-stage table."""
+    """CPU baseline beside the GPU number (reported, never the target).  kind "reference" = the reference itself run in place
+    (cpu_baseline_reference) when its tree is available, with the oracle port's figure of the SAME workload beside it under `port`;
+    kind "port" (the oracle, torch-CPU operators = what the reference's MAX_VOLUME=0 path runs) otherwise.  Thread count: one stated
+    rule (cpu_threads_rule), median of >= 10 runs; the single-thread figure and a per-stage table from the
+    port."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sis3d_oracle as orc
     from sis3d import config, synthetic
     cores = os.cpu_count() or 1
+    threads, rule = cpu_threads_rule()
+    threads = max(1, min(threads, cores))
     net = orc.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
     data = synthetic.synth_chunk(0)
     feats = i3d = i2d = None
@@ -499,29 +588,25 @@ def cpu_baseline(workload, sd, cfg, seconds):
                 break
         return (time.time() - t0) / n, n
 
-    # oneDNN does not scale to hundreds of threads on a 0.1-GFLOP/voxel workload: pick the best of a short sweep
-    best_t, best = None, None
-    for t in [c for c in (16, 32, 64, 128) if c <= cores] or [cores]:
-        torch.set_num_threads(t)
-        d, _ = timed(one, 0.0, 2)
-        if best is None or d < best:
-            best_t, best = t, d
-        if d > 2.0 * best:
-            break
-    torch.set_num_threads(best_t)
-    per, n = timed(one, seconds * 0.5)
-    # per-stage table at the best thread count, then the whole forward at one thread
+    ref = None
+    try:
+        ref = cpu_baseline_reference(workload, sd, cfg, seconds * 0.35, threads)
+    except Exception as e:                                   # the reported baseline must never take the line down
+        ref = {"error": "%s: %s" % (type(e).__name__, e)}
+    torch.set_num_threads(threads)
+    per, n, lo, hi = _median_runs(one, seconds * (0.25 if ref and "value" in ref else 0.5))
+    # per-stage table at the same thread count, then the whole forward at one thread
     stages = {}
     with torch.no_grad():
         l1, l2 = net.backbone(data, None) if workload != "images" else net.backbone(data, orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
         o = None
         if not cfg["USE_IMAGES"]:
             o = net.forward(data)
-        share = seconds * 0.3 / 6.0
+        share = seconds * 0.25 / 6.0
 
         def st(name, fn, unit_work=VOXELS):
             d, k = timed(lambda: fn(), share, 50)
-            stages[name] = {"ms": d * 1e3, "threads": best_t, "runs": k}
+            stages[name] = {"ms": d * 1e3, "threads": threads, "runs": k}
         if workload != "images":
             st("backbone", lambda: net.backbone(data, None))
         st("rpn_convs_heads", lambda: (net.rpn(l1, 1), net.rpn(l2, 2)))
@@ -544,14 +629,27 @@ def cpu_baseline(workload, sd, cfg, seconds):
         if feats is not None:
             st("projection_view_max", lambda: orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
     torch.set_num_threads(1)
-    per1, n1 = timed(one, seconds * 0.2, 3)
-    torch.set_num_threads(best_t)
-    return dict(value=VOXELS / per, unit="voxels/s", cores=best_t, kind="port", host_cores=cores, cpu=cpu_model(),
-                single_thread={"value": VOXELS / per1, "unit": "voxels/s", "cores": 1, "runs": n1},
-                stages=stages,
-                sample="%d forward passes of one 96x48x96 chunk (%s; oracle = the reference's CPU operators via torch-CPU/oneDNN, "
-                       "%d threads, best of a 16/32/64/128 sweep) in %.1f s; stages: per-stage means at the same thread count; "
-                       "single_thread: %d passes" % (n, workload, best_t, per * n, n1))
+    per1, n1 = timed(one, seconds * 0.15, 3)
+    torch.set_num_threads(threads)
+    port = {"value": VOXELS / per, "unit": "voxels/s", "cores": threads, "kind": "port", "runs": n,
+            "ms_per_chunk_median": per * 1e3, "ms_per_chunk_min_max": [lo * 1e3, hi * 1e3],
+            "what": "the pinned oracle (oracle/sis3d_oracle.py: the reference's CPU operators via torch-CPU/oneDNN) on the GPU line's own "
+                    "workload (%s)" % workload}
+    head = ref if (ref and "value" in ref) else port
+    out = dict(value=head["value"], unit="voxels/s", cores=threads, kind=head["kind"], host_cores=cores, cpu=cpu_model(),
+               threads_rule=rule, runs=head["runs"], ms_per_chunk_median=head["ms_per_chunk_median"],
+               ms_per_chunk_min_max=head["ms_per_chunk_min_max"],
+               single_thread={"value": VOXELS / per1, "unit": "voxels/s", "cores": 1, "runs": n1, "kind": "port"},
+               stages=stages, port=port,
+               sample=("%d forward passes of one 96x48x96 chunk; value = MEDIAN of the runs at %d threads (%s); "
+                       % (head["runs"], threads, rule))
+               + ("kind reference: the reference's own Network.forward TEST branch run in place (config[0], full detection pass); "
+                  "`port` = the oracle on the GPU line's workload (%s); " % workload if head is ref else
+                  "kind port: the oracle on the GPU line's workload (%s) -- the reference tree was not available here; " % workload)
+               + "stages: per-stage means of the port at the same thread count; single_thread: %d passes of the port" % n1)
+    if ref is not None:
+        out["reference"] = ref
+    return out
 
 
 def ops_mod():
@@ -572,6 +670,65 @@ def preheat(step, ms):
         for _ in range(16):
             step()
         torch.cuda.synchronize()
+
+
+def time_streamed(eng, args, rank, nfl, barrier, mode):
+    """The same pipelines on FRESH chunks from pinned host memory (the reference's forward owns the upload:
+    `blobs['data'].cuda()`, lib/nets/network.py:191): every step every pipeline consumes a chunk it has not seen in the previous
+    RING - 1 steps, uploaded on the copy stream one chunk ahead (PipelinedEngines.feed / run_fed), so the H2D copy of chunk k + 1 runs
+    under the compute of chunk k.  mode 'grid': the encoded (1,2,96,48,96) float32 grid the reference's dataloader hands over
+    (3.54 MB per chunk); 'sdf': the raw SDF block of a .chunk file (1.77 MB), TSDF-encoded on the device (sis3d_tsdf_encode).
+    -> dict(dt, bytes_per_chunk)"""
+    import torch
+    from sis3d import synthetic
+    RING = 4
+    torch.cuda.synchronize()
+    eng.enable_feed(mode)
+    ring = []
+    for i in range(nfl):
+        row = []
+        for r in range(RING):
+            cid = 1000 + (rank * nfl + i) * RING + r
+            t = synthetic.synth_chunk(cid) if mode == "grid" else synthetic.synth_sdf(cid)
+            row.append(t.contiguous().pin_memory())
+        ring.append(row)
+    for i in range(nfl):
+        eng.feed(i, ring[i][0])
+
+    def step(k):
+        for i in range(nfl):
+            eng.run_fed(i)
+            eng.feed(i, ring[i][(k + 1) % RING])
+    k = 0
+    for _ in range(max(args.warmup, 4)):
+        step(k)
+        k += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(k)
+        k += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    # drain: one chunk per pipeline is still staged
+    for i in range(nfl):
+        eng.run_fed(i)
+    torch.cuda.synchronize()
+    return dict(dt=dt, bytes_per_chunk=ring[0][0].numel() * 4, ring=RING)
+
+
+def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
+    ms = st["dt"] / steps * 1e3
+    chunks_per_s = vox_per_step / VOXELS * steps / st["dt"]
+    return {"value": vox_per_step * steps / st["dt"], "unit": "voxels/s", "ms_per_step": ms,
+            "ratio_to_resident": resident_dt / st["dt"], "host_bytes_per_chunk": st["bytes_per_chunk"],
+            "h2d_gbs_per_gpu": chunks_per_s / world * st["bytes_per_chunk"] / 1e9,
+            "input": ("encoded (1,2,96,48,96) float32 grid = the reference's blobs['data'] (lib/nets/network.py:191)" if mode == "grid"
+                      else "raw float32 SDF block in .chunk file order, TSDF-encoded on the device (sis3d_tsdf_encode; dataset.py:54-70)"),
+            "how": "every step each of the %d pipelines runs a chunk it was fed from PINNED HOST memory one chunk ahead: H2D on a copy "
+                   "stream into one of two staging buffers, device copy / encode into the graph's static input, graph replay "
+                   "(PipelinedEngines.feed / run_fed); ring of %d distinct host chunks per pipeline; the timed region contains every "
+                   "upload" % (nfl, st["ring"])}
 
 
 def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):
@@ -616,6 +773,27 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
     barrier()
     dt = time.perf_counter() - t0
     extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl}
+    streamed = {}
+    if workload in ("backbone_rpn", "detect") and not masks and grp == 1 and not args.no_graph and not args.no_streamed:
+        for mode in ("grid", "sdf"):
+            try:
+                streamed[mode] = time_streamed(eng, args, rank, nfl, barrier, mode)
+            except Exception as e:                               # a side measurement must never take the headline down
+                streamed[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the static buffers now hold ring chunks: put the resident chunks back (single-chunk latency / snapshots below use them)
+        for i in range(nfl):
+            eng.load(i, synthetic.synth_chunk(rank * nfl + i))
+        torch.cuda.synchronize()
+    # Winograd accounting of THIS configuration under the regime its pipelines captured: one eager pass of pipeline 0
+    wino_flops = None
+    if rank == 0 and grp == 1:
+        ops_mod().flop_tally(True)
+        try:
+            with torch.no_grad(), torch.cuda.stream(eng.streams[0]):
+                eng.engines[0]._step()
+        finally:
+            wino_flops = ops_mod().flop_tally(False)["wino_algorithmic_flops"]
+        torch.cuda.synchronize()
     if workload == "images" and args.rgb:
         extra["views_from"] = ("RGB images (5 x 3 x 256 x 328) through the ENet encoder inside the step (5.2 GFLOP; csrc/enet.hip, one launch "
                                "per bottleneck: 25 launches)")
@@ -715,18 +893,22 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
         torch.cuda.synchronize()
         o0 = eng.engines[0].out
         snap = {k: o0[k].detach().clone() for k in o0 if k.startswith("rpn_") and torch.is_tensor(o0[k])} if isinstance(o0, dict) else None
-    return dict(dt=dt, vox_per_step=world * nfl * grp * VOXELS, single_ms=single_ms, extra=extra, snap=snap)
+    return dict(dt=dt, vox_per_step=world * nfl * grp * VOXELS, single_ms=single_ms, extra=extra, snap=snap, streamed=streamed,
+                wino_flops=wino_flops, nfl=nfl)
 
 
 def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None, inflight=None, emulate=None, gathered=None,
-              want_table=False):
+              want_table=False, streamed=False, runner=None):
     """BASELINE config 5: n_chunks chunks of one scene (4 x 1 x n/4 grid of 96x48x96 chunks, origins `--scene-stride` apart),
     chunk c -> rank c mod W,
     per-chunk detection, ONE all-gather of the record blocks, whole-scene NMS on every rank.  A step = one whole scene.
     The host reads a scene's two result lengths (8 bytes) one step LATE -- after the next scene has been enqueued -- like a consumer
     that double-buffers its results; every scene's lengths are read, the last one inside the timed region.
     emulate = (r, W) + gathered = a full scene's gathered table: rank r's share of a W-rank run on this GPU alone -- its own chunks
-    (one graph launch when it owns one chunk per pipeline), its rows written over the table, the merge of the FULL table."""
+    (one graph launch when it owns one chunk per pipeline), its rows written over the table, the merge of the FULL table.
+    streamed: the rank's chunks sit in PINNED HOST memory and every scene uploads all of them (SceneRunner's double-buffered feed:
+    copy stream, one chunk ahead per pipeline; the next scene's first chunks are prefetched under the current scene's compute).
+    runner: reuse a SceneRunner (its captured graphs) from a previous call with the same sharding."""
     import torch
     from sis3d import parallel, synthetic
     from sis3d.scene import SceneRunner
@@ -735,19 +917,27 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         gr, gw = emulate
     n_local = len(range(gr, n_chunks, gw))
     nfl = inflight or (args.inflight if args.inflight > 0 else (n_local if n_local <= 4 else default_inflight("scene")))
-    runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph, inflight=max(1, nfl), solo=(group == "solo"), emulate=emulate)
+    if runner is None:
+        runner = SceneRunner(net, synthetic.CHUNK_DIMS, use_graph=not args.no_graph, inflight=max(1, nfl), solo=(group == "solo"), emulate=emulate)
     chunks = []
     for c in range(n_chunks):
-        payload = synthetic.synth_chunk(c).cuda() if c % gw == gr else None     # resident in HBM, own shard only
+        payload = None
+        if c % gw == gr:                                                         # own shard only
+            payload = synthetic.synth_chunk(c).contiguous().pin_memory() if streamed else synthetic.synth_chunk(c).cuda()
         chunks.append((c, scene_origin(c, args.scene_stride), payload))
     torch.cuda.synchronize()
     steps = steps or args.steps
     # late reads only where a scene is ONE graph launch (a share of <= 4 chunks, one per pipeline); with tens of per-chunk graph
     # launches per scene, letting the host run a whole scene ahead was measured slower (10.2 vs 8.65 ms for the 32-chunk scene)
     lazy = not args.masks and n_local == nfl and not args.no_graph
+    if lazy:
+        runner.prepare_round()              # the one-launch round graph is captured here, not inside the first timed / pipelined call
 
     def one():
-        return runner.infer(chunks, with_masks=args.masks, gathered=gathered, lazy=lazy)
+        r = runner.infer(chunks, with_masks=args.masks, gathered=gathered, lazy=lazy)
+        if streamed:
+            runner.prefetch(chunks)         # the next scene's first chunk of every pipeline: uploaded under this scene's compute
+        return r
 
     def done(r):
         return r.resolve() if lazy else r
@@ -772,11 +962,117 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     if args.masks:
         extra["masks_on_this_rank"] = len(res[2])
         extra["mask_voxels_on_this_rank"] = int(sum(m.numel() for _, m in res[2].values()))
-    out = dict(dt=dt, vox_per_step=n_chunks * VOXELS, single_ms=None, extra=extra, steps=steps)
+    out = dict(dt=dt, vox_per_step=n_chunks * VOXELS, single_ms=None, extra=extra, steps=steps, runner=runner)
+    if streamed:
+        torch.cuda.synchronize()
+        for e in range(len(runner.pipes.engines)):          # drain the chunks the last prefetch staged
+            while runner.pipes.pending(e):
+                runner.pipes.consume(e, runner.pipes.streams[e])
+        torch.cuda.synchronize()
     if want_table:
         with torch.no_grad():
             out["table"] = parallel.gather_blocks(runner.run_chunks(chunks), n_chunks, runner.k_rows, solo=True).clone()
         torch.cuda.synchronize()
+    return out
+
+
+def collective_latency_world_of_one(block_floats_per_rank, iters=50):
+    """The one collective of a scene -- `all_gather_into_tensor` of a rank's record blocks -- timed on THIS GPU in an RCCL world of
+    ONE (a one-GPU box has no peer: this is the call's launch + kernel latency, not an xGMI transfer; the payload at N = 8 is 8 x
+    51 KB, far below any link limit, so the latency term is what a rank pays).  HIP events around `iters` back-to-back calls.
+    -> (microseconds per call | None, how)"""
+    import torch
+    import torch.distributed as dist
+    made = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(free_port())
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+            made = True
+        send = torch.zeros(int(block_floats_per_rank), device="cuda")
+        recv = torch.empty(dist.get_world_size() * int(block_floats_per_rank), device="cuda")
+        for _ in range(5):
+            dist.all_gather_into_tensor(recv, send)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_gather_into_tensor(recv, send)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        return us, "RCCL all_gather_into_tensor of %d floats in a world of %d on this GPU, %d back-to-back calls, HIP events" % (
+            int(block_floats_per_rank), dist.get_world_size(), iters)
+    except Exception as e:
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+
+
+ENET_FLOPS = 5.2e9                      # 5 views of 256 x 328 through the encoder (SURVEY 8a row a15)
+
+
+def config_entry(res, steps, workload, masks=False, rgb=False, what=None):
+    """one BASELINE config as a sub-object of the line: throughput with `chunks_per_step_per_gpu` chunks in flight, latency of one
+    chunk alone, and the two roofline fractions of the STEP (executed MFMA FLOPs / time / 157.3 TF; algorithmic bytes / time / 8 TB/s)"""
+    ms = res["dt"] / steps * 1e3
+    nchunk = res["vox_per_step"] / VOXELS
+    algo = dict(ALGO[workload])
+    if masks and "mask_head_gflop" in res["extra"]:
+        algo["flops"] += res["extra"]["mask_head_gflop"] * 1e9
+    if rgb:
+        algo["flops"] += ENET_FLOPS
+    e = {"workload": what or WORKLOAD_TEXT[workload], "value": res["vox_per_step"] * steps / res["dt"], "unit": "voxels/s",
+         "ms_per_step": ms, "steps": steps, "chunks_per_step_per_gpu": nchunk, "single_chunk_latency_ms": res["single_ms"],
+         "hbm_frac": algo["bytes"] * nchunk / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         "algorithmic_gflop_per_chunk": algo["flops"] / 1e9}
+    if res.get("wino_flops") is not None:
+        ex = executed_flops(algo["flops"], res["wino_flops"])
+        e["fp32_frac"] = ex * nchunk / (ms * 1e-3) / 1e12 / FP32_PEAK_TF
+        e["executed_gflop_per_chunk"] = ex / 1e9
+    for k in ("mask_boxes", "mask_voxels", "mask_head_gflop", "mask_head_ms", "mask_head_fp32_frac", "mask_head_algorithmic_tflops",
+              "enet_ms_5_views", "enet_impl", "views_from"):
+        if k in res["extra"]:
+            e[k] = res["extra"][k]
+    return e
+
+
+def side_configs(args, rank, world, barrier):
+    """BASELINE configs[2] and [3] on the default N = 1 line: detect, detect + mask head, the 5-view image path
+    from feature maps and from RGB pixels -- each with its own network (the config decides the architecture), the same pipelines /
+    steps / warm-up as the headline, one after the other"""
+    import argparse as _ap
+    import gc
+    import torch
+    out = {}
+    plan = [("detect", "detect", False, False, "config[2]: backbone + RPN + decode / top-k / 3D NMS + RoI pooling + classifier (no mask head)"),
+            ("detect_masks", "detect", True, False, "config[2] in full: + mask head on a fixed deterministic detection set (the first "
+                                                    "%d post-NMS RoIs stand in as detections)" % args.mask_boxes),
+            ("images", "images", False, False, "config[3]: 5-view back-projection gather (feature maps given) + colour/geometry backbone + RPN"),
+            ("images_rgb", "images", False, True, "config[3] from pixels: 5 RGB views through the ENet encoder (csrc/enet.hip) inside the step, "
+                                                  "then as `images`")]
+    for key, workload, masks, rgb, what in plan:
+        a = _ap.Namespace(**vars(args))
+        a.masks, a.rgb, a.from_depth, a.group = masks, rgb, False, 1
+        a.inflight = default_inflight(workload)
+        a.no_streamed = True
+        t0 = time.perf_counter()
+        try:
+            net, cfg, _ = build_net(workload, masks=masks, rgb=rgb)
+            res = run_chunk_pipeline(net, cfg, a, rank, world, workload, barrier, masks=masks)
+            out[key] = config_entry(res, a.steps, workload, masks=masks, rgb=rgb, what=what)
+            out[key]["bench_wall_s"] = time.perf_counter() - t0
+        except Exception as e:                                   # a side config must never take the headline down
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        net = res = None
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     return out
 
 
@@ -896,8 +1192,36 @@ def main(argv=None):
     if both:
         side["chunk_pipeline"] = chunk_pipeline_entry(cp["vox_per_step"] * args.steps / cp["dt"], "voxels/s", cp["dt"] / args.steps * 1e3,
                                                       cp["vox_per_step"] / VOXELS / world, cp["single_ms"])
+        for mode, key in (("grid", "streamed"), ("sdf", "streamed_sdf")):
+            st = (cp.get("streamed") or {}).get(mode)
+            if st is not None:
+                if "dt" in st:
+                    st["dt"] = max_over_ranks(st["dt"])
+                    side["chunk_pipeline"][key] = streamed_entry(st, cp["dt"], args.steps, cp["vox_per_step"], cp["nfl"], world, mode)
+                else:
+                    side["chunk_pipeline"][key] = st
         side["scene"] = scene_entry(sc["vox_per_step"] * sc["steps"] / sc["dt"], "voxels/s", sc["dt"] / sc["steps"] * 1e3, sc["steps"],
                                     sc["extra"])
+        if not args.no_streamed and not args.masks and not args.no_graph:
+            # the same scene with every chunk uploaded from pinned host memory inside the timed region (same runner: same graphs)
+            try:
+                saved = args.inflight
+                if workload != "scene":
+                    args.inflight = 0
+                ss = run_scene(net, args, rank, world, args.scene_chunks, barrier, steps=sc["steps"], streamed=True, runner=sc.get("runner"))
+                args.inflight = saved
+                ss["dt"] = max_over_ranks(ss["dt"])
+                n_local = ss["extra"]["chunks_on_this_rank"]
+                side["scene"]["streamed"] = {
+                    "value": ss["vox_per_step"] * ss["steps"] / ss["dt"], "unit": "voxels/s", "ms_per_scene": ss["dt"] / ss["steps"] * 1e3,
+                    "ratio_to_resident": sc["dt"] / sc["steps"] / (ss["dt"] / ss["steps"]),
+                    "host_bytes_per_scene_per_gpu": n_local * 2 * VOXELS * 4,
+                    "records_gathered": ss["extra"]["records_gathered"], "kept_after_scene_nms": ss["extra"]["kept_after_scene_nms"],
+                    "how": "every scene uploads this rank's %d chunks (3.54 MB each, pinned host memory) through SceneRunner's "
+                           "double-buffered feed: copy stream, one chunk ahead per pipeline, the next scene's first chunks prefetched "
+                           "under the current scene's compute" % n_local}
+            except Exception as e:
+                side["scene"]["streamed"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world > 1 and rank == 0:
             # rank 0 alone on the same scene, same process: the 1-GPU reference point of the strong-scaling figure
             saved = args.inflight
@@ -920,15 +1244,39 @@ def main(argv=None):
                                emulate=(0, 8), gathered=sc["table"])
             finally:
                 args.inflight = saved_i
+            try:
+                from sis3d import parallel as _par
+                coll_us, coll_how = collective_latency_world_of_one(sh["extra"]["chunks_on_this_rank"] * _par.block_floats(200))
+            except Exception as e:
+                coll_us, coll_how = None, "%s: %s" % (type(e).__name__, e)
+            share_ms = sh["dt"] / sh["steps"] * 1e3
+            total_ms = share_ms + (coll_us or 0.0) * 1e-3
             side["scene"]["share_of_one_rank_at_8"] = {
-                "chunks": sh["extra"]["chunks_on_this_rank"], "ms": sh["dt"] / sh["steps"] * 1e3,
+                "chunks": sh["extra"]["chunks_on_this_rank"], "ms": share_ms,
+                "collective_us_world_of_one": coll_us, "collective_how": coll_how,
+                "ms_with_collective": total_ms,
                 "records_merged": sh["extra"]["records_gathered"], "kept_after_scene_nms": sh["extra"]["kept_after_scene_nms"],
                 "one_graph_launch_per_scene": sh["extra"]["one_graph_launch_per_scene"],
-                "ceiling_speedup_at_8": (sc["dt"] / sc["steps"]) / (sh["dt"] / sh["steps"]),
-                "how": "this GPU alone as rank 0 of 8: its scene_chunks/8 chunks, then the merge of the FULL scene's gathered table "
-                       "(its own rows fresh, the other ranks' rows from the 32-chunk run above): the per-rank critical path at N = 8 "
-                       "minus the collective itself"}
-    if rank == 0 and world == 1 and not args.masks and not args.no_split_line and not args.no_graph:
+                "ceiling_speedup_at_8": (sc["dt"] / sc["steps"] * 1e3) / total_ms,
+                "ceiling_without_collective_term": (sc["dt"] / sc["steps"] * 1e3) / share_ms,
+                "how": "this GPU alone as rank 0 of 8: its scene_chunks/8 chunks (one graph launch), then the merge of the FULL scene's "
+                       "gathered table (its own rows fresh, the other ranks' rows from the 32-chunk run above), PLUS the latency of the "
+                       "scene's one collective measured in an RCCL world of one on this GPU (collective_us_world_of_one; serial in "
+                       "this sum, although on hardware it overlaps with the next scene's detect).  An emulation on one GPU, not a "
+                       "measurement of an 8-GPU run: no xGMI transfer, no launch skew between ranks"}
+    if sc is not None:
+        sc.pop("runner", None)                       # the scene's engines and graphs are not needed any more
+    if both and rank == 0 and cp.get("wino_flops") is not None:
+        # the same two fractions every config sub-object carries (config_entry), for config[1] itself
+        ce = config_entry(cp, args.steps, "backbone_rpn")
+        side["chunk_pipeline"].update({k: ce[k] for k in ("fp32_frac", "hbm_frac", "executed_gflop_per_chunk", "algorithmic_gflop_per_chunk")
+                                       if k in ce})
+    if rank == 0 and world == 1 and args.workload == "auto" and not args.masks and not args.no_graph and not args.no_side_configs:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        side.update(side_configs(args, rank, world, barrier))
+    if rank == 0 and world == 1 and not args.masks and args.split_line and not args.no_graph:
         # SEPARATELY REPORTED (never the headline): the headline workload with the balanced k3 convs on the bf16 matrix
         # pipe, operands split hi + lo (csrc/conv3d_b16.hip); `value` above stays on the exact-fp32 kernels
         try:

@@ -54,11 +54,12 @@ const char *sis3d_last_hip_error(void);
  * one-workgroup sweep; larger n (a whole scene's records) take a sparse suppressor table +
  * parallel fixed-point resolve -- same keep list. */
 size_t sis3d_nms_workspace_bytes(int n);
-/* which of the two algorithms sis3d_nms uses: 0 = by size (default), 1 = one-workgroup sweep, 2 = parallel resolve
- * (tuning / parity hook; both give the same keep list) */
-int sis3d_nms_set_path(int path);
+/* path: which of the two algorithms this call uses: 0 = by size (what every product call passes), 1 = one-workgroup sweep,
+ * 2 = parallel resolve (parity hook: the tests force both at every size; both give the same keep list).  A per-call argument
+ * (r5; it was a process-wide switch before): nothing about the dispatch lives in library state, so calls on distinct streams
+ * from distinct threads do not interact. */
 int sis3d_nms(const float *boxes, int n, float thresh, int max_keep, int64_t *keep, int32_t *num_keep,
-              void *workspace, size_t workspace_bytes, sis3d_stream_t stream);
+              void *workspace, size_t workspace_bytes, int path, sis3d_stream_t stream);
 /* the IoU bit matrix alone: mask [n][ceil(n/64)] u64, bit j of word cb set iff
  * box 64*cb+j (> i) is suppressed by box i (nms_kernel.cu:34-79). */
 int sis3d_nms_mask(const float *boxes, int n, float thresh, uint64_t *mask, sis3d_stream_t stream);
@@ -352,16 +353,16 @@ int sis3d_rpn_heads(const float *in1, const float *packed_w1, const float *bias1
  * brick: index of the voxel brick (0: 6x6x12, 1: 6x6x6, 2: 3x6x6, 3: 3x3x6, 4: 4x4x4, 5: 4x4x8, 6: 4x8x8) or -1 =
  * sis3d_conv3d_k3t16_brick's choice (fewest SIMD-cycles on the busiest CU for this grid).  Any grid size; partial
  * bricks are masked. */
-/* process-wide cap on the brick volume sis3d_conv3d_k3t16_brick may choose (0 = none).  One chunk alone is fastest on the
- * largest brick (one workgroup per CU); with several chunks in flight on separate streams bricks of <= 108 voxels (46 KB of
- * LDS, 3 workgroups per CU) let the streams' kernels share the CUs (+3-4 % throughput, profiles/README.md). */
-int sis3d_conv3d_k3t16_set_brick_cap(int max_voxels);
+/* sis3d_conv3d_k3t16_brick(..., max_voxels): cap on the brick volume the choice may take (0 = none).  One chunk alone is fastest
+ * on the largest brick (one workgroup per CU); with several chunks in flight on separate streams bricks of <= 108 voxels (46 KB of
+ * LDS, 3 workgroups per CU) let the streams' kernels share the CUs (+3-4 % throughput, profiles/README.md).  The cap is an ARGUMENT
+ * (r5; a process-wide setter before): the caller that knows its regime asks for the brick and passes it to sis3d_conv3d_k3t16. */
 /* profiling hook (tools/t16_trace.py): every later k3t16 launch writes {start, end (100 MHz wall clock ticks), HW_ID} of each of its
  * first capacity_blocks workgroups into buf (3 x int64 per workgroup, device memory); NULL switches it off */
 int sis3d_conv3d_k3t16_set_trace(void *buf, int capacity_blocks);
 size_t sis3d_conv_k3t16_packed_floats(int cout, int cin);
 int sis3d_conv_k3t16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
-int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob);
+int sis3d_conv3d_k3t16_brick(int X, int Y, int Z, int cin, int cout, int nprob, int max_voxels);
 int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
                        const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
                        int out_stride, int out_coff, int brick, sis3d_stream_t stream);
@@ -373,14 +374,18 @@ int sis3d_conv3d_k3t16(int nprob, const float *const *ins, int X, int Y, int Z, 
  * association (same error class: ~2-3e-6 against float64 on the rpn_net layer for both).  1..4 same-shape problems per launch,
  * channels-last activations, any grid size (partial 2x2x2 output blocks are masked), cin % 8 == 0, output may be a channel
  * slice (out_stride, out_coff).  Weights: sis3d_conv_k3wino_pack_weight transforms (Cout,Cin,3,3,3) once (fp32) into
- * U[cout tile][cin / 4][xi / 4][lane 64][4] (sis3d_conv_k3wino_packed_floats floats).  flags: 0 or SIS3D_EPI_RELU. */
+ * U[cout tile][cin / 4][xi / 4][lane 64][4] (sis3d_conv_k3wino_packed_floats floats).  flags: SIS3D_EPI_RELU |
+ * SIS3D_DISPATCH_SHARED_CHIP. */
 /* 1 when the Winograd kernel is expected to beat sis3d_conv3d_k3t16 on this layer (enough (block, cout pair) work items to fill
  * the chip; measured table in csrc/conv3d_wino.hip), else 0: the host-side dispatch rule */
-int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob);
-/* process-wide hint (r4), like sis3d_conv3d_k3t16_set_brick_cap: on != 0 says that launches made from now on share the chip with
- * other streams' kernels (several chunks in flight), so layers that would take ONE cout tile per workgroup to fill the chip alone
- * (geometry2[0]) take two -- fewer, longer work items, less CU-time.  Results are identical either way. */
-int sis3d_conv3d_k3wino_set_shared_chip(int on);
+/* shared_chip != 0 (and SIS3D_DISPATCH_SHARED_CHIP in sis3d_conv3d_k3wino's flags): the launch shares the chip with other streams'
+ * kernels (several chunks in flight), so what counts is CU-time, not the launch's own duration: layers that would take ONE cout tile
+ * per workgroup to fill the chip alone (geometry2[0]) take two -- fewer, longer work items -- and layers with >= 48 work items
+ * (the 64 -> 64 convs) take this kernel at all.  A per-call argument (r5; a process-wide setter before): the two regimes can be
+ * launched / captured concurrently from different threads.  For one layer the two cout-tile counts give bit-identical results;
+ * a layer that changes KERNEL between the regimes (direct <-> Winograd) differs by summation order (~2e-5 relative). */
+#define SIS3D_DISPATCH_SHARED_CHIP 0x100
+int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout, int nprob, int shared_chip);
 size_t sis3d_conv_k3wino_packed_floats(int cout, int cin);
 int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
 int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
@@ -464,9 +469,10 @@ int sis3d_bottleneck16(const float *y1, int X, int Y, int Z, int planes, const f
  * in the kernel's epilogue:  y2 = relu(conv2(y1) + b2);  out = relu(conv3(y2) + b3 + x);  y1n = relu(conv1_next(out) + b1n) (c2 > 0).
  * Replaces the cuDNN calls behind Bottleneck.forward (lib/nets/backbones.py:27-40) for planes = 32 (the workgroup's two cout tiles
  * are all of conv2's channels).  w2_wino: sis3d_conv_k3wino_pack_weight(32, 32); w3_pw16 / w1n_pw16: sis3d_conv_pw16_pack_weight.
- * (planes, cio, c2) instantiated: (32,32,{0,32}) (32,64,0); others -> SIS3D_EUNSUPPORTED.  sis3d_bottleneck_wino_prefer: 1 where this
- * launch is expected to beat sis3d_bottleneck16 (>= 200 blocks of 8 x 4 x 8 voxels: the 48 x 24 x 48 maps). */
-int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int cio, int c2);
+ * (planes, cio, c2) instantiated: (32,32,{0,32}) (32,64,0) (32,128,0); others -> SIS3D_EUNSUPPORTED.  sis3d_bottleneck_wino_prefer: 1 where this
+ * launch is expected to beat sis3d_bottleneck16 (>= 200 blocks of 8 x 4 x 8 voxels: the 48 x 24 x 48 maps; with shared_chip != 0,
+ * see sis3d_conv3d_k3wino_prefer, >= 24 blocks: the Bottleneck(128, 32) bodies of the 24 x 12 x 24 maps as 27 fat work items). */
+int sis3d_bottleneck_wino_prefer(int X, int Y, int Z, int planes, int cio, int c2, int shared_chip);
 int sis3d_bottleneck_wino(const float *y1, int X, int Y, int Z, int planes, const float *w2_wino, const float *b2, const float *w3_pw16,
                           const float *b3, int cio, const float *residual, int res_stride, float *out, int out_stride, int out_coff,
                           const float *w1n_pw16, const float *b1n, int c2, float *y1n, sis3d_stream_t stream);

@@ -48,21 +48,33 @@ def _resolve_root():
     if os.path.isdir("/root/reference/lib/nets"):
         return "/root/reference", "in place"
     if os.path.isfile(_REF_TGZ):
+        # unpacked into a FRESH private directory (mkdtemp: not a predictable path another user could have pre-populated), members
+        # restricted to plain files / directories below it (tarfile's "data" filter), every file checked against the committed
+        # manifest tests/golden/reference_tree.sha256 before anything is imported from it; removed again at exit
+        import atexit
         import hashlib
+        import shutil
         import tarfile
         import tempfile
-        with open(_REF_TGZ, "rb") as f:
-            tag = hashlib.sha256(f.read()).hexdigest()[:16]
-        root = os.path.join(tempfile.gettempdir(), "sis3d_reference_" + tag)
-        if not os.path.isdir(os.path.join(root, "lib", "nets")):
-            tmp = root + ".%d.part" % os.getpid()
-            with tarfile.open(_REF_TGZ) as t:
-                t.extractall(tmp)
+        root = tempfile.mkdtemp(prefix="sis3d_reference_")
+        atexit.register(shutil.rmtree, root, True)
+        with tarfile.open(_REF_TGZ) as t:
             try:
-                os.rename(tmp, root)
-            except OSError:                                    # another process won the race
-                import shutil
-                shutil.rmtree(tmp, ignore_errors=True)
+                t.extractall(root, filter="data")
+            except TypeError:                                  # Python without extraction filters: refuse anything but plain members
+                for m in t.getmembers():
+                    if not (m.isfile() or m.isdir()) or m.name.startswith(("/", "..")) or "/../" in m.name:
+                        raise RuntimeError("reference archive holds an unsafe member: %s" % m.name)
+                t.extractall(root)
+        manifest = os.path.join(os.path.dirname(_HERE), "tests", "golden", "reference_tree.sha256")
+        if os.path.isfile(manifest):
+            with open(manifest) as f:
+                for ln in f:
+                    want, rel = ln.split(None, 1)
+                    rel = rel.strip()
+                    with open(os.path.join(root, rel), "rb") as fh:
+                        if hashlib.sha256(fh.read()).hexdigest() != want:
+                            raise RuntimeError("staged reference tree: %s does not match tests/golden/reference_tree.sha256" % rel)
         return root, "staged archive"
     return "/root/reference", "absent"
 

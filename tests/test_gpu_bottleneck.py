@@ -113,7 +113,7 @@ def test_winograd_body_network_shapes(ops, planes, cio, c2, dims):
     the bound test_gpu_conv_wino.py holds the kernel to) and vs the direct-convolution body; and it IS what bottleneck16 dispatches
     to on these grids."""
     x, y1, pc2, pc3, stage, want, wantn = _case(ops, planes, cio, c2, dims, 11 + planes + cio + c2)
-    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, planes, cio, c2) == 1
+    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, planes, cio, c2, 0) == 1
     out, y1n = ops.bottleneck_wino(cl(y1), pc2, pc3, cl(x), stage=stage)
     assert ops.is_cl(out) and out.shape == want.shape
     assert (out.cpu() - want).abs().max().item() <= TOL
@@ -153,18 +153,18 @@ def test_winograd_body_partial_blocks_and_channel_range(ops, dims, cio, c2):
 
 def test_winograd_body_refuses_other_planes(ops):
     x, y1, pc2, pc3, stage, want, _ = _case(ops, 64, 128, 0, (24, 12, 24), 5)
-    assert ops.lib().sis3d_bottleneck_wino_prefer(24, 12, 24, 64, 128, 0) == 0
+    assert ops.lib().sis3d_bottleneck_wino_prefer(24, 12, 24, 64, 128, 0, 0) == 0
     with pytest.raises(ops.Sis3dUnsupported):
         ops.bottleneck_wino(cl(y1), pc2, pc3, cl(x))
-    assert ops.lib().sis3d_bottleneck_wino_prefer(24, 12, 24, 32, 128, 32) == 0     # 27 blocks: the direct body serves the 24 x 12 x 24 maps
+    assert ops.lib().sis3d_bottleneck_wino_prefer(24, 12, 24, 32, 128, 32, 0) == 0     # 27 blocks: the direct body serves the 24 x 12 x 24 maps
 
 
-# ---- r4: dispatch on a SHARED chip (several chunks in flight: sis3d_conv3d_k3wino_set_shared_chip) -- fewer, fatter Winograd work items
+# ---- r4: dispatch on a SHARED chip (several chunks in flight) -- fewer, fatter Winograd work items.  r5: the regime is the calling
+# thread's (ops.dispatch_regime) and reaches the library as per-call arguments; nothing process-wide is set or reset
 @pytest.fixture
 def shared_chip(ops):
-    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1)
-    yield
-    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
+    with ops.dispatch_regime(shared_chip=True):
+        yield
 
 
 @pytest.mark.parametrize("c2", [32, 0])
@@ -173,8 +173,8 @@ def test_winograd_body_128_channels_on_a_shared_chip(ops, c2, shared_chip):
     only where the hint is set; same bounds as the planes-32 bodies of the 48 x 24 x 48 maps"""
     dims = (24, 12, 24)
     x, y1, pc2, pc3, stage, want, wantn = _case(ops, 32, 128, c2, dims, 77 + c2)
-    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, 32, 128, 0) == 1
-    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, 32, 128, 32) == 0    # no instantiation holds both 128-channel weight sets of the tail
+    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, 32, 128, 0, 1) == 1
+    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, 32, 128, 32, 1) == 0    # no instantiation holds both 128-channel weight sets of the tail
     out, none = ops.bottleneck_wino(cl(y1), pc2, pc3, cl(x))
     assert none is None and (out.cpu() - want).abs().max().item() <= TOL
     if c2:
@@ -188,9 +188,9 @@ def test_winograd_body_128_channels_on_a_shared_chip(ops, c2, shared_chip):
         assert (via16n.cpu() - wantn).abs().max().item() <= TOL
     else:
         assert via16n is None
-    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
-    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, 32, 128, 0) == 0
-    direct, _ = ops.bottleneck16(cl(y1), pc2, pc3, cl(x), stage=stage)       # hint off: the direct-convolution body, same result within fp32 order
+    assert ops.lib().sis3d_bottleneck_wino_prefer(*dims, 32, 128, 0, 0) == 0
+    with ops.dispatch_regime(shared_chip=False):
+        direct, _ = ops.bottleneck16(cl(y1), pc2, pc3, cl(x), stage=stage)   # hint off: the direct-convolution body, same result within fp32 order
     assert (direct - out).abs().max().item() <= 2e-5 * float(want.abs().max())
 
 
@@ -209,8 +209,8 @@ def test_shared_chip_sends_the_64_channel_convs_to_winograd(ops, shared_chip):
     """conv2 of geometry2's Bottleneck(128, 64) blocks (64 -> 64 on 24 x 12 x 24: 54 Winograd work items) and geometry2[0] with two cout
     tiles per workgroup: taken only on a shared chip; results equal the direct kernel's within the fp32-order bound"""
     lib = ops.lib()
-    assert lib.sis3d_conv3d_k3wino_prefer(24, 12, 24, 64, 64, 1) == 1
-    assert lib.sis3d_conv3d_k3wino_prefer(12, 6, 12, 64, 64, 1) == 0           # 8 work items: not even there
+    assert lib.sis3d_conv3d_k3wino_prefer(24, 12, 24, 64, 64, 1, 1) == 1
+    assert lib.sis3d_conv3d_k3wino_prefer(12, 6, 12, 64, 64, 1, 1) == 0         # 8 work items: not even there
     g = torch.Generator().manual_seed(9)
     x = cl(torch.relu(torch.randn(1, 64, 24, 12, 24, generator=g)))
     w, b = _w(64, 64, 3, g), torch.randn(64, generator=g) * 0.1
@@ -218,11 +218,11 @@ def test_shared_chip_sends_the_64_channel_convs_to_winograd(ops, shared_chip):
     ops.flop_tally(True)
     y = ops.conv3d_k3t16([x], [pc], relu=True)[0]
     assert ops.flop_tally(False)["wino_launches"] == 1
-    lib.sis3d_conv3d_k3wino_set_shared_chip(0)
-    assert lib.sis3d_conv3d_k3wino_prefer(24, 12, 24, 64, 64, 1) == 0
-    ops.flop_tally(True)
-    d = ops.conv3d_k3t16([x], [pc], relu=True)[0]
-    assert ops.flop_tally(False)["wino_launches"] == 0
+    assert lib.sis3d_conv3d_k3wino_prefer(24, 12, 24, 64, 64, 1, 0) == 0
+    with ops.dispatch_regime(shared_chip=False):
+        ops.flop_tally(True)
+        d = ops.conv3d_k3t16([x], [pc], relu=True)[0]
+        assert ops.flop_tally(False)["wino_launches"] == 0
     want = F.relu(F.conv3d(x.cpu().double(), w.double(), b.double(), padding=1))
     scale = float(want.abs().max())
     assert (y.cpu().double() - want).abs().max().item() <= 2e-5 * scale

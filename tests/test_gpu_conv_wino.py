@@ -78,8 +78,8 @@ def test_winograd_batched_slice_and_no_relu():
 def test_winograd_is_the_default_route_and_can_be_switched_off():
     from sis3d import ops
     x, w, b = _case(128, 256, (24, 12, 24), 5)              # rpn_net: a layer sis3d_conv3d_k3wino_prefer takes
-    assert ops.lib().sis3d_conv3d_k3wino_prefer(24, 12, 24, 128, 256, 1) == 1
-    assert ops.lib().sis3d_conv3d_k3wino_prefer(24, 12, 24, 64, 64, 1) == 0       # too few work items: stays on the direct kernel
+    assert ops.lib().sis3d_conv3d_k3wino_prefer(24, 12, 24, 128, 256, 1, 0) == 1
+    assert ops.lib().sis3d_conv3d_k3wino_prefer(24, 12, 24, 64, 64, 1, 0) == 0       # too few work items: stays on the direct kernel
     pc = ops.PackedConv(w.cuda(), b.cuda())
     xc = ops.to_cl(x.cuda())
     assert ops.WINOGRAD

@@ -165,7 +165,7 @@ def test_full_forward_masks(oracle, golden):
 
 @pytest.mark.parametrize("name,use_images", [("e2e_geometry_full", False), ("e2e_images_small", True)])
 def test_forward_under_the_shared_chip_dispatch(oracle, golden, name, use_images):
-    """r4: the dispatch that pipelines of several chunks in flight capture (sis3d_conv3d_k3wino_set_shared_chip: geometry2[0] with two cout
+    """r4: the dispatch that pipelines of several chunks in flight capture (ops.dispatch_regime(shared_chip=True): geometry2[0] with two cout
     tiles per Winograd workgroup, the 64 -> 64 convs and the Bottleneck(128,32) bodies on the Winograd kernel) -- i.e. the kernels that set the
     bench headline -- against the oracle and the reference's own fixture at the same tolerances and the same 0-near-tie rule as the default
     dispatch, and against the default dispatch itself (levels within 2e-5 of their scale)"""
@@ -184,13 +184,10 @@ def test_forward_under_the_shared_chip_dispatch(oracle, golden, name, use_images
     ops.flop_tally(True)
     net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
     base = ops.flop_tally(False)["wino_launches"]
-    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1)
-    try:
+    with ops.dispatch_regime(shared_chip=True):
         ops.flop_tally(True)
         p = net.forward(blobs_for(data, feats, i3d, i2d), "TEST", [])
         shared = ops.flop_tally(False)["wino_launches"]
-    finally:
-        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
     if dims == (96, 48, 96):
         assert shared > base, (shared, base)                   # more layers really took the Winograd kernel
     o = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2)).forward(data, feats, i3d, i2d)
