@@ -202,7 +202,38 @@ __global__ void tsdf_encode_kernel(const float *__restrict__ sdf, int X, int Y, 
     }
 }
 
+// grid-stride 16-byte copy; src may be pinned host memory mapped into the device's address space (the loads cross PCIe).
+// FEW workgroups, MANY loads in flight per lane: a resident wave of ANY kernel keeps a Winograd workgroup (512 registers per lane = a
+// SIMD's whole file, 148 KB of LDS) off its CU for as long as it lives, and a wave that waits on the link lives long -- the first
+// version (64 workgroups, 4 loads in flight) cost four chunk pipelines 13-17 % of their throughput although the link was idle half of
+// the time; 8 workgroups x 256 lanes x 8 x 16 B = 256 KB in flight cover the link's latency-bandwidth product several times over and
+// occupy 8 of the 256 CUs.
+typedef float upl4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void upload_kernel(const upl4 *__restrict__ src, upl4 *__restrict__ dst, int64_t n4)
+{
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        upl4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+    }
+    for (; i < n4; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 } // namespace
+
+extern "C" int sis3d_upload_f32(const float *src, float *dst, int64_t n, int workgroups, sis3d_stream_t stream)
+{
+    if (!src || !dst || n <= 0 || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || workgroups < 0) return SIS3D_EINVAL;
+    static const int env_wg = [] { const char *e = getenv("SIS3D_UPLOAD_WGS"); return e ? atoi(e) : 0; }();      // tuning hook
+    const int wg = workgroups > 0 ? workgroups : (env_wg > 0 ? env_wg : 8);
+    hipLaunchKernelGGL(upload_kernel, dim3(wg), dim3(256), 0, as_stream(stream), (const upl4 *)src, (upl4 *)dst, n / 4);
+    return sis3d_check_launch();
+}
 
 extern "C" int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout, float truncated, int mode, float *out,
                                  int64_t os_c, int64_t os_x, int64_t os_y, int64_t os_z, sis3d_stream_t stream)

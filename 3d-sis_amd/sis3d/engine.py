@@ -14,6 +14,45 @@ from .synthetic import CHUNK_DIMS
 RECORD_WIDTH = ops.RECORD_WIDTH     # proposal box (6), rpn score, level, class id, class prob, class-regressed final box (6)
 
 
+# ---- r5: one small set of HIP streams per device, by ROLE.  `torch.cuda.Stream()` hands out streams from a pool of 32 per device
+# round-robin and WRAPS AROUND: a process that has asked for more than 32 (a bench that builds one engine set per configuration, a
+# server that rebuilds its runners) gets the SAME underlying stream for two of its chunk pipelines, which then serialise silently
+# (measured: the four-chunk share of a scene 1.5 -> 3.0 ms, profiles/r05_stream_pool.txt).  Every engine set of a device therefore
+# uses the same streams: pipeline i always runs on ("pipe", i), captures warm up on ("capture", 0), and so on.  Engine sets of one
+# device do not run concurrently with each other (they share the chip), so sharing their streams costs nothing, and the mapping of
+# streams onto the GPU_MAX_HW_QUEUES hardware queues stays the one the first engine set got.
+_STREAM_POOL = {}
+
+
+def candidate_streams(count=16, device=None):
+    """up to `count` DISTINCT streams for the chunk pipelines to choose from (("pipe", 0 .. count-1) of the pool); stops early when
+    torch's round-robin pool wraps around onto a stream this pool already holds"""
+    dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    have = {st.cuda_stream for (d, _, _), st in _STREAM_POOL.items() if d == dev}
+    out = []
+    for j in range(int(count)):
+        key = (dev, "pipe", j)
+        st = _STREAM_POOL.get(key)
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            if st.cuda_stream in have:
+                break                                    # wrapped around: no more distinct streams to be had
+            _STREAM_POOL[key] = st
+            have.add(st.cuda_stream)
+        out.append(st)
+    return out
+
+
+def pooled_stream(role, index=0, device=None):
+    dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    key = (dev, role, int(index))
+    st = _STREAM_POOL.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _STREAM_POOL[key] = st
+    return st
+
+
 class ChunkEngine:
     def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1,
                  mask_boxes=0, shared_chip=False, brick_cap=0):
@@ -131,7 +170,7 @@ class ChunkEngine:
             torch.cuda.synchronize()
             if self.rgb and self.use_graph:
                 try:
-                    side = torch.cuda.Stream()
+                    side = pooled_stream("capture", 0, self.device)
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         self._encode_views()
@@ -149,7 +188,7 @@ class ChunkEngine:
                 self.out = self._step()
                 torch.cuda.synchronize()
             if self.use_graph:
-                side = torch.cuda.Stream()
+                side = pooled_stream("capture", 0, self.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     self.out = self._step()          # one more eager pass on the capture stream
@@ -299,7 +338,8 @@ class PipelinedEngines:
         cap = (108 if n >= 2 else 0) if brick_cap is None else int(brick_cap)
         self._brick_cap = cap
         check_hw_queues(n)
-        self.streams = [torch.cuda.Stream() for _ in range(n)]
+        self.streams = [pooled_stream("pipe", i) for i in range(n)]
+        self.stream_window, self.stream_window_times = 0, {}
         self.engines = []
         for s in self.streams:
             s.wait_stream(torch.cuda.current_stream())
@@ -315,10 +355,12 @@ class PipelinedEngines:
         torch.cuda.synchronize()
         return self
 
-    def load(self, i, *a, **kw):
-        """copy a chunk (CPU or GPU tensors) into pipeline i's static buffers, on pipeline i's stream"""
+    def load(self, i, *a, wait=True, **kw):
+        """copy a chunk (CPU or GPU tensors) into pipeline i's static buffers, on pipeline i's stream.  wait=False: the caller has
+        already ordered the pipeline's stream behind the producer of the inputs (SceneRunner does it once per scene)"""
         s = self.streams[i]
-        s.wait_stream(torch.cuda.current_stream())         # GPU inputs may still be in flight on the caller's stream
+        if wait:
+            s.wait_stream(torch.cuda.current_stream())     # GPU inputs may still be in flight on the caller's stream
         with torch.cuda.stream(s):
             self.engines[i].load(*a, **kw)
         for t in a:
@@ -331,39 +373,66 @@ class PipelinedEngines:
     # reads (a 3.5 MB device copy, or sis3d_tsdf_encode when the host hands over the raw 1.77 MB SDF block of a .chunk file:
     # lib/datasets/dataset.py:54-70), releases the staging buffer and replays the graph.  Fed one chunk ahead, the upload of chunk
     # k + 1 runs under the compute of chunk k; nothing on the host waits.
-    def enable_feed(self, mode="grid", truncated=3.0):
+    def enable_feed(self, mode="grid", truncated=3.0, copy="kernel"):
         """mode 'grid': hosts hand over the encoded (1,2,X,Y,Z) float32 grid, as the reference's dataloader does; 'sdf': the raw
-        float32 SDF block in file order (x fastest), encoded on the device.  Host tensors must be pinned."""
+        float32 SDF block in file order (x fastest), encoded on the device.  Host tensors must be pinned.
+        copy: how / where the upload is enqueued --
+          'kernel'        (default) by a KERNEL on the pipeline's own stream that reads the pinned host memory across PCIe
+                          (sis3d_upload_f32: 8 workgroups, 256 KB in flight -- grids go straight into the graph's static input, an SDF
+                          block into a staging buffer sis3d_tsdf_encode reads).  An ordinary launch: it can be enqueued one chunk
+                          ahead, right behind the previous replay, without ever blocking the host;
+          'own'           on the pipeline's own stream, straight into the buffer the device copy / encode reads: no second stream, no
+                          event handshake; the upload of chunk k + 1 sits behind the replay of chunk k in stream order, i.e. a
+                          pipeline pauses for its own upload (71 us for 3.54 MB at the measured 50 GB/s) while the other pipelines
+                          keep the chip busy;
+          'per_pipeline'  on a copy stream of the pipeline's own, double-buffered: the upload of chunk k + 1 runs under chunk k;
+          'shared'        one copy stream for all pipelines (measured: the handshakes of four pipelines on one stream serialise
+                          them -- 0.77 -> 1.13 ms per step before a single byte is copied; kept for the A/B).
+        Measured (profiles/r05_stream_probe.txt, four backbone + RPN pipelines, ms per step): resident 0.770, own 0.831,
+        per_pipeline 0.829, shared 1.38."""
         if mode not in ("grid", "sdf"):
             raise ValueError("feed mode must be 'grid' or 'sdf'")
+        if copy not in ("kernel", "own", "per_pipeline", "shared"):
+            raise ValueError("copy must be 'kernel', 'own', 'per_pipeline' or 'shared'")
         if any(e.group != 1 or e.use_images for e in self.engines):
             raise ops._lib.Sis3dError("streamed inputs: geometry-only engines of one chunk per graph")
-        self._feed_mode, self._feed_trunc = mode, float(truncated)
-        self.copy_stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        self._feed_mode, self._feed_trunc, self._feed_copy = mode, float(truncated), copy
         self._feed = []
-        for e in self.engines:
+        for i, e in enumerate(self.engines):
             X, Y, Z = e.dims
             shape = (1, 2, X, Y, Z) if mode == "grid" else (X * Y * Z,)
-            self._feed.append({"stage": [torch.empty(shape, device=e.device) for _ in range(2)],
-                               "ready": [torch.cuda.Event() for _ in range(2)], "free": [torch.cuda.Event() for _ in range(2)],
-                               "tag": [None, None], "used": [False, False], "fed": 0, "run": 0})
+            # grids are uploaded straight into the graph's static input (no staging at all); an SDF block goes to a staging buffer the
+            # encode kernel reads (an encode that reads the host block itself puts a link-bound wave on every CU: measured slower)
+            direct = mode == "grid" and copy in ("kernel", "own")
+            nbuf = 1 if copy in ("own", "kernel") else 2
+            cs = self.streams[i] if copy in ("own", "kernel") else pooled_stream("copy", i if copy == "per_pipeline" else 0)
+            self._feed.append({"stage": [e.scenes[0]] if direct else [torch.empty(shape, device=e.device) for _ in range(nbuf)],
+                               "direct": direct, "nbuf": nbuf, "stream": cs,
+                               "ready": [torch.cuda.Event() for _ in range(nbuf)], "free": [torch.cuda.Event() for _ in range(nbuf)],
+                               "tag": [None] * nbuf, "used": [False] * nbuf, "fed": 0, "run": 0})
         return self
 
     def feed(self, i, host):
-        """enqueue the upload of one chunk for pipeline i (at most two outstanding per pipeline) -> False if both staging buffers
-        hold chunks that have not been run yet (nothing is enqueued then)"""
+        """enqueue the upload of one chunk for pipeline i -> False if the pipeline's staging buffers all hold chunks that have not
+        been consumed yet (nothing is enqueued then)"""
         f = self._feed[i]
-        if f["fed"] - f["run"] >= 2:
+        if f["fed"] - f["run"] >= f["nbuf"]:
             return False
         if host.is_cuda or not host.is_pinned():
             raise ops._lib.Sis3dError("feed: the chunk must sit in pinned host memory (an upload from pageable memory blocks the host)")
-        s = f["fed"] & 1
-        cs = self.copy_stream
-        if f["used"][s]:
+        s = f["fed"] % f["nbuf"]
+        cs = f["stream"]
+        own = self._feed_copy in ("own", "kernel")
+        if not own and f["used"][s]:
             cs.wait_event(f["free"][s])                   # the chunk this buffer held has been moved into the static buffer
-        with torch.cuda.stream(cs):
-            f["stage"][s].copy_(host.view(f["stage"][s].shape), non_blocking=True)
-            f["ready"][s].record(cs)
+        with torch.cuda.stream(cs), torch.no_grad():
+            if self._feed_copy == "kernel":
+                ops.upload(host, f["stage"][s])
+            else:
+                f["stage"][s].copy_(host.view(f["stage"][s].shape), non_blocking=True)
+            if not own:
+                f["ready"][s].record(cs)
         f["tag"][s], f["used"][s] = host.data_ptr(), True
         f["fed"] += 1
         return True
@@ -371,7 +440,7 @@ class PipelinedEngines:
     def is_fed(self, i, host):
         """is an upload of THIS host tensor outstanding on pipeline i (fed, not yet consumed)?"""
         f = self._feed[i]
-        return any(f["tag"][k & 1] == host.data_ptr() for k in range(f["run"], f["fed"]))
+        return any(f["tag"][k % f["nbuf"]] == host.data_ptr() for k in range(f["run"], f["fed"]))
 
     def pending(self, i):
         """chunks fed to pipeline i and not yet consumed"""
@@ -384,15 +453,23 @@ class PipelinedEngines:
         f = self._feed[i]
         if f["fed"] == f["run"]:
             raise ops._lib.Sis3dError("streamed inputs: nothing was fed to pipeline %d" % i)
-        s = f["run"] & 1
+        s = f["run"] % f["nbuf"]
         e = self.engines[i]
+        own = self._feed_copy in ("own", "kernel")
         with torch.cuda.stream(stream), torch.no_grad():
-            stream.wait_event(f["ready"][s])
-            if self._feed_mode == "grid":
+            if own:
+                if stream is not f["stream"]:
+                    stream.wait_stream(f["stream"])       # (the one-launch round consumes on its capture stream)
+            else:
+                stream.wait_event(f["ready"][s])
+            if f["direct"]:
+                pass                                      # the upload went straight into the static input
+            elif self._feed_mode == "grid":
                 e.scenes[0].copy_(f["stage"][s], non_blocking=True)
             else:
                 ops.tsdf_encode(f["stage"][s], e.dims, self._feed_trunc, "abs", None, out=e.scenes[0])
-            f["free"][s].record(stream)
+            if not own:
+                f["free"][s].record(stream)
         f["run"] += 1
 
     def run_fed(self, i, host=None):
@@ -422,7 +499,7 @@ class PipelinedEngines:
         ordered behind all of them without a host-side join.  -> (graph, capture stream)"""
         if any(eng.group != 1 for eng in self.engines):
             raise ops._lib.Sis3dError("capture_round: engines of one chunk per graph only (group == 1)")
-        main = torch.cuda.Stream()
+        main = pooled_stream("round", 0)
         main.wait_stream(torch.cuda.current_stream())
         with torch.no_grad():
             g = torch.cuda.CUDAGraph()
@@ -448,6 +525,41 @@ class PipelinedEngines:
                     main.wait_stream(s)
         torch.cuda.synchronize()
         return g, main
+
+    def calibrate(self, run_once, reps=3, warm=1, count=16, windows=None):
+        """Choose the HIP streams the pipelines run on BY MEASUREMENT (r5).  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues
+        when they are created and does not say how; which queues four pipelines land on -- relative to each other, to the stream
+        that issues the serial part of the work, and to the hardware pipes behind the queues -- moves a 32-chunk scene between 7.5 and
+        12.5 ms and four backbone + RPN pipelines between 0.77 and 1.19 ms per step on the same graphs (profiles/r05_queue_map.txt:
+        every window of four consecutive pool streams, same process).  The captured graphs replay on any stream, so: for every window
+        of len(engines) consecutive candidate streams run `run_once()` (one pass of the caller's real workload over these pipelines,
+        enqueued, not synchronised) warm + reps times, time the reps, keep the fastest window.  One-time cost: windows x (warm + reps)
+        passes.  -> (best window index, {window index: ms per pass})"""
+        import time
+        n = len(self.engines)
+        cands = candidate_streams(count, self.engines[0].device)
+        if len(cands) < n + 1:
+            return 0, {}
+        wins = list(range(0, len(cands) - n + 1)) if windows is None else [w for w in windows if w + n <= len(cands)]
+        times = {}
+        for w in wins:
+            self.streams = cands[w:w + n]
+            for _ in range(warm):
+                run_once()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run_once()
+            torch.cuda.synchronize()
+            times[w] = (time.perf_counter() - t0) / reps * 1e3
+        best = min(times, key=times.get)
+        self.streams = cands[best:best + n]
+        self.stream_window = best
+        self.stream_window_times = times
+        if hasattr(self, "_feed") and getattr(self, "_feed_copy", None) in ("own", "kernel"):
+            for i, f in enumerate(self._feed):
+                f["stream"] = self.streams[i]
+        return best, times
 
     def join(self):
         """make the current stream wait for every pipeline"""

@@ -339,11 +339,32 @@ def compute_projection(depths, view_params, volume_dims, image_dims, intrinsic, 
 TSDF_MODES = {"abs": 0, "flip": 1, "log": 2}
 
 
+def _pinned(t, name):
+    """a float32 tensor in PINNED host memory (device-mapped: kernels may read it through its host pointer)"""
+    if not isinstance(t, torch.Tensor) or t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_pinned():
+        raise _lib.Sis3dError("%s must be a contiguous float32 tensor in pinned host memory" % name)
+    return t
+
+
+def upload(host, out, workgroups=0):
+    """pinned host tensor -> `out` (cuda, same numel) by a kernel that reads the host memory across PCIe (sis3d_upload_f32): an
+    ordinary launch on the current stream -- it never blocks the enqueueing thread, unlike a hipMemcpyAsync behind a pending graph"""
+    _pinned(host, "host")
+    _dev(out, "out")
+    if not out.is_contiguous() or out.numel() != host.numel():
+        raise _lib.Sis3dError("upload: `out` must be contiguous with %d elements" % host.numel())
+    check(lib().sis3d_upload_f32(_ptr(host), _ptr(out), host.numel(), int(workgroups), _stream()), "sis3d_upload_f32")
+    return out
+
+
 def tsdf_encode(sdf, dims, truncated=3.0, mode="abs", max_height=None, channels_last=True, out=None):
     """raw sdf grid in file order (flat, x fastest; numel X*Y*Z, cuda) -> network input, logical (1,2,X,Yout,Z)
     (dataset.py:54-70 + the max-height crop :196-211).  out: a contiguous planar (1,2,X,Yout,Z) buffer to write into (the static
     input buffer of a chunk pipeline: engine.PipelinedEngines.run_fed)."""
-    sdf = _dev(sdf, "sdf").contiguous()
+    if isinstance(sdf, torch.Tensor) and not sdf.is_cuda and out is not None:
+        sdf = _pinned(sdf, "sdf")                    # r5: the kernel reads the pinned host block itself (upload + encode in one pass)
+    else:
+        sdf = _dev(sdf, "sdf").contiguous()
     X, Y, Z = (int(v) for v in dims)
     if sdf.numel() != X * Y * Z:
         raise _lib.Sis3dError("tsdf_encode: sdf has %d elements, dims say %d" % (sdf.numel(), X * Y * Z))

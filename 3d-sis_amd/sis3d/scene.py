@@ -7,14 +7,15 @@ import torch
 import torch.distributed as dist
 
 from . import ops, parallel
-from .engine import PipelinedEngines
+from .engine import PipelinedEngines, pooled_stream
 
 
 import os as _os
 # capture_round's staggered start (pipeline e waits for pipeline e - 1's level 1): measured and lost on the 4-chunk share
 # (1.357 vs 1.331 ms in the same box run, tools/r04_scene_share.sh) -- off by default, kept as an A/B switch
 ROUND_STAGGER = _os.environ.get("SIS3D_ROUND_STAGGER", "0") != "0"
-# lazy results: the whole-scene merge on its own stream (A/B switch; on by default since r5)
+# lazy results: join + gather + whole-scene merge on their own stream, scenes overlap (A/B switch; on by default since r5)
+WAIT_PER_CHUNK = _os.environ.get("SIS3D_WAIT_PER_CHUNK", "0") != "0"      # A/B switch (r4 behaviour: a cross-stream wait per chunk)
 MERGE_STREAM = _os.environ.get("SIS3D_MERGE_STREAM", "1") != "0"
 
 
@@ -76,6 +77,9 @@ class SceneRunner:
         self._round = None          # (graph, stream, send buffer): one launch for a share of exactly len(engines) chunks
         self._round_ok, self._round_error = True, None
         self._merge_stream = None
+        self._sends, self._consumed, self._scene_no, self._send_slot = [None, None], [None, None, None], 0, 0
+        self._use_round = True          # calibrate() may find per-chunk launches on well-placed streams faster than the round graph
+        self.calibration = None
 
     def mask_fn(self, payload, windows, classes, values=False):
         """mask head of one chunk's surviving detections: one ragged launch per layer for all its boxes, then the predicted
@@ -105,23 +109,45 @@ class SceneRunner:
         live = dist.is_initialized() and not self.solo
         return (dist.get_rank(group), dist.get_world_size(group)) if live else (0, 1)
 
-    def run_chunks(self, chunks, group=None):
+    def run_chunks(self, chunks, group=None, post=None):
         """this rank's chunks through the captured per-chunk graphs, `inflight` at a time -> (n_local, block_floats) tensor of
         record blocks in ascending chunk order (rows are written by async device copies on the pipelines' streams; the
-        current stream waits for all of them before returning)"""
+        current stream waits for all of them before returning).
+        post (r5, the pipelined path of infer(lazy=True)): a stream that takes the place of the current stream as the one ordered
+        behind the pipelines -- the caller gathers and merges there -- so the CURRENT stream never waits for a scene's chunks and the
+        next scene's chunks start on each pipeline as soon as that pipeline is free, not when the slowest pipeline of this scene has
+        finished.  The record rows then go to one of two alternating send buffers (the previous scene's may still be being read)."""
         rank, world = self._rank_world(group)
         mine = parallel.shard_chunks(len(chunks), rank, world)
         bf = parallel.block_floats(self.k_rows)
         dev = self.pipes.engines[0].device
         streamed = self._streamed(chunks, mine)
-        if self.use_graph and len(mine) == len(self.pipes.engines) and all(not isinstance(chunks[c][2], (tuple, list)) for c in mine) \
-                and self.prepare_round():
-            return self._run_round(chunks, mine, bf, dev, streamed)
-        if self._send is None or self._send.shape[0] != len(mine):
-            self._send = torch.zeros(max(1, len(mine)), bf, device=dev)
-        send = self._send
+        if self.use_graph and self._use_round and len(mine) == len(self.pipes.engines) \
+                and all(not isinstance(chunks[c][2], (tuple, list)) for c in mine) and self.prepare_round():
+            return self._run_round(chunks, mine, bf, dev, streamed, post)
+        if post is not None:
+            b = self._scene_no & 1
+            self._scene_no += 1
+            if self._sends[b] is None or self._sends[b].shape[0] != max(1, len(mine)):
+                self._sends[b] = torch.zeros(max(1, len(mine)), bf, device=dev)
+                self._consumed[b] = None
+            send = self._sends[b]
+            self._send_slot = b
+        else:
+            if self._send is None or self._send.shape[0] != len(mine):
+                self._send = torch.zeros(max(1, len(mine)), bf, device=dev)
+            send = self._send
         n = len(self.pipes.engines)
         with torch.no_grad():
+            if post is not None and self._consumed[self._send_slot] is not None:
+                for st in self.pipes.streams:                 # the scene before last has been gathered out of this send buffer
+                    st.wait_event(self._consumed[self._send_slot])
+            if not WAIT_PER_CHUNK:
+                # the pipelines' streams are ordered behind the caller's stream ONCE per scene (the chunks of a scene are all there when
+                # infer() is called), not once per chunk: 4 cross-queue barriers per scene instead of 32
+                cur = torch.cuda.current_stream()
+                for st in self.pipes.streams:
+                    st.wait_stream(cur)
             for j, c in enumerate(mine):
                 cid, origin, payload = chunks[c]
                 e = j % n
@@ -131,17 +157,25 @@ class SceneRunner:
                     if not self.pipes.is_fed(e, payload):
                         self.pipes.feed(e, payload)
                     self.pipes.consume(e, self.pipes.streams[e])
-                    if j + n < len(mine):
-                        self.pipes.feed(e, chunks[mine[j + n]][2])
                 elif isinstance(payload, (tuple, list)):
-                    self.pipes.load(e, *payload)
+                    self.pipes.load(e, *payload, wait=WAIT_PER_CHUNK)
                 else:
-                    self.pipes.load(e, payload)
+                    self.pipes.load(e, payload, wait=WAIT_PER_CHUNK)
                 with torch.cuda.stream(self.pipes.streams[e]):
                     eng.origins[0].copy_(self._origin(origin), non_blocking=True)
                     out = eng.run()
                     send[j].copy_(out["block"], non_blocking=True)     # out of the graph's static buffer before its next replay
-            self.pipes.join()
+                if streamed and j + n < len(mine) and self.pipes._feed_copy != "own":
+                    # look-ahead BEHIND the replay (the upload may go straight into the graph's static input): this pipeline's next
+                    # chunk is on its way while the host moves on.  Not with hipMemcpyAsync ('own'): enqueued right behind a graph
+                    # launch it blocks the HOST until the graph has drained (0.12 -> 0.9 ms of host time per step), so there chunk
+                    # j + n is fed when its turn comes
+                    self.pipes.feed(e, chunks[mine[j + n]][2])
+            if post is not None:
+                for st in self.pipes.streams:
+                    post.wait_stream(st)
+            else:
+                self.pipes.join()
         return send[:len(mine)]
 
     def _streamed(self, chunks, mine):
@@ -151,7 +185,7 @@ class SceneRunner:
             return False
         ok = all(torch.is_tensor(chunks[c][2]) and not chunks[c][2].is_cuda and chunks[c][2].is_pinned() for c in mine)
         if ok and not hasattr(self.pipes, "_feed"):
-            self.pipes.enable_feed("grid")
+            self.pipes.enable_feed("grid", copy=_os.environ.get("SIS3D_FEED_COPY", "kernel"))
         return ok
 
     def prefetch(self, chunks, group=None):
@@ -160,13 +194,50 @@ class SceneRunner:
         for the staging buffers, not for the pipelines)"""
         rank, world = self._rank_world(group)
         mine = parallel.shard_chunks(len(chunks), rank, world)
-        if not self._streamed(chunks, mine):
-            return 0
+        if not self._streamed(chunks, mine) or self.pipes._feed_copy == "own":
+            return 0                                    # ('own': see run_chunks -- an upload behind a fresh graph launch blocks the host)
         n, fed = len(self.pipes.engines), 0
         for j, c in enumerate(mine[:n]):
             if self.pipes.pending(j % n) == 0 and self.pipes.feed(j % n, chunks[c][2]):
                 fed += 1
         return fed
+
+    def calibrate(self, chunks, group=None, reps=2, count=16, gathered=None):
+        """choose the pipelines' streams -- and, for a share of exactly one chunk per pipeline, between the one-launch round graph
+        and per-chunk launches -- by timing infer() on `chunks` (PipelinedEngines.calibrate; one-time cost: ~13 x 3 scenes).
+        -> dict describing the choice"""
+        import time
+        use_round_saved = self._use_round
+        self._use_round = False
+
+        def once():
+            self.infer(chunks, group=group, gathered=gathered)
+        best, times = self.pipes.calibrate(once, reps=reps, warm=1, count=count)
+        out = {"stream_window": best, "ms_per_scene_by_window": {str(k): round(v, 3) for k, v in times.items()}}
+        self._use_round = use_round_saved
+        rank, world = self._rank_world(group)
+        if self.use_graph and len(parallel.shard_chunks(len(chunks), rank, world)) == len(self.pipes.engines) and self.prepare_round():
+            res = {}
+            for flag in (False, True):
+                self._use_round = flag
+                for _ in range(2):
+                    self.infer(chunks, group=group, lazy=True, gathered=gathered).resolve()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                prev = None
+                for _ in range(6):
+                    cur = self.infer(chunks, group=group, lazy=True, gathered=gathered)
+                    if prev is not None:
+                        prev.resolve()
+                    prev = cur
+                prev.resolve()
+                torch.cuda.synchronize()
+                res[flag] = (time.perf_counter() - t0) / 6 * 1e3
+            self._use_round = res[True] <= res[False]
+            out.update({"ms_per_scene_round_graph": round(res[True], 3), "ms_per_scene_per_chunk_launches": round(res[False], 3),
+                        "one_launch_round": self._use_round})
+        self.calibration = out
+        return out
 
     def prepare_round(self):
         """capture the one-launch round graph now (outside any timed or pipelined call): a share of exactly one chunk per pipeline
@@ -184,13 +255,17 @@ class SceneRunner:
                 self._round_error = "%s: %s" % (type(e).__name__, e)
         return self._round is not None
 
-    def _run_round(self, chunks, mine, bf, dev, streamed=False):
+    def _run_round(self, chunks, mine, bf, dev, streamed=False, post=None):
         """the share is exactly one chunk per pipeline: inputs copied into the static buffers on ONE stream, then ONE graph launch
         (PipelinedEngines.capture_round) runs all of them and leaves their record blocks in the send buffer; the caller's stream
         is ordered behind the graph, no host-side join"""
         g, main, send = self._round
         cur = torch.cuda.current_stream()
         main.wait_stream(cur)
+        if post is not None:
+            self._send_slot = 2
+            if self._consumed[2] is not None:
+                main.wait_event(self._consumed[2])         # the previous scene's rows have been gathered out of the graph's send buffer
         if streamed:
             for e, c in enumerate(mine):
                 if not self.pipes.is_fed(e, chunks[c][2]):
@@ -207,8 +282,41 @@ class SceneRunner:
                         payload.record_stream(main)
                 eng.origins[0].copy_(self._origin(origin), non_blocking=True)
             g.replay()
-        cur.wait_stream(main)
+            if streamed:
+                # uploads enqueued on a pipeline's own stream (feed copy 'kernel' / 'own') write the static inputs this graph reads
+                for st in self.pipes.streams:
+                    st.wait_stream(main)
+        (post if post is not None else cur).wait_stream(main)
         return send
+
+    def _infer_pipelined(self, chunks, thresh, group, max_keep, gathered):
+        """infer(lazy=True) on tables the fused merge serves: everything behind the per-chunk detection -- join, gather (the scene's
+        ONE collective), whole-scene merge -- is enqueued on the merge stream, ordered behind the pipelines only.  The current stream
+        carries nothing of a scene, so scene k + 1's chunks do not wait for scene k's slowest pipeline, gather or merge: consecutive
+        scenes overlap on the chip."""
+        if self._merge_stream is None:
+            self._merge_stream = pooled_stream("merge", 0)
+        ms = self._merge_stream
+        n_chunks = len(chunks)
+        with torch.no_grad():
+            ms.wait_stream(torch.cuda.current_stream())        # `gathered` / process-group state produced on the caller's stream
+            local = self.run_chunks(chunks, group, post=ms)
+            with torch.cuda.stream(ms):
+                if gathered is not None:
+                    rank, world = self._rank_world(group)
+                    rows = parallel._chunk_ids(tuple(parallel.shard_chunks(n_chunks, rank, world)), local.device)
+                    blocks = gathered.index_copy(0, rows, local)
+                else:
+                    blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group, solo=self.solo)
+                    if blocks.data_ptr() == local.data_ptr():
+                        blocks = blocks.clone()                   # a world of one: the table must not alias the send buffer
+                ev = torch.cuda.Event()
+                ev.record(ms)
+                self._consumed[self._send_slot] = ev
+                recs, order, keep, counts = ops.scene_merge_raw(blocks, self.k_rows, thresh, 6, 0, max_keep)
+                done = torch.cuda.Event()
+                done.record(ms)
+        return SceneResult(recs, order, keep, counts, self.k_rows, False, done=done)
 
     def infer(self, chunks, thresh=None, group=None, max_keep=0, with_masks=False, mask_values=False, gathered=None, lazy=False):
         """chunks: [(chunk_id, origin, data or (data, feats, i3d, i2d) or None)] for the whole scene (entries of other
@@ -220,6 +328,10 @@ class SceneRunner:
         the table, already resolved otherwise (with_masks, > 8192 rows, CPU tables) -- whose resolve() gives the eager tuple."""
         thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
         n_chunks = len(chunks)
+        pipelined = (lazy and MERGE_STREAM and not with_masks and n_chunks * self.k_rows <= 8192
+                     and self.pipes.engines[0].device.type == "cuda")
+        if pipelined:
+            return self._infer_pipelined(chunks, thresh, group, max_keep, gathered)
         with torch.no_grad():
             local = self.run_chunks(chunks, group)
             if gathered is not None:
@@ -229,23 +341,6 @@ class SceneRunner:
             else:
                 blocks = parallel.gather_blocks(local, n_chunks, self.k_rows, group, solo=self.solo)
             if lazy and not with_masks and blocks.is_cuda and blocks.shape[0] * self.k_rows <= 8192:
-                if MERGE_STREAM:
-                    # r5: the merge of scene k runs on its own stream, ordered behind the gathered table only, so the stream that
-                    # launches scene k + 1's detection graphs does not queue behind ~85 us of one-to-64-workgroup merge kernels
-                    if self._merge_stream is None:
-                        self._merge_stream = torch.cuda.Stream()
-                    ms = self._merge_stream
-                    ms.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(ms):
-                        recs, order, keep, counts = ops.scene_merge_raw(blocks, self.k_rows, thresh, 6, 0, max_keep)
-                        done = torch.cuda.Event()
-                        done.record(ms)
-                    blocks.record_stream(ms)
-                    if blocks.data_ptr() == local.data_ptr():
-                        # a world of one: the table IS this rank's send buffer, which the next scene's graphs overwrite --
-                        # they must wait for the merge (no overlap to be had; with a gathered / received table there is)
-                        torch.cuda.current_stream().wait_event(done)
-                    return SceneResult(recs, order, keep, counts, self.k_rows, False, done=done)
                 recs, order, keep, counts = ops.scene_merge_raw(blocks, self.k_rows, thresh, 6, 0, max_keep)
                 return SceneResult(recs, order, keep, counts, self.k_rows, False)
             if not with_masks:

@@ -104,6 +104,8 @@ def parse(argv=None):
                     "dominant kernel at the end of an N = 1 run; `roofline.traffic` then is the committed figure of profiles/")
     ap.add_argument("--split-line", action="store_true", help="also time the opt-in split-bf16 variant of the k3 convs (separately "
                     "reported, never the headline; off by default since r5: it does not beat the exact-fp32 path in throughput)")
+    ap.add_argument("--no-calibrate", action="store_true", help="keep the pipelines on the first streams of the pool instead of choosing "
+                    "the window of streams by measurement (PipelinedEngines.calibrate / SceneRunner.calibrate)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the streamed-input variants (fresh chunks from pinned host memory)")
     ap.add_argument("--no-side-configs", action="store_true", help="N = 1 default run: skip the detect / detect_masks / images / "
                     "images_rgb sub-objects (BASELINE configs[2], [3])")
@@ -683,7 +685,7 @@ def time_streamed(eng, args, rank, nfl, barrier, mode):
     from sis3d import synthetic
     RING = 4
     torch.cuda.synchronize()
-    eng.enable_feed(mode)
+    eng.enable_feed(mode, copy=os.environ.get("SIS3D_FEED_COPY", "kernel"))
     ring = []
     for i in range(nfl):
         row = []
@@ -692,13 +694,20 @@ def time_streamed(eng, args, rank, nfl, barrier, mode):
             t = synthetic.synth_chunk(cid) if mode == "grid" else synthetic.synth_sdf(cid)
             row.append(t.contiguous().pin_memory())
         ring.append(row)
-    for i in range(nfl):
-        eng.feed(i, ring[i][0])
+    own = eng._feed_copy == "own"          # hipMemcpyAsync on the pipeline's stream: must not be enqueued behind a fresh graph launch
+    if not own:
+        for i in range(nfl):
+            eng.feed(i, ring[i][0])
 
     def step(k):
         for i in range(nfl):
-            eng.run_fed(i)
-            eng.feed(i, ring[i][(k + 1) % RING])
+            if own:
+                # upload, then replay, on the pipeline's own stream: the upload is enqueued when the PREVIOUS replay of this pipeline is
+                # a whole step old (an upload enqueued right behind a fresh graph launch blocks the host until the graph drains)
+                eng.run_fed(i, ring[i][k % RING])
+            else:
+                eng.run_fed(i)
+                eng.feed(i, ring[i][(k + 1) % RING])
     k = 0
     for _ in range(max(args.warmup, 4)):
         step(k)
@@ -708,13 +717,16 @@ def time_streamed(eng, args, rank, nfl, barrier, mode):
     for _ in range(args.steps):
         step(k)
         k += 1
+    t_host = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     # drain: one chunk per pipeline is still staged
     for i in range(nfl):
-        eng.run_fed(i)
+        if eng.pending(i):
+            eng.run_fed(i)
     torch.cuda.synchronize()
-    return dict(dt=dt, bytes_per_chunk=ring[0][0].numel() * 4, ring=RING)
+    return dict(dt=dt, bytes_per_chunk=ring[0][0].numel() * 4, ring=RING, host_ms_per_step=t_host / args.steps * 1e3,
+                copy=eng._feed_copy)
 
 
 def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
@@ -723,12 +735,15 @@ def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
     return {"value": vox_per_step * steps / st["dt"], "unit": "voxels/s", "ms_per_step": ms,
             "ratio_to_resident": resident_dt / st["dt"], "host_bytes_per_chunk": st["bytes_per_chunk"],
             "h2d_gbs_per_gpu": chunks_per_s / world * st["bytes_per_chunk"] / 1e9,
+            "host_enqueue_ms_per_step": st.get("host_ms_per_step"), "upload_by": st.get("copy"),
             "input": ("encoded (1,2,96,48,96) float32 grid = the reference's blobs['data'] (lib/nets/network.py:191)" if mode == "grid"
                       else "raw float32 SDF block in .chunk file order, TSDF-encoded on the device (sis3d_tsdf_encode; dataset.py:54-70)"),
-            "how": "every step each of the %d pipelines runs a chunk it was fed from PINNED HOST memory one chunk ahead: H2D on a copy "
-                   "stream into one of two staging buffers, device copy / encode into the graph's static input, graph replay "
-                   "(PipelinedEngines.feed / run_fed); ring of %d distinct host chunks per pipeline; the timed region contains every "
-                   "upload" % (nfl, st["ring"])}
+            "how": "every step each of the %d pipelines runs a FRESH chunk from pinned host memory: the upload is a KERNEL on the "
+                   "pipeline's own stream that reads the host memory across PCIe (sis3d_upload_f32 into the graph's static input; sdf: "
+                   "sis3d_tsdf_encode reads the host block itself), enqueued one chunk ahead right behind the previous replay "
+                   "(PipelinedEngines.feed / run_fed, copy='kernel': no copy stream, no event handshake, no staging buffer -- the other "
+                   "pipelines keep the CUs busy while one waits on the link); ring of %d distinct host chunks per pipeline; the timed "
+                   "region contains every upload" % (nfl, st["ring"])}
 
 
 def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):
@@ -763,6 +778,9 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
             else:
                 eng.load(i, data, slot=g)
     eng.prepare(warmup=2)
+    if not args.no_calibrate and nfl >= 2 and not args.no_graph:
+        preheat(eng.run, min(args.preheat_ms, 60.0))
+        eng.calibrate(eng.run, reps=8, warm=2)
     preheat(eng.run, args.preheat_ms)
     for _ in range(args.warmup):
         eng.run()
@@ -773,6 +791,9 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
     barrier()
     dt = time.perf_counter() - t0
     extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl}
+    if eng.stream_window_times:
+        extra["stream_window"] = eng.stream_window
+        extra["stream_window_ms_per_step"] = {str(k): round(v, 4) for k, v in eng.stream_window_times.items()}
     streamed = {}
     if workload in ("backbone_rpn", "detect") and not masks and grp == 1 and not args.no_graph and not args.no_streamed:
         for mode in ("grid", "sdf"):
@@ -853,7 +874,8 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
             # ragged launches, HIP events around 50 replays -> mask_head_ms / mask_head_tf (algorithmic FLOPs / time)
             e0 = eng.engines[0]
             with torch.no_grad():
-                side = torch.cuda.Stream()
+                from sis3d.engine import pooled_stream
+                side = pooled_stream("capture", 0)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     net.mask_backbone.forward_planned(e0.scenes[0], e0.mask_plan)
@@ -932,6 +954,9 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     lazy = not args.masks and n_local == nfl and not args.no_graph
     if lazy:
         runner.prepare_round()              # the one-launch round graph is captured here, not inside the first timed / pipelined call
+    if not args.no_calibrate and not args.no_graph and not args.masks and runner.calibration is None and not streamed:
+        runner.infer(chunks, gathered=gathered)
+        runner.calibrate(chunks, gathered=gathered)
 
     def one():
         r = runner.infer(chunks, with_masks=args.masks, gathered=gathered, lazy=lazy)
@@ -958,7 +983,9 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     recs, keep = res[0], res[1]
     extra = {"scene_chunks": n_chunks, "scene_stride": args.scene_stride, "chunks_on_this_rank": n_local, "streams_per_gpu": nfl,
              "records_gathered": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel()),
-             "one_graph_launch_per_scene": runner._round is not None}
+             "one_graph_launch_per_scene": runner._round is not None and runner._use_round}
+    if runner.calibration:
+        extra["calibration"] = runner.calibration
     if args.masks:
         extra["masks_on_this_rank"] = len(res[2])
         extra["mask_voxels_on_this_rank"] = int(sum(m.numel() for _, m in res[2].values()))

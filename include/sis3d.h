@@ -169,6 +169,18 @@ int sis3d_compute_projection(const float *depth, const float *view_params, int V
 int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout, float truncated, int mode, float *out,
                       int64_t os_c, int64_t os_x, int64_t os_y, int64_t os_z, sis3d_stream_t stream);
 
+/* ---- upload of a chunk by a KERNEL that reads host memory (r5) ---------------------------------------------------------------
+ * Replaces the `blobs['data'].cuda()` at the head of the reference's forward (lib/nets/network.py:191) for chunk pipelines.
+ * src: n floats in PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory: the pointer is valid on the device);
+ * dst: n floats of device memory; both 16-byte aligned, n % 4 == 0.  A grid-stride 16-byte copy on `stream`: the launch is an
+ * ordinary kernel launch, so -- unlike hipMemcpyAsync, which was measured to BLOCK THE HOST when it is enqueued behind a captured
+ * graph that has not drained -- it never stalls the enqueueing thread, needs no copy stream and no events, and the reads cross PCIe
+ * at the link rate while the other pipelines' kernels keep the CUs busy.  sis3d_tsdf_encode accepts such a host pointer as `sdf`
+ * too (upload and TSDF encoding in one pass over the 1.77 MB block, but with one short-lived wave per 32 x 32 tile on every CU: chunk pipelines upload with this
+ * function and encode from the device copy).  workgroups: 0 = default (8: few workgroups with 8 x 16 B in flight per lane -- a
+ * wave waiting on the link must not sit on many CUs, see csrc/pool_misc.hip). */
+int sis3d_upload_f32(const float *src_host_mapped, float *dst, int64_t n, int workgroups, sis3d_stream_t stream);
+
 /* ------------------------------------------------------- proposal decoding --
  * Replaces proposal_layer.py:96-103 + bbox_transform_inv / clip_boxes
  * (lib/utils/bbox_transform.py:59-99,4-21) for one level:
