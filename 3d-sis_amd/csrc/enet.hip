@@ -398,6 +398,8 @@ template <int C, int MID, int MIDN, bool ASYM>
 int launch_block_k(const EnetBlockArgs &a, hipStream_t st)
 {
     static const int waves = [] { const char *e = getenv("SIS3D_ENET_WAVES"); return e && atoi(e) == 1 ? 1 : 4; }();      // A/B switch
+    // 32-bit byte offsets in the inline-asm row loads (ybase + tap offsets): refuse maps whose conv1 rows do not fit
+    if ((int64_t)a.npix * MID * 4 + (int64_t)16 * 4 * MID * (a.W + 1) * (a.kind == 0 ? a.dil : 2) >= 0x7fffffffLL) return SIS3D_EUNSUPPORTED;
     if (waves == 1) {
         hipLaunchKernelGGL((enet_block_kernel<C, MID, MIDN, 1, ASYM>), dim3((unsigned)cdiv(a.npix, 16)), dim3(64), 0, st, a);
         return sis3d_check_launch();

@@ -357,10 +357,13 @@ extern "C" int sis3d_topk_desc(const float *scores, int n, int k, float *out_sco
     if (n > EPT * TPB) return SIS3D_EUNSUPPORTED;        // caller falls back to a full sort
     if (n == 0 || k == 0) return SIS3D_OK;
     if (!scores || !out_scores || !out_idx) return SIS3D_EINVAL;
-#ifndef TOPK_TIMING
+#ifdef TOPK_TIMING
+    (void)stream;
+    return SIS3D_EUNSUPPORTED;      // a timing build's kernel takes the timestamp buffer: this entry must not report success without a launch
+#else
     hipLaunchKernelGGL(topk_desc_kernel, dim3(1), dim3(TPB), 0, as_stream(stream), scores, n, k, out_scores, out_idx);
-#endif
     return sis3d_check_launch();
+#endif
 }
 
 #ifdef TOPK_TIMING

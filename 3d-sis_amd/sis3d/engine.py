@@ -202,8 +202,9 @@ class ChunkEngine:
 
     def _encode_views(self):
         """RGB views -> ENet feature maps, written into the static feature buffers the 3D graph reads"""
-        for g in range(self.group):
-            self.feats_[g].copy_(self.net.image_features(self.images_[g]))
+        with ops.dispatch_regime(self.shared_chip, self.brick_cap):
+            for g in range(self.group):
+                self.feats_[g].copy_(self.net.image_features(self.images_[g]))
 
     def load_rgb(self, data, images, i3d, i2d, slot=0):
         """rgb engines: grid, RGB views (V,3,H,W), packed index lists"""

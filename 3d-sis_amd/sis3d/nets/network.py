@@ -279,6 +279,11 @@ class Network(nn.Module):
             out["cls_score"], out["cls_pred"], out["cls_prob"], out["bbox_pred"] = self._classify_rois(l1, l2)
         return out
 
+    def _apply(self, fn, *args, **kwargs):
+        # every re-placement of the module (cuda / to / cpu / float ...) invalidates forward()'s cached device check
+        self._placement_version = getattr(self, "_placement_version", 0) + 1
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, blobs, mode="TRAIN", killing_inds=None):
         if mode != "TEST":
             raise NotImplementedError("forward-only build: mode must be 'TEST' (training is out of scope, SURVEY.md 2)")
@@ -292,8 +297,13 @@ class Network(nn.Module):
         self.batch_size = 1
         self._mode = "TEST"
         dev = torch.device("cuda", torch.cuda.current_device())
-        if any(q.device != dev for q in self.parameters()):
-            self.cuda()                                    # network.py:75: the reference's forward moves the module itself
+        # network.py:75: the reference's forward moves the module itself.  Walking every parameter costs tens of microseconds per call,
+        # so the walk is repeated only after something re-placed the module (`_apply`: .cuda() / .to() / .cpu() bump the counter)
+        placed = (getattr(self, "_placement_version", 0), dev)
+        if getattr(self, "_placement_checked", None) != placed:
+            if any(q.device != dev for q in self.parameters()):
+                self.cuda()
+            self._placement_checked = (getattr(self, "_placement_version", 0), dev)
         with torch.no_grad():
             self.eval()
             scene = blobs["data"].to(dev, non_blocking=True).float()

@@ -1014,7 +1014,8 @@ def set_sparse_projection(on):
     SPARSE_PROJECTION = bool(on)
 
 
-_SPARSE_WS = {}
+_SPARSE_WS = {}                 # (grid, device, stream handle) -> (weakref to the torch stream object, workspace)
+_SPARSE_WS_MAX = 16             # bounded: engines use a handful of (grid, stream) pairs; the oldest entry goes first
 
 
 def _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main):
@@ -1039,11 +1040,16 @@ def _conv3d_chain_projected_sparse(x, pc, stages, relu, want_main):
     # the graph's pool, because graphs captured on one stream may replay concurrently on several
     capturing = torch.cuda.is_current_stream_capturing()
     key = (X, Y, Z, x.device, int(torch.cuda.current_stream().cuda_stream))
-    ws = None if capturing else _SPARSE_WS.get(key)
+    ws = None if capturing else _SPARSE_WS.pop(key, None)
     if ws is None:
         ws = torch.empty(lib().sis3d_conv3d_k2s2_projected_sparse_workspace_bytes(X, Y, Z), dtype=torch.uint8, device=x.device)
-        if not capturing:
-            _SPARSE_WS[key] = ws
+    if not capturing:
+        # most recently used last; bounded.  A recycled stream handle inheriting an old workspace is harmless: launches on one
+        # stream are ordered, and the buffer belongs to the caching allocator's pool of the stream it was allocated on (the
+        # pipelines' streams of sis3d.engine live as long as the process: engine.pooled_stream)
+        _SPARSE_WS[key] = ws
+        while len(_SPARSE_WS) > _SPARSE_WS_MAX:
+            _SPARSE_WS.pop(next(iter(_SPARSE_WS)))
     wsb = ws.numel()
     rc = lib().sis3d_conv3d_k2s2_projected_sparse(_ptr(x.table), _ptr(x.rows), x.nslots, x.npix, X, Y, Z, pc.cin, _ptr(pc.packed_pw16),
                                                   _ptr(pc.bias), pc.cout, 1 if relu else 0, _ptr(main), _ptr(spc.packed_pw16) if spc else None,

@@ -23,6 +23,42 @@ import os as _os
 FORCE_COLLECTIVE = bool(_os.environ.get("SIS3D_FORCE_COLLECTIVE"))
 
 
+def rank_cpu_block(avail, local_rank, local_world):
+    """the logical CPUs rank `local_rank` of `local_world` ranks on one host should run on: a contiguous block of the host's first
+    hardware threads (Linux numbers the second SMT thread of core c as c + ncores) plus their SMT siblings.  Contiguous blocks follow
+    the sockets (ranks 0..W/2-1 on socket 0, the rest on socket 1 of a two-socket node: the usual GPU <-> NUMA layout of an 8-GPU box),
+    and eight launcher processes -- each enqueueing ~100 us of work per chunk -- do not migrate across each other's cores."""
+    avail = sorted(int(c) for c in avail)
+    n = len(avail)
+    if local_world <= 1 or n < 2 * local_world:
+        return avail
+    half = n // 2
+    smt = n % 2 == 0 and half >= 2 * local_world               # treat the upper half as SMT siblings only when there is room to spare
+    first = avail[:half] if smt else avail
+    k = len(first) // local_world
+    block = first[local_rank * k:(local_rank + 1) * k]
+    if smt:
+        block = block + [avail[half + first.index(c)] for c in block]
+    return block
+
+
+def pin_rank_to_cpus(local_rank, local_world):
+    """apply rank_cpu_block to this process (os.sched_setaffinity) and cap its CPU-side thread pools to the block: the timed path
+    is GPU-only, the host threads of N ranks must not oversubscribe each other.  SIS3D_NO_AFFINITY=1 leaves the process alone.
+    -> the CPUs the process now runs on (or None if nothing was changed)"""
+    if _os.environ.get("SIS3D_NO_AFFINITY") or not hasattr(_os, "sched_setaffinity") or local_world <= 1:
+        return None
+    try:
+        block = rank_cpu_block(_os.sched_getaffinity(0), local_rank, local_world)
+        if not block:
+            return None
+        _os.sched_setaffinity(0, block)
+        torch.set_num_threads(max(1, min(16, len(block))))
+        return block
+    except OSError:
+        return None
+
+
 def shard_chunks(n_chunks, rank, world):
     """chunk ids owned by `rank`: c mod W == rank, ascending"""
     return list(range(rank, n_chunks, world))

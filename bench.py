@@ -1131,10 +1131,14 @@ def main(argv=None):
                                                                                        if torch.cuda.is_available() else 0))
         return 2
     use_dist = world > 1 or bool(os.environ.get("SIS3D_FORCE_DIST"))     # FORCE: exercise the RCCL path on one GPU
+    cpus = None
     if world > 1:
         # N ranks share one host: keep each rank's torch-CPU helpers (synthetic inputs, weight init) from spawning a thread
-        # per core each; the timed path is GPU-only
+        # per core each, and every rank on its own block of cores (the launcher thread of a rank enqueues ~100 us of work per
+        # chunk: eight of them must not migrate across each other); the timed path is GPU-only
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
+        from sis3d import parallel as _par
+        cpus = _par.pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.cuda.set_device(local)
     if use_dist:
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -1361,6 +1365,7 @@ def main(argv=None):
                            else ""),
                        "chunk": [96, 48, 96], "hip_graph": not args.no_graph, "parallelism": "chunk-dp%d" % world,
                        "hw_queues": hw_queues(),
+                       **({"rank0_cpus": "%d logical CPUs (block of this rank: sis3d.parallel.pin_rank_to_cpus)" % len(cpus)} if cpus else {}),
                        **({"TEST_HOOK": "all ranks share GPU 0, gloo instead of RCCL: functional run, not a measurement"} if share else {}),
                        "chunks_per_step_per_gpu": nchunk_step, "single_chunk_latency_ms": res["single_ms"], **res["extra"]},
             "roofline": roofline_entry(kt, kt_direct, ops.WINOGRAD),

@@ -6,7 +6,11 @@ logits, so the stable sort may order such a pair differently and NMS then keeps 
 Contract of the committed seeds (round 3): every end-to-end test passes `max_near=0` (the default), i.e. a near-tie FAILS the
 test; the row-for-row comparisons that follow are therefore unconditional.  Should a box ever produce a near-tie on some host,
 the remedy is a different seed for that case, stated in the test -- not a silent skip.  Every `[parity]` line is also appended
-to the file named by $SIS3D_PARITY_LOG (profiles/r03_parity_log.txt is one such run on the MI355X box)."""
+to the file named by $SIS3D_PARITY_LOG (profiles/r03_parity_log.txt is one such run on the MI355X box).
+
+How often near-ties occur on seeds that were NOT chosen is measured, not assumed: tools/parity_sweep.py runs 32 fresh seeds (weights
+and inputs) through configs 1/2, 3 and 4 with `compare_proposals` below -- the same comparison without the assertions -- and writes
+the counts of exact matches, near-ties and hard mismatches to profiles/r05_parity_sweep.txt (round 5)."""
 import os
 
 import torch
@@ -48,6 +52,25 @@ def nearest_score_gap(score, all_scores_sorted):
     k = int(d.argmin())                                     # the candidate itself (or its fp32 twin on the other side)
     d[k] = float("inf")
     return float(d.min()) if d.numel() > 1 else float("inf")
+
+
+def compare_proposals(got_rois, got_scores, want_rois, want_scores, all_scores_sorted, tol=1e-3, gap=1e-5):
+    """the comparison of assert_proposals_match WITHOUT the assertions (tools/parity_sweep.py: near-tie frequency over many seeds,
+    reported instead of selected away -- SURVEY.md 8c(3)) -> dict(oracle, device, matched, near, hard, max_score_err): `near` =
+    unmatched boxes whose RPN score has another candidate's score within `gap`; `hard` = unmatched boxes WITHOUT such a rival, i.e.
+    real disagreements"""
+    got_rois, want_rois = got_rois.float().cpu(), want_rois.float().cpu()
+    gs, ws = got_scores.float().cpu().view(-1), want_scores.float().cpu().view(-1)
+    pairs, un_w, un_g = match_sets(got_rois, want_rois, tol)
+    err = max([abs(float(ws[i]) - float(gs[j])) for i, j in pairs] or [0.0])
+    near = hard = 0
+    for idx, sc in ((un_w, ws), (un_g, gs)):
+        for k in idx:
+            if nearest_score_gap(float(sc[k]), all_scores_sorted.float().cpu().clone()) <= gap + 2e-6:
+                near += 1
+            else:
+                hard += 1
+    return {"oracle": len(want_rois), "device": len(got_rois), "matched": len(pairs), "near": near, "hard": hard, "max_score_err": err}
 
 
 def assert_proposals_match(got_rois, got_scores, want_rois, want_scores, all_scores_sorted, tol=1e-3, gap=1e-5, score_tol=1e-4,

@@ -110,3 +110,17 @@ def test_cpu_thread_rule_and_config_entry(monkeypatch):
     assert abs(st["ratio_to_resident"] - 0.8) < 1e-9 and abs(st["h2d_gbs_per_gpu"] - 3200 * 3.538944e6 / 1e9) < 1e-6
     t, n_runs, lo, hi = bench._median_runs(lambda: None, 0.0, min_runs=10)
     assert n_runs == 10 and lo <= t <= hi
+
+
+def test_rank_cpu_blocks_partition_the_host():
+    """r5: N launcher processes on one host each get their own block of cores + SMT siblings"""
+    from sis3d import parallel
+    avail = list(range(256))                                       # 2 sockets x 64 cores x 2 threads
+    blocks = [parallel.rank_cpu_block(avail, r, 8) for r in range(8)]
+    assert all(len(b) == 32 for b in blocks) and sorted(c for b in blocks for c in b) == avail
+    assert blocks[0][:16] == list(range(16)) and blocks[0][16:] == list(range(128, 144))     # cores 0-15 and their siblings
+    assert blocks[4][:16] == list(range(64, 80))                                             # ranks 4-7 on the second socket
+    assert parallel.rank_cpu_block(avail, 0, 1) == avail
+    assert parallel.rank_cpu_block(list(range(8)), 1, 8) == list(range(8))                   # too few CPUs to split: left alone
+    odd = parallel.rank_cpu_block(list(range(0, 48)), 2, 4)
+    assert len(odd) == 12 and len(set(odd)) == 12
