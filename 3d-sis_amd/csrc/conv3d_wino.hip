@@ -328,7 +328,7 @@ struct NextV {
 // WC (r4): waves along the cout axis.  WC = 2 puts EIGHT waves in the workgroup -- two per SIMD -- that share one raw brick and one
 // U ring: wave (wc, h, g) takes cout tile group wc (NC tiles), xi half h, tile group g.  Its 128 NC accumulator registers fit twice in
 // a SIMD's file only with NC = 1; the input transform is then computed by both waves of a SIMD (each for its own cout tile); the idea
-// was that while one of them issues VMEM / waits at the barrier, the other keeps the matrix pipe fed.  MEASURED (tools/r04_wc.sh,
+// was that while one of them issues VMEM / waits at the barrier, the other keeps the matrix pipe fed.  MEASURED (profiles/r04_wino_two_waves_per_simd.txt,
 // -DWN_WC2_EXPERIMENT, rpn_net 128 -> 256): bit-identical output, 56.5 us against 52.3 -- the per-step costs beside the MFMAs (LDS-DMA
 // and VALU issue) are costs of the SIMD, not of the wave, so a second wave hides none of them and the duplicated transform adds
 // its 8 %.  Kept as a template parameter (the default WC = 1 is the shipped kernel); not instantiated in the library.
@@ -853,7 +853,7 @@ static int wino_nc(int X, int Y, int Z, int cin, int cout, bool shared_chip)
     if (shared_chip && blocks * ((nt + 1) / 2) >= shared_min) return 2;
     if (blocks * nt >= 200 && cin >= 128) {
         // one cout tile per workgroup fills the chip when the launch has it alone (geometry2[0]: 216 work items, 34 us; on a shared
-        // chip the rule above has already given it two: 108 work items x ~50 us, tools/r04_exp1.sh: 1.958 -> 1.992 G voxels/s with
+        // chip the rule above has already given it two: 108 work items x ~50 us, profiles/r04_shared_chip_rule.txt: 1.958 -> 1.992 G voxels/s with
         // three chunks in flight, one chunk alone 0.295 -> 0.308 ms)
         return 1;
     }

@@ -12,7 +12,7 @@ from .engine import PipelinedEngines, pooled_stream
 
 import os as _os
 # capture_round's staggered start (pipeline e waits for pipeline e - 1's level 1): measured and lost on the 4-chunk share
-# (1.357 vs 1.331 ms in the same box run, tools/r04_scene_share.sh) -- off by default, kept as an A/B switch
+# (1.357 vs 1.331 ms in the same box run, profiles/r04_scene_share_pipelines.txt) -- off by default, kept as an A/B switch
 ROUND_STAGGER = _os.environ.get("SIS3D_ROUND_STAGGER", "0") != "0"
 # lazy results: join + gather + whole-scene merge on their own stream, scenes overlap (A/B switch; on by default since r5)
 WAIT_PER_CHUNK = _os.environ.get("SIS3D_WAIT_PER_CHUNK", "0") != "0"      # A/B switch (r4 behaviour: a cross-stream wait per chunk)

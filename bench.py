@@ -15,7 +15,7 @@ all-gather and whole-scene NMS, `records_gathered`, `kept_after_scene_nms`, `ms_
 same scene = `single_gpu` and `speedup_vs_1gpu`).  So value(N) / value(1) compares like with like, and the strong-scaling figure
 of the collective path can be read off the `scene` key of the same lines.  `--workload scene` makes the scene the headline instead.
   backbone_rpn  BASELINE config[1]: one 96x48x96 geometry-only chunk per pipeline, HIP backbone + RPN; a step = one pass
-                over `--inflight` (default 4 on the 8 hardware queues this script asks HIP for, tools/r04_hwq.sh)
+                over `--inflight` (default 4 on the 8 hardware queues this script asks HIP for, profiles/r04_hw_queues.txt)
                 independent chunks per GPU, each on its own HIP stream / captured graph, inputs resident in HBM.  Ranks share
                 nothing (scaling: weak).
   detect        config[2]: + decode / top-k / NMS / RoI pooling / classifier (+ `--masks`: mask head on a fixed
@@ -46,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
 # HIP gives a process 4 hardware queues by default and maps its streams onto them round-robin: the pipelines' streams, the capture /
 # side streams and the null stream then share queues, and a FOURTH chunk in flight serialises behind another one (round 4,
-# tools/r04_hwq.sh, same box: 4 in flight 1.80 G voxels/s on 4 queues, 2.28 G on >= 6; 3 in flight 2.16 G on either).  Read by the HIP
+# profiles/r04_hw_queues.txt, same box: 4 in flight 1.80 G voxels/s on 4 queues, 2.28 G on >= 6; 3 in flight 2.16 G on either).  Read by the HIP
 # runtime when it initialises, i.e. before torch is imported anywhere below; an integrator sets the same variable in his launcher.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -662,7 +662,7 @@ def ops_mod():
 def preheat(step, ms):
     """untimed passes of the workload itself for `ms` of wall clock, in front of the W warm-up steps: a 20-step timed region is ~20 ms,
     and measured from a cold start (clocks at idle: the first thing a fresh process does) the same code reads 1.39-1.77 instead of
-    1.95 G voxels/s (round 4, tools/r04_inflight.sh) -- whatever ran before the timed region decided the number.  Synchronises
+    1.95 G voxels/s (round 4, profiles/r04_inflight.txt) -- whatever ran before the timed region decided the number.  Synchronises
     every 16 passes so the launch queue stays shallow."""
     import torch
     if ms <= 0:
@@ -847,13 +847,15 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
         # caller with one chunk would (no shared-chip hint): the pipelines above took the dispatch for several chunks in flight --
         # fewer, fatter Winograd work items -- which is slower when a chunk has the chip alone
         torch.cuda.synchronize()
-        if nfl >= 2 and grp == 1 and not args.no_graph and not (workload == "images" and (args.rgb or from_depth)):
+        if nfl >= 2 and grp == 1 and not args.no_graph and not (workload == "images" and from_depth):
             from sis3d.engine import ChunkEngine
             solo = ChunkEngine(net, stage=stage, **kw)
             src = eng.engines[0]
             solo.scenes[0].copy_(src.scenes[0])
             if solo.use_images:
                 solo.feats_[0].copy_(src.feats_[0]); solo.i3d_[0].copy_(src.i3d_[0]); solo.i2d_[0].copy_(src.i2d_[0])
+            if getattr(solo, "rgb", False):
+                solo.images_[0].copy_(src.images_[0])          # its own 5-view encoder pass in front of its 3D graph
             solo.prepare(warmup=2)
             one = solo.run
         else:

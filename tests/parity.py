@@ -70,7 +70,13 @@ def compare_proposals(got_rois, got_scores, want_rois, want_scores, all_scores_s
                 near += 1
             else:
                 hard += 1
-    return {"oracle": len(want_rois), "device": len(got_rois), "matched": len(pairs), "near": near, "hard": hard, "max_score_err": err}
+    # same SET, different ORDER: the lists are score-ordered, so two kept proposals whose scores tie within fp32 noise may swap places
+    # without anything being kept or dropped differently.  swaps = matched pairs sitting at different positions; swap_gap = the
+    # largest oracle-score difference between the two positions such a pair occupies (a benign swap has a gap of ~1e-7)
+    swaps = [(i, j) for i, j in pairs if i != j]
+    swap_gap = max([abs(float(ws[i]) - float(ws[j])) for i, j in swaps if j < len(ws)] or [0.0])
+    return {"oracle": len(want_rois), "device": len(got_rois), "matched": len(pairs), "near": near, "hard": hard, "max_score_err": err,
+            "swaps": len(swaps), "swap_gap": swap_gap, "pairs": pairs}
 
 
 def assert_proposals_match(got_rois, got_scores, want_rois, want_scores, all_scores_sorted, tol=1e-3, gap=1e-5, score_tol=1e-4,

@@ -41,6 +41,10 @@ def main():
         x64 = ops.new_act(64, (48, 24, 48), dev).normal_()
         for _ in range(20):
             ops.maxpool3(x64)
+        host = synthetic.synth_chunk(3).contiguous().pin_memory()
+        dst = torch.empty(1, 2, *dims, device=dev)
+        for _ in range(20):
+            ops.upload(host, dst)
     torch.cuda.synchronize()
 
 

@@ -8,11 +8,12 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  for what in detect images misc rpn; do
+  for what in detect images images_rgb misc rpn; do
     rm -rf /tmp/hp_${ctr}_$what
     case $what in
-      detect) cmd="python $ROOT/bench.py --workload detect --inflight 1 --steps 30 --warmup 5 --no-cpu-baseline --no-stages --no-graph";;
+      detect) cmd="python $ROOT/bench.py --workload detect --inflight 1 --steps 30 --warmup 5 --no-cpu-baseline --no-stages --no-graph --no-live-pmc --no-side-workloads";;
       images) cmd="python $ROOT/tools/hbm_drivers.py images";;
+      images_rgb) cmd="python $ROOT/bench.py --workload images --rgb --inflight 1 --steps 12 --warmup 3 --no-cpu-baseline --no-stages --no-graph --no-live-pmc --no-side-workloads";;
       misc) cmd="python $ROOT/tools/hbm_drivers.py misc";;
       rpn) cmd="python $ROOT/tools/t16_pmc.py rpn 1";;
     esac
@@ -25,6 +26,7 @@ python "$ROOT/tools/hbm_table.py" --table "$OUT" > "$OUT/hbm_kernels.json"
 python - "$OUT/hbm_kernels.json" <<'PY'
 import json, sys
 for r in json.load(open(sys.argv[1]))["kernels"]:
-    print("%-52s %7.1f us  algo %6.2f MB  pmc %6.2f MB (rd %6.2f wr %6.2f)  %5.0f GB/s algo = %4.1f %% of 8 TB/s" % (
-        r["kernel"][:52], r["us"], r["algorithmic_mb"] or 0, r["pmc_mb"], r["fetch_mb"], r["write_mb"], r["algo_gbs"] or 0, 100 * (r["hbm_frac"] or 0)))
+    print("%-52s %7.1f us  algo %6.2f MB  pmc %6.2f MB (rd %6.2f wr %6.2f) ratio %5.2f  %5.0f GB/s algo = %4.1f %% of 8 TB/s" % (
+        r["kernel"][:52], r["us"], r["algorithmic_mb"] or 0, r["pmc_mb"], r["fetch_mb"], r["write_mb"], r.get("traffic_ratio") or 0,
+        r["algo_gbs"] or 0, 100 * (r["hbm_frac"] or 0)))
 PY

@@ -28,6 +28,18 @@ ALGO = [
     ("pw16_kernel<128, 64, 0, 4, 1>", None, "conv1 128->64 @24x12x24", 4 * V24 * (128 + 64)),
     ("pw16_kernel<64, 128, 64, 4, 1>", None, "conv3 64->128 + residual + ReLU + next conv1 @24x12x24", 4 * V24 * (64 + 128 + 128 + 64)),
     ("pw16_kernel<64, 128, 0, 4, 1>", None, "conv3 64->128 + residual + ReLU @24x12x24", 4 * V24 * (64 + 128 + 128)),
+    ("maxpool3_lds_kernel", None, "MaxPool3d(3,1,1) 128 ch @24x12x24, halo brick through LDS (r4)", 4 * V24 * 128 * 2),
+    ("conv3d_k3wino_kernel<2, 32, 32", 216, "Bottleneck(32,32) body @48x24x48 on the Winograd kernel + next conv1 (r4): y1 + residual in, out + y1n out",
+     4 * (V48 * 32 * 4 + 64 * 32 * 32 + 2 * 32 * 32)),
+    ("conv3d_k3wino_kernel<2, 32, 0", 216, "Bottleneck(32,32) body @48x24x48 on the Winograd kernel (r4): y1 + residual in, out",
+     4 * (V48 * 32 * 3 + 64 * 32 * 32 + 32 * 32)),
+    ("conv3d_k3wino_kernel<2, 128, 0", None, "Bottleneck(128,32) body @24x12x24 on the Winograd kernel (shared-chip form)",
+     4 * (V24 * (32 + 128 + 128) + 64 * 32 * 32 + 128 * 32)),
+    ("enet_block_kernel<128, 32, 32, 4", None, "ENet bottleneck, stage 2/3 (5 x 32 x 41 px): x 128 + y1 32 in, out 128 + y1n 32, weights once",
+     4 * (6560 * (128 + 32 + 128 + 32) + 9 * 32 * 32 + 128 * 32 + 32 * 128)),
+    ("enet_block_kernel<64, 16, 16, 4", None, "ENet bottleneck, stage 1 (5 x 64 x 82 px)", 4 * (26240 * (64 + 16 + 64 + 16) + 9 * 16 * 16 + 64 * 16 + 16 * 64)),
+    ("proj_tile_kernel", None, "sparse colour stem on the back-projected volume: active output voxels only", None),
+    ("upload_kernel", None, "chunk upload by a kernel reading pinned host memory (3.54 MB over PCIe in, 3.54 MB out)", 2 * 4 * 2 * 96 * 48 * 96),
     ("maxpool3_kernel<1>", 865, "MaxPool3d(3,1,1) 128 ch @24x12x24", 4 * V24 * 128 * 2),
     ("maxpool3_kernel<2>", None, "MaxPool3d(3,1,1) 64 ch @48x24x48", 4 * V48 * 64 * 2),
     ("rpn_heads_kernel", None, "both RPN heads of both levels (score, prob, bbox)", 4 * V24 * (2 * 256 + 30 + 110)),
@@ -82,6 +94,7 @@ def table(d):
         rows.append({"kernel": name, "workgroups": int(wgs), "what": label, "us": us,
                      "algorithmic_mb": None if algo is None else algo / MB, "fetch_mb": fetch / MB, "write_mb": write / MB,
                      "pmc_mb": (fetch + write) / MB, "algo_gbs": None if algo is None else algo / us / 1e3,
+                     "traffic_ratio": None if not algo else (fetch + write) / algo,
                      "pmc_gbs": (fetch + write) / us / 1e3, "hbm_frac": None if algo is None else algo / us / 1e3 / 8000.0,
                      "hbm_frac_pmc": (fetch + write) / us / 1e3 / 8000.0})
     rows.sort(key=lambda r: -r["us"])

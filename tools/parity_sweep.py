@@ -65,9 +65,13 @@ def chunk_case(seed, use_images):
             errs[k % lv] = float((p[k % lv].cpu() - o[k % lv]).abs().max())
     c = compare_proposals(p["rois"][0].cpu(), p["roi_scores"][0].cpu(), o["rois"][0], o["roi_scores"][0], o["_scores_sorted_all"])
     if c["near"] == 0 and c["hard"] == 0 and p["cls_score"].shape == o["cls_score"].shape:
-        errs["cls_score"] = float((p["cls_score"].cpu() - o["cls_score"]).abs().max())
-        errs["bbox_pred"] = float((p["bbox_pred"].cpu() - o["bbox_pred"]).abs().max())
-        c["cls_pred_equal"] = bool(torch.equal(p["cls_pred"].cpu(), o["cls_pred"]))
+        # classifier outputs of MATCHED proposals (the lists may order a score tie differently: compare_proposals' `swaps`)
+        wi = torch.tensor([i for i, _ in c["pairs"]], dtype=torch.long)
+        gj = torch.tensor([j for _, j in c["pairs"]], dtype=torch.long)
+        errs["cls_score"] = float((p["cls_score"].cpu()[gj] - o["cls_score"][wi]).abs().max())
+        errs["bbox_pred"] = float((p["bbox_pred"].cpu()[gj] - o["bbox_pred"][wi]).abs().max())
+        c["cls_pred_equal"] = bool(torch.equal(p["cls_pred"].cpu()[gj], o["cls_pred"][wi]))
+    c.pop("pairs", None)
     c["max_err"] = max(errs.values())
     c["errs"] = errs
     return c
@@ -100,6 +104,7 @@ def scene_case(seed):
     orecs, okeep = parallel.infer_scene(chunks, odetect, orc.nms, cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH)
     a = torch.cat(allsc).sort(descending=True).values
     c = compare_proposals(recs[:, :6].cpu(), recs[:, 6].cpu(), orecs[:, :6], orecs[:, 6], a)
+    c.pop("pairs", None)
     c["keep_equal"] = bool(recs.shape[0] == orecs.shape[0] and torch.equal(keep.cpu(), okeep))
     c["kept"], c["max_err"] = int(keep.numel()), c["max_score_err"]
     del runner
@@ -132,6 +137,9 @@ def main():
             n_near, seeds_near, len(rows), 100.0 * n_near / max(props, 1), hard))
         lines.append("  largest error: %.3g (tolerance %g)   largest score error of a matched proposal: %.3g" % (
             worst, TOL, max(r["max_score_err"] for r in rows)))
+        lines.append("  order: %d matched proposals in %d seeds sit at a different list position (score ties ordered differently); largest "
+                     "oracle-score gap between the swapped positions: %.3g" % (sum(r["swaps"] for r in rows), sum(1 for r in rows if r["swaps"]),
+                                                                                max(r["swap_gap"] for r in rows)))
         if "cls_pred_equal" in rows[0] or any("cls_pred_equal" in r for r in rows):
             full = [r for r in rows if "cls_pred_equal" in r]
             lines.append("  seeds compared row for row down to the classifier (no near-tie): %d, cls_pred equal in %d" % (
@@ -140,7 +148,7 @@ def main():
             lines.append("  whole-scene keep list identical to the oracle's: %d of %d seeds (the others are the near-tie seeds)" % (
                 sum(1 for r in rows if r["keep_equal"]), len(rows)))
         for i, r in enumerate(rows):
-            if r["near"] or r["hard"] or r["max_err"] > TOL:
+            if r["near"] or r["hard"] or r["max_err"] > TOL or r["swaps"]:
                 lines.append("    seed %d: %s" % (a.first + i, {k: v for k, v in r.items() if k != "errs"}))
     lines.append("")
     lines.append("wall %.0f s" % (time.time() - t0))
