@@ -359,7 +359,7 @@ def time_stages(net, wino, reps=60):
 
 
 PMC_FILES = {True: ("r02_pmc_rpn_net.json", "r01_pmc_rpn_net.json"),
-             False: ("r04_pmc_rpn_net_winograd.json", "r03_pmc_rpn_net_winograd.json")}
+             False: ("r05_pmc_rpn_net_winograd.json", "r04_pmc_rpn_net_winograd.json", "r03_pmc_rpn_net_winograd.json")}
 DOMINANT_BYTES = (6912 * 128 + 6912 * 256 + 256 * 128 * 27) * 4.0      # in + out + weights once: 14.16 MB per launch
 
 

@@ -28,6 +28,7 @@ ALGO = [
     ("pw16_kernel<128, 64, 0, 4, 1>", None, "conv1 128->64 @24x12x24", 4 * V24 * (128 + 64)),
     ("pw16_kernel<64, 128, 64, 4, 1>", None, "conv3 64->128 + residual + ReLU + next conv1 @24x12x24", 4 * V24 * (64 + 128 + 128 + 64)),
     ("pw16_kernel<64, 128, 0, 4, 1>", None, "conv3 64->128 + residual + ReLU @24x12x24", 4 * V24 * (64 + 128 + 128)),
+    ("maxpool3_lds_kernel", 1024, "MaxPool3d(3,1,1) 64 ch @48x24x48 (colour path), halo brick through LDS (r4)", 4 * V48 * 64 * 2),
     ("maxpool3_lds_kernel", None, "MaxPool3d(3,1,1) 128 ch @24x12x24, halo brick through LDS (r4)", 4 * V24 * 128 * 2),
     ("conv3d_k3wino_kernel<2, 32, 32", 216, "Bottleneck(32,32) body @48x24x48 on the Winograd kernel + next conv1 (r4): y1 + residual in, out + y1n out",
      4 * (V48 * 32 * 4 + 64 * 32 * 32 + 2 * 32 * 32)),
