@@ -224,7 +224,86 @@ __global__ __launch_bounds__(256) void upload_kernel(const upl4 *__restrict__ sr
     for (; i < n4; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// ---- host -> graph mailbox (include/sis3d.h): kernels inside a captured graph read what changes per chunk from a pinned host ring
+struct MailSlot { unsigned long long src, dst; float origin[3]; unsigned flags; };
+static_assert(sizeof(MailSlot) == 32, "mail slot layout");
+constexpr int MAIL_SLOT_WORD = 8;          // state[8..15]: the fetched slot
+
+// ONE read of the slot across the link (two 16-byte loads), parked in device memory for the launches behind it
+__global__ __launch_bounds__(64) void mail_fetch_kernel(const upl4 *__restrict__ ring, int ring_size, unsigned *__restrict__ state)
+{
+    if (threadIdx.x < 2) {
+        const unsigned k = state[0];
+        const upl4 v = __builtin_nontemporal_load(ring + (size_t)(k % (unsigned)ring_size) * 2 + threadIdx.x);
+        reinterpret_cast<upl4 *>(state + MAIL_SLOT_WORD)[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mail_upload_kernel(const unsigned *__restrict__ state, upl4 *__restrict__ dst, int64_t n4,
+                                                          float *__restrict__ origin_dst)
+{
+    const MailSlot s = *reinterpret_cast<const MailSlot *>(state + MAIL_SLOT_WORD);      // device memory, uniform
+    if (blockIdx.x == 0 && threadIdx.x < 3 && origin_dst && (s.flags & 1u)) origin_dst[threadIdx.x] = s.origin[threadIdx.x];
+    const upl4 *src = reinterpret_cast<const upl4 *>(s.src);
+    // a HOST source is pulled across the link by the first 8 workgroups only (a wave that waits on the link must not sit on many CUs:
+    // see upload_kernel); a DEVICE source (flags bit 1) is copied by the whole grid at HBM speed
+    const int active = (s.flags & 2u) ? (int)gridDim.x : (gridDim.x < 8 ? (int)gridDim.x : 8);
+    if (!src || (int)blockIdx.x >= active) return;
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)active * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        upl4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+    }
+    for (; i < n4; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+__global__ __launch_bounds__(256) void mail_post_kernel(unsigned *__restrict__ state, const float *__restrict__ block_src, int64_t n,
+                                                        unsigned long long *__restrict__ progress)
+{
+    const MailSlot s = *reinterpret_cast<const MailSlot *>(state + MAIL_SLOT_WORD);
+    float *dst = reinterpret_cast<float *>(s.dst);
+    if (dst && block_src)
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = block_src[i];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned k = state[0] + 1u;
+        state[0] = k;
+        if (progress) __hip_atomic_store(progress, (unsigned long long)k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 } // namespace
+
+extern "C" int sis3d_mail_fetch(const void *ring, int ring_size, uint32_t *state, sis3d_stream_t stream)
+{
+    if (!ring || ring_size <= 0 || !state || ((uintptr_t)ring & 15) || ((uintptr_t)state & 15)) return SIS3D_EINVAL;
+    hipLaunchKernelGGL(mail_fetch_kernel, dim3(1), dim3(64), 0, as_stream(stream), (const upl4 *)ring, ring_size, (unsigned *)state);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, int workgroups, sis3d_stream_t stream)
+{
+    if (!state || !input_dst || n <= 0 || (n & 3) || ((uintptr_t)input_dst & 15) || workgroups < 0) return SIS3D_EINVAL;
+    static const int env_wg = [] { const char *e = getenv("SIS3D_MAIL_WGS"); return e ? atoi(e) : 0; }();      // tuning hook
+    const int wg = workgroups > 0 ? workgroups : (env_wg > 0 ? env_wg : 64);
+    hipLaunchKernelGGL(mail_upload_kernel, dim3(wg), dim3(256), 0, as_stream(stream), (const unsigned *)state, (upl4 *)input_dst, n / 4,
+                       origin_dst);
+    return sis3d_check_launch();
+}
+
+extern "C" int sis3d_mail_post(uint32_t *state, const float *block_src, int64_t n, uint64_t *progress, sis3d_stream_t stream)
+{
+    if (!state || n < 0 || (n > 0 && !block_src)) return SIS3D_EINVAL;
+    hipLaunchKernelGGL(mail_post_kernel, dim3(1), dim3(256), 0, as_stream(stream), (unsigned *)state, block_src, n,
+                       (unsigned long long *)progress);
+    return sis3d_check_launch();
+}
 
 extern "C" int sis3d_upload_f32(const float *src, float *dst, int64_t n, int workgroups, sis3d_stream_t stream)
 {

@@ -34,6 +34,9 @@ SIGNATURES = {
     "sis3d_compute_projection": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_f32,
                                          c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_upload_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    "sis3d_mail_fetch": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "sis3d_mail_upload": (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
+    "sis3d_mail_post": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "sis3d_tsdf_encode": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "sis3d_proposal_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_topk_desc": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -55,7 +55,7 @@ def pooled_stream(role, index=0, device=None):
 
 class ChunkEngine:
     def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1,
-                 mask_boxes=0, shared_chip=False, brick_cap=0):
+                 mask_boxes=0, shared_chip=False, brick_cap=0, mailbox=False, mail_input="grid", truncated=3.0):
         """stage: 'backbone' (the two pyramid levels only), 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect'
         (+ proposals, RoI pooling, classifier).
         from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
@@ -74,6 +74,13 @@ class ChunkEngine:
         and eager passes alike -- is dispatched for a chip shared with other chunks' kernels / with the direct k3 kernel's brick capped.
         An attribute of the engine, passed to the library per call: engines of different regimes can be prepared concurrently."""
         self.shared_chip, self.brick_cap = bool(shared_chip), int(brick_cap)
+        # mailbox (r5): what changes per chunk -- the source of the input grid (pinned host or device memory), the chunk origin, the
+        # row that receives the record block -- reaches the captured graph through a ring of slots in pinned host memory
+        # (ops.Mailbox), read by kernels INSIDE the graph: `submit()` is CPU stores + ONE graph launch.  mail_input 'sdf': the source is
+        # the raw SDF block of a .chunk file, TSDF-encoded by the graph's second node (lib/datasets/dataset.py:54-70).
+        self.mail = None
+        self.mail_input, self._trunc = mail_input, float(truncated)
+        self._slot = None
         self.mask_boxes = int(mask_boxes)
         self.mask_plan = None
         self.net, self.dims, self.stage, self.use_graph = net, tuple(dims), stage, use_graph
@@ -111,6 +118,12 @@ class ChunkEngine:
         self.graph = None
         self.out = None
         self.records = None
+        if mailbox:
+            if G != 1 or mail_input not in ("grid", "sdf"):
+                raise ops._lib.Sis3dError("mailbox engines: one chunk per graph, mail_input 'grid' or 'sdf'")
+            self.mail = ops.Mailbox(self.device)
+            if mail_input == "sdf":
+                self._sdf_stage = torch.zeros(self.dims[0] * self.dims[1] * self.dims[2], device=self.device)
 
     # slot-0 views of the static buffers (the single-chunk API)
     scene = property(lambda self: self.scenes[0])
@@ -134,9 +147,33 @@ class ChunkEngine:
         d["records"], d["block"] = ops.pack_records(d, self.dims, self.origins[g])
         return d
 
+    def _mail_commit(self):
+        src, dst, origin = self._slot or (None, None, None)
+        self.mail.write(src, dst, origin)
+        self._slot = None
+
     def _step(self):
+        if self.mail is not None and not torch.cuda.is_current_stream_capturing():
+            self._mail_commit()                      # every EXECUTED pass consumes one slot (a capture records the kernels, it runs none)
         with ops.dispatch_regime(self.shared_chip, self.brick_cap):
-            return self._step_body()
+            if self.mail is not None:
+                if self.mail_input == "sdf":
+                    ops.mail_upload(self.mail, self._sdf_stage, self.origins[0])
+                    ops.tsdf_encode(self._sdf_stage, self.dims, self._trunc, "abs", None, out=self.scenes[0])
+                else:
+                    ops.mail_upload(self.mail, self.scenes[0], self.origins[0])
+            out = self._step_body()
+            if self.mail is not None:
+                ops.mail_post(self.mail, out["block"] if isinstance(out, dict) and "block" in out else None)
+            return out
+
+    def submit(self, src=None, block_dst=None, origin=None):
+        """mailbox engines: one pass on the chunk `src` points at (pinned host or device tensor; None = the static input as it is),
+        record block to `block_dst`, boxes shifted by `origin`: CPU stores into the next mailbox slot + one graph launch"""
+        if self.mail is None:
+            raise ops._lib.Sis3dError("submit() needs an engine built with mailbox=True")
+        self._slot = (src, block_dst, origin)
+        return self.run()
 
     def _step_body(self):
         net = self.net
@@ -274,6 +311,8 @@ class ChunkEngine:
                 else:
                     self._encode_views()
             if self.graph is not None:
+                if self.mail is not None:
+                    self._mail_commit()
                 self.graph.replay()
             else:
                 self.out = self._step()
@@ -374,6 +413,10 @@ class PipelinedEngines:
     # reads (a 3.5 MB device copy, or sis3d_tsdf_encode when the host hands over the raw 1.77 MB SDF block of a .chunk file:
     # lib/datasets/dataset.py:54-70), releases the staging buffer and replays the graph.  Fed one chunk ahead, the upload of chunk
     # k + 1 runs under the compute of chunk k; nothing on the host waits.
+    @property
+    def mailbox(self):
+        return self.engines[0].mail is not None
+
     def enable_feed(self, mode="grid", truncated=3.0, copy="kernel"):
         """mode 'grid': hosts hand over the encoded (1,2,X,Y,Z) float32 grid, as the reference's dataloader does; 'sdf': the raw
         float32 SDF block in file order (x fastest), encoded on the device.  Host tensors must be pinned.
@@ -393,6 +436,14 @@ class PipelinedEngines:
         per_pipeline 0.829, shared 1.38."""
         if mode not in ("grid", "sdf"):
             raise ValueError("feed mode must be 'grid' or 'sdf'")
+        if self.mailbox:
+            # engines built with mailbox=True take their chunks through the graph's own upload node (ChunkEngine.submit): nothing
+            # to set up, no command per chunk besides the graph launch; the engines' mail_input fixes the format
+            if any(e.mail_input != mode for e in self.engines):
+                raise ops._lib.Sis3dError("these engines were captured for mail_input=%r" % self.engines[0].mail_input)
+            self._feed_mode, self._feed_copy = mode, "mailbox"
+            self._mail_q = [[] for _ in self.engines]
+            return self
         if copy not in ("kernel", "own", "per_pipeline", "shared"):
             raise ValueError("copy must be 'kernel', 'own', 'per_pipeline' or 'shared'")
         if any(e.group != 1 or e.use_images for e in self.engines):
@@ -417,6 +468,11 @@ class PipelinedEngines:
     def feed(self, i, host):
         """enqueue the upload of one chunk for pipeline i -> False if the pipeline's staging buffers all hold chunks that have not
         been consumed yet (nothing is enqueued then)"""
+        if self.mailbox:
+            if host.is_cuda or not host.is_pinned():
+                raise ops._lib.Sis3dError("feed: the chunk must sit in pinned host memory")
+            self._mail_q[i].append(host)                # no GPU work here: the graph's upload node reads it when the pass runs
+            return True
         f = self._feed[i]
         if f["fed"] - f["run"] >= f["nbuf"]:
             return False
@@ -440,11 +496,15 @@ class PipelinedEngines:
 
     def is_fed(self, i, host):
         """is an upload of THIS host tensor outstanding on pipeline i (fed, not yet consumed)?"""
+        if self.mailbox:
+            return any(h.data_ptr() == host.data_ptr() for h in self._mail_q[i])
         f = self._feed[i]
         return any(f["tag"][k % f["nbuf"]] == host.data_ptr() for k in range(f["run"], f["fed"]))
 
     def pending(self, i):
         """chunks fed to pipeline i and not yet consumed"""
+        if self.mailbox:
+            return len(self._mail_q[i])
         f = self._feed[i]
         return f["fed"] - f["run"]
 
@@ -477,6 +537,11 @@ class PipelinedEngines:
         """run pipeline i on the next chunk it was fed (host given and nothing outstanding: fed now) -> the static output dict"""
         if host is not None and self.pending(i) == 0:
             self.feed(i, host)
+        if self.mailbox:
+            if not self._mail_q[i]:
+                raise ops._lib.Sis3dError("streamed inputs: nothing was fed to pipeline %d" % i)
+            with torch.cuda.stream(self.streams[i]):
+                return self.engines[i].submit(src=self._mail_q[i].pop(0))
         st = self.streams[i]
         self.consume(i, st)
         with torch.cuda.stream(st):

@@ -98,15 +98,17 @@ class HipEncoder(object):
     def __call__(self, images):
         if not images.is_cuda:
             raise _lib.Sis3dError("enet_hip: images must be on the GPU (the product has no CPU path)")
-        # the folded weights reach the kernels as raw pointers: every parameter / buffer of the module tree must live on the images'
-        # device, or the launch would dereference host (or another GPU's) memory -- a Python error here, not a GPU fault there
-        for m in self.entries:
-            for q in list(m.parameters()) + list(m.buffers()):
-                if q.device != images.device:
-                    raise _lib.Sis3dError("enet_hip: encoder weights are on %s but the images on %s (call net.cuda() first)"
-                                          % (q.device, images.device))
+        # ONE walk over the module tree per call: (data_ptr, version) of every parameter / buffer tells both whether the folded plan is
+        # still valid and -- only when it is not -- that everything has to be checked for its device before raw pointers reach a kernel
+        # (a Python error here, not a GPU fault there).  A tensor that moves device changes its data_ptr, so an unchanged key implies
+        # an unchanged placement.
         key = (self._version(), images.device)
         if key != self._key:
+            for m in self.entries:
+                for q in list(m.parameters()) + list(m.buffers()):
+                    if q.device != images.device:
+                        raise _lib.Sis3dError("enet_hip: encoder weights are on %s but the images on %s (call net.cuda() first)"
+                                              % (q.device, images.device))
             self._plan, self._key = self._build(), key
         L = lib()
         st = _stream()

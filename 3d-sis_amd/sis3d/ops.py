@@ -357,6 +357,70 @@ def upload(host, out, workgroups=0):
     return out
 
 
+class Mailbox(object):
+    """Host side of the host -> graph mailbox (include/sis3d.h, sis3d_mail_upload / sis3d_mail_post): a ring of 32-byte slots in
+    PINNED host memory that kernels inside a captured graph read, the device counter of consumed slots and the pinned progress
+    word the device writes back.  `write()` is plain CPU stores -- no HIP call -- so a pipeline's only call per chunk is the graph
+    launch (a command enqueued behind a graph launch that has not finished can block the host on this runtime).
+    slot = { u64 src; u64 dst; f32 origin[3]; u32 flags }."""
+    RING = 256
+
+    def __init__(self, device, ring=RING):
+        import numpy as np
+        self.ring_size = int(ring)
+        self.buf = torch.zeros(self.ring_size * 32, dtype=torch.uint8).pin_memory()
+        a = self.buf.numpy()
+        self.u64 = a.view(np.uint64).reshape(self.ring_size, 4)
+        self.f32 = a.view(np.float32).reshape(self.ring_size, 8)
+        self.u32 = a.view(np.uint32).reshape(self.ring_size, 8)
+        self.state = torch.zeros(16, dtype=torch.int32, device=device)      # [0] consumed slots, [8..15] the slot of the running pass
+        self._progress_t = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.progress = self._progress_t.numpy()
+        self.head = 0                                  # slots written so far (the device has consumed progress[0] of them)
+        self.keep = [None] * self.ring_size            # the tensors behind the pointers of the outstanding slots stay alive
+
+    def write(self, src=None, dst=None, origin=None):
+        """the slot of the NEXT pass: src = tensor to copy into the pipeline's input (pinned host or device memory; None: the input
+        buffer already holds the chunk), dst = tensor that receives the pass's record block (None: nowhere), origin = (x, y, z)"""
+        while self.head - int(self.progress[0]) >= self.ring_size - 1:
+            pass                                       # the producer is a whole ring ahead of the device: wait for a slot (rare)
+        k = self.head % self.ring_size
+        self.u64[k, 0] = src.data_ptr() if src is not None else 0
+        self.u64[k, 1] = dst.data_ptr() if dst is not None else 0
+        flags = 2 if (src is not None and src.is_cuda) else 0          # bit 1: a device source is copied by the whole grid
+        if origin is not None:
+            self.f32[k, 4] = origin[0]; self.f32[k, 5] = origin[1]; self.f32[k, 6] = origin[2]
+            flags |= 1
+        self.u32[k, 7] = flags
+        self.keep[k] = (src, dst)
+        self.head += 1
+
+
+def mail_source(t, numel):
+    """a tensor a mailbox slot may name as the source of a chunk: contiguous float32 with `numel` elements, on the device or in pinned
+    host memory -> the tensor, else None (the caller copies it the ordinary way)"""
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != numel:
+        return None
+    if t.is_cuda or t.is_pinned():
+        return t
+    return None
+
+
+def mail_upload(mb, input_dst, origin_dst=None, workgroups=0):
+    """first two nodes of a pipeline's graph: fetch the slot of this pass across PCIe (sis3d_mail_fetch), then slot.src -> input_dst and
+    slot.origin -> origin_dst (sis3d_mail_upload)"""
+    _dev(input_dst, "input_dst")
+    check(lib().sis3d_mail_fetch(_ptr(mb.buf), mb.ring_size, _ptr(mb.state), _stream()), "sis3d_mail_fetch")
+    check(lib().sis3d_mail_upload(_ptr(mb.state), _ptr(input_dst), input_dst.numel(), _ptr(origin_dst), int(workgroups), _stream()),
+          "sis3d_mail_upload")
+
+
+def mail_post(mb, block_src):
+    """last node: the record block -> slot.dst, and the slot is consumed (sis3d_mail_post)"""
+    n = block_src.numel() if block_src is not None else 0
+    check(lib().sis3d_mail_post(_ptr(mb.state), _ptr(block_src), n, _ptr(mb._progress_t), _stream()), "sis3d_mail_post")
+
+
 def tsdf_encode(sdf, dims, truncated=3.0, mode="abs", max_height=None, channels_last=True, out=None):
     """raw sdf grid in file order (flat, x fastest; numel X*Y*Z, cuda) -> network input, logical (1,2,X,Yout,Z)
     (dataset.py:54-70 + the max-height crop :196-211).  out: a contiguous planar (1,2,X,Yout,Z) buffer to write into (the static

@@ -15,7 +15,6 @@ import os as _os
 # (1.357 vs 1.331 ms in the same box run, profiles/r04_scene_share_pipelines.txt) -- off by default, kept as an A/B switch
 ROUND_STAGGER = _os.environ.get("SIS3D_ROUND_STAGGER", "0") != "0"
 # lazy results: join + gather + whole-scene merge on their own stream, scenes overlap (A/B switch; on by default since r5)
-WAIT_PER_CHUNK = _os.environ.get("SIS3D_WAIT_PER_CHUNK", "0") != "0"      # A/B switch (r4 behaviour: a cross-stream wait per chunk)
 MERGE_STREAM = _os.environ.get("SIS3D_MERGE_STREAM", "1") != "0"
 
 
@@ -71,7 +70,10 @@ class SceneRunner:
         self.solo = bool(solo) or self.emulate is not None
         self.k_rows = int(net.cfg.TEST.RPN_POST_NMS_TOP_N)
         self.use_graph = bool(use_graph)
-        self.pipes = PipelinedEngines(net, inflight, dims=dims, stage="detect", use_graph=use_graph).prepare()
+        self.dims = tuple(int(d) for d in dims)
+        # mailbox engines (r5): a chunk costs the host one graph launch and nothing else (ChunkEngine.submit)
+        self.pipes = PipelinedEngines(net, inflight, dims=dims, stage="detect", use_graph=use_graph,
+                                      mailbox=(_os.environ.get("SIS3D_SCENE_MAILBOX", "1") != "0")).prepare()
         self._origins = {}
         self._send = None
         self._round = None          # (graph, stream, send buffer): one launch for a share of exactly len(engines) chunks
@@ -121,10 +123,9 @@ class SceneRunner:
         mine = parallel.shard_chunks(len(chunks), rank, world)
         bf = parallel.block_floats(self.k_rows)
         dev = self.pipes.engines[0].device
-        streamed = self._streamed(chunks, mine)
         if self.use_graph and self._use_round and len(mine) == len(self.pipes.engines) \
                 and all(not isinstance(chunks[c][2], (tuple, list)) for c in mine) and self.prepare_round():
-            return self._run_round(chunks, mine, bf, dev, streamed, post)
+            return self._run_round(chunks, mine, bf, dev, post)
         if post is not None:
             b = self._scene_no & 1
             self._scene_no += 1
@@ -138,69 +139,50 @@ class SceneRunner:
                 self._send = torch.zeros(max(1, len(mine)), bf, device=dev)
             send = self._send
         n = len(self.pipes.engines)
+        nfloat = 2 * self.dims[0] * self.dims[1] * self.dims[2]
         with torch.no_grad():
             if post is not None and self._consumed[self._send_slot] is not None:
                 for st in self.pipes.streams:                 # the scene before last has been gathered out of this send buffer
                     st.wait_event(self._consumed[self._send_slot])
-            if not WAIT_PER_CHUNK:
-                # the pipelines' streams are ordered behind the caller's stream ONCE per scene (the chunks of a scene are all there when
-                # infer() is called), not once per chunk: 4 cross-queue barriers per scene instead of 32
-                cur = torch.cuda.current_stream()
-                for st in self.pipes.streams:
-                    st.wait_stream(cur)
+            # the pipelines' streams are ordered behind the caller's stream ONCE per scene (the chunks of a scene are all there when
+            # infer() is called), not once per chunk: 4 cross-queue barriers per scene instead of 32
+            cur = torch.cuda.current_stream()
+            for st in self.pipes.streams:
+                st.wait_stream(cur)
             for j, c in enumerate(mine):
                 cid, origin, payload = chunks[c]
                 e = j % n
                 eng = self.pipes.engines[e]
-                if streamed:
-                    # host chunks (pinned): uploaded on the copy stream one chunk ahead of the pipeline that consumes them
-                    if not self.pipes.is_fed(e, payload):
-                        self.pipes.feed(e, payload)
-                    self.pipes.consume(e, self.pipes.streams[e])
-                elif isinstance(payload, (tuple, list)):
-                    self.pipes.load(e, *payload, wait=WAIT_PER_CHUNK)
+                org = (float(origin[0]), float(origin[1]), float(origin[2]))
+                if eng.mail is not None:
+                    # r5: ONE call per chunk -- the graph launch.  Where the grid comes from (device memory or PINNED HOST memory: the
+                    # reference's forward owns the upload, lib/nets/network.py:191), the chunk origin and the send-buffer row that
+                    # receives the record block travel in a mailbox slot (CPU stores) and are applied by kernels inside the graph; a
+                    # copy enqueued behind a graph launch that has not finished can block the host on this runtime
+                    src = None
+                    if isinstance(payload, (tuple, list)):
+                        self.pipes.load(e, *payload, wait=False)          # image-path payloads: feature maps + index lists, copied eagerly
+                    else:
+                        src = ops.mail_source(payload, nfloat)
+                        if src is None:
+                            self.pipes.load(e, payload, wait=False)       # pageable / strided / non-fp32 grids: an ordinary copy
+                    with torch.cuda.stream(self.pipes.streams[e]):
+                        eng.submit(src=src, block_dst=send[j], origin=org)
+                    continue
+                if isinstance(payload, (tuple, list)):
+                    self.pipes.load(e, *payload, wait=False)
                 else:
-                    self.pipes.load(e, payload, wait=WAIT_PER_CHUNK)
+                    self.pipes.load(e, payload, wait=False)
                 with torch.cuda.stream(self.pipes.streams[e]):
                     eng.origins[0].copy_(self._origin(origin), non_blocking=True)
                     out = eng.run()
                     send[j].copy_(out["block"], non_blocking=True)     # out of the graph's static buffer before its next replay
-                if streamed and j + n < len(mine) and self.pipes._feed_copy != "own":
-                    # look-ahead BEHIND the replay (the upload may go straight into the graph's static input): this pipeline's next
-                    # chunk is on its way while the host moves on.  Not with hipMemcpyAsync ('own'): enqueued right behind a graph
-                    # launch it blocks the HOST until the graph has drained (0.12 -> 0.9 ms of host time per step), so there chunk
-                    # j + n is fed when its turn comes
-                    self.pipes.feed(e, chunks[mine[j + n]][2])
             if post is not None:
                 for st in self.pipes.streams:
                     post.wait_stream(st)
             else:
                 self.pipes.join()
         return send[:len(mine)]
-
-    def _streamed(self, chunks, mine):
-        """True when every chunk of this rank's share arrives as a pinned HOST grid: the double-buffered upload path
-        (PipelinedEngines.feed / consume) serves it; the feeder is set up on first use"""
-        if not mine:
-            return False
-        ok = all(torch.is_tensor(chunks[c][2]) and not chunks[c][2].is_cuda and chunks[c][2].is_pinned() for c in mine)
-        if ok and not hasattr(self.pipes, "_feed"):
-            self.pipes.enable_feed("grid", copy=_os.environ.get("SIS3D_FEED_COPY", "kernel"))
-        return ok
-
-    def prefetch(self, chunks, group=None):
-        """start uploading the first chunk of every pipeline of a scene whose chunks sit in pinned host memory -- call it right after
-        infer() of the PREVIOUS scene has been enqueued: the uploads then run under that scene's compute (the copy stream waits only
-        for the staging buffers, not for the pipelines)"""
-        rank, world = self._rank_world(group)
-        mine = parallel.shard_chunks(len(chunks), rank, world)
-        if not self._streamed(chunks, mine) or self.pipes._feed_copy == "own":
-            return 0                                    # ('own': see run_chunks -- an upload behind a fresh graph launch blocks the host)
-        n, fed = len(self.pipes.engines), 0
-        for j, c in enumerate(mine[:n]):
-            if self.pipes.pending(j % n) == 0 and self.pipes.feed(j % n, chunks[c][2]):
-                fed += 1
-        return fed
 
     def calibrate(self, chunks, group=None, reps=2, count=16, gathered=None):
         """choose the pipelines' streams -- and, for a share of exactly one chunk per pipeline, between the one-launch round graph
@@ -255,10 +237,10 @@ class SceneRunner:
                 self._round_error = "%s: %s" % (type(e).__name__, e)
         return self._round is not None
 
-    def _run_round(self, chunks, mine, bf, dev, streamed=False, post=None):
-        """the share is exactly one chunk per pipeline: inputs copied into the static buffers on ONE stream, then ONE graph launch
-        (PipelinedEngines.capture_round) runs all of them and leaves their record blocks in the send buffer; the caller's stream
-        is ordered behind the graph, no host-side join"""
+    def _run_round(self, chunks, mine, bf, dev, post=None):
+        """the share is exactly one chunk per pipeline: every pipeline's mailbox slot is written (grid source, origin), then ONE graph
+        launch (PipelinedEngines.capture_round) runs all of them and leaves their record blocks in the send buffer; the caller's
+        stream (or `post`) is ordered behind the graph, no host-side join"""
         g, main, send = self._round
         cur = torch.cuda.current_stream()
         main.wait_stream(cur)
@@ -266,26 +248,23 @@ class SceneRunner:
             self._send_slot = 2
             if self._consumed[2] is not None:
                 main.wait_event(self._consumed[2])         # the previous scene's rows have been gathered out of the graph's send buffer
-        if streamed:
-            for e, c in enumerate(mine):
-                if not self.pipes.is_fed(e, chunks[c][2]):
-                    self.pipes.feed(e, chunks[c][2])
+        nfloat = 2 * self.dims[0] * self.dims[1] * self.dims[2]
         with torch.no_grad(), torch.cuda.stream(main):
             for e, c in enumerate(mine):
                 cid, origin, payload = chunks[c]
                 eng = self.pipes.engines[e]
-                if streamed:
-                    self.pipes.consume(e, main)
+                org = (float(origin[0]), float(origin[1]), float(origin[2]))
+                if eng.mail is not None:
+                    src = ops.mail_source(payload, nfloat)
+                    if src is None:
+                        eng._copy(eng.scenes[0], payload)
+                    eng.mail.write(src, None, org)             # the round graph copies the blocks into its own send buffer
                 else:
                     eng._copy(eng.scenes[0], payload)
                     if payload.is_cuda:
                         payload.record_stream(main)
-                eng.origins[0].copy_(self._origin(origin), non_blocking=True)
+                    eng.origins[0].copy_(self._origin(origin), non_blocking=True)
             g.replay()
-            if streamed:
-                # uploads enqueued on a pipeline's own stream (feed copy 'kernel' / 'own') write the static inputs this graph reads
-                for st in self.pipes.streams:
-                    st.wait_stream(main)
         (post if post is not None else cur).wait_stream(main)
         return send
 

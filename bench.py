@@ -674,18 +674,20 @@ def preheat(step, ms):
         torch.cuda.synchronize()
 
 
-def time_streamed(eng, args, rank, nfl, barrier, mode):
-    """The same pipelines on FRESH chunks from pinned host memory (the reference's forward owns the upload:
-    `blobs['data'].cuda()`, lib/nets/network.py:191): every step every pipeline consumes a chunk it has not seen in the previous
-    RING - 1 steps, uploaded on the copy stream one chunk ahead (PipelinedEngines.feed / run_fed), so the H2D copy of chunk k + 1 runs
-    under the compute of chunk k.  mode 'grid': the encoded (1,2,96,48,96) float32 grid the reference's dataloader hands over
-    (3.54 MB per chunk); 'sdf': the raw SDF block of a .chunk file (1.77 MB), TSDF-encoded on the device (sis3d_tsdf_encode).
-    -> dict(dt, bytes_per_chunk)"""
+def time_streamed(net, stage, args, rank, nfl, barrier, mode):
+    """The chunk pipelines on FRESH chunks from pinned host memory (the reference's forward owns the upload:
+    `blobs['data'].cuda()`, lib/nets/network.py:191): every step every pipeline runs a chunk it has not seen in the previous RING - 1
+    steps.  The pipelines are captured with a MAILBOX (PipelinedEngines(mailbox=True), ops.Mailbox): the first node of a pipeline's
+    graph reads the chunk's host pointer from a ring of slots in pinned memory and pulls the chunk across PCIe itself
+    (sis3d_mail_upload), so the host's only call per chunk is the graph launch.  mode 'grid': the encoded (1,2,96,48,96) float32 grid
+    the reference's dataloader hands over (3.54 MB per chunk); 'sdf': the raw SDF block of a .chunk file (1.77 MB), TSDF-encoded by the
+    graph's second node.  -> dict(dt, bytes_per_chunk, ...)"""
     import torch
     from sis3d import synthetic
+    from sis3d.engine import PipelinedEngines
     RING = 4
     torch.cuda.synchronize()
-    eng.enable_feed(mode, copy=os.environ.get("SIS3D_FEED_COPY", "kernel"))
+    eng = PipelinedEngines(net, nfl, stage=stage, mailbox=True, mail_input=mode)
     ring = []
     for i in range(nfl):
         row = []
@@ -694,39 +696,29 @@ def time_streamed(eng, args, rank, nfl, barrier, mode):
             t = synthetic.synth_chunk(cid) if mode == "grid" else synthetic.synth_sdf(cid)
             row.append(t.contiguous().pin_memory())
         ring.append(row)
-    own = eng._feed_copy == "own"          # hipMemcpyAsync on the pipeline's stream: must not be enqueued behind a fresh graph launch
-    if not own:
-        for i in range(nfl):
-            eng.feed(i, ring[i][0])
+    eng.prepare(warmup=2)
+    eng.enable_feed(mode)
+    k = [0]
 
-    def step(k):
+    def step():
         for i in range(nfl):
-            if own:
-                # upload, then replay, on the pipeline's own stream: the upload is enqueued when the PREVIOUS replay of this pipeline is
-                # a whole step old (an upload enqueued right behind a fresh graph launch blocks the host until the graph drains)
-                eng.run_fed(i, ring[i][k % RING])
-            else:
-                eng.run_fed(i)
-                eng.feed(i, ring[i][(k + 1) % RING])
-    k = 0
+            eng.run_fed(i, ring[i][k[0] % RING])
+        k[0] += 1
+    if not args.no_calibrate and nfl >= 2:
+        preheat(step, min(args.preheat_ms, 60.0))
+        eng.calibrate(step, reps=8, warm=2)
+    preheat(step, args.preheat_ms)
     for _ in range(max(args.warmup, 4)):
-        step(k)
-        k += 1
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(k)
-        k += 1
+        step()
     t_host = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
-    # drain: one chunk per pipeline is still staged
-    for i in range(nfl):
-        if eng.pending(i):
-            eng.run_fed(i)
-    torch.cuda.synchronize()
-    return dict(dt=dt, bytes_per_chunk=ring[0][0].numel() * 4, ring=RING, host_ms_per_step=t_host / args.steps * 1e3,
-                copy=eng._feed_copy)
+    return dict(dt=dt, bytes_per_chunk=ring[0][0].numel() * 4, ring=RING, host_ms_per_step=t_host / args.steps * 1e3, copy="mailbox",
+                stream_window=eng.stream_window)
 
 
 def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
@@ -738,11 +730,12 @@ def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
             "host_enqueue_ms_per_step": st.get("host_ms_per_step"), "upload_by": st.get("copy"),
             "input": ("encoded (1,2,96,48,96) float32 grid = the reference's blobs['data'] (lib/nets/network.py:191)" if mode == "grid"
                       else "raw float32 SDF block in .chunk file order, TSDF-encoded on the device (sis3d_tsdf_encode; dataset.py:54-70)"),
-            "how": "every step each of the %d pipelines runs a FRESH chunk from pinned host memory: the upload is a KERNEL on the "
-                   "pipeline's own stream that reads the host memory across PCIe (sis3d_upload_f32 into the graph's static input; sdf: "
-                   "sis3d_tsdf_encode reads the host block itself), enqueued one chunk ahead right behind the previous replay "
-                   "(PipelinedEngines.feed / run_fed, copy='kernel': no copy stream, no event handshake, no staging buffer -- the other "
-                   "pipelines keep the CUs busy while one waits on the link); ring of %d distinct host chunks per pipeline; the timed "
+            "how": "every step each of the %d pipelines runs a FRESH chunk from pinned host memory.  The pipelines are captured with a "
+                   "mailbox: the first node of a pipeline's graph reads the chunk's host pointer from a ring of slots in pinned memory "
+                   "(CPU stores by the host, no HIP call) and pulls the chunk across PCIe itself (sis3d_mail_upload: 8 workgroups, 256 KB "
+                   "in flight; sdf: + sis3d_tsdf_encode as the second node), so the host's ONLY call per chunk is the graph launch -- a "
+                   "command enqueued behind a graph launch that has not finished can block the host on this runtime.  A pipeline pauses for "
+                   "its own upload while the other pipelines keep the CUs busy; ring of %d distinct host chunks per pipeline; the timed "
                    "region contains every upload" % (nfl, st["ring"])}
 
 
@@ -798,12 +791,9 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
     if workload in ("backbone_rpn", "detect") and not masks and grp == 1 and not args.no_graph and not args.no_streamed:
         for mode in ("grid", "sdf"):
             try:
-                streamed[mode] = time_streamed(eng, args, rank, nfl, barrier, mode)
+                streamed[mode] = time_streamed(net, stage, args, rank, nfl, barrier, mode)
             except Exception as e:                               # a side measurement must never take the headline down
                 streamed[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
-        # the static buffers now hold ring chunks: put the resident chunks back (single-chunk latency / snapshots below use them)
-        for i in range(nfl):
-            eng.load(i, synthetic.synth_chunk(rank * nfl + i))
         torch.cuda.synchronize()
     # Winograd accounting of THIS configuration under the regime its pipelines captured: one eager pass of pipeline 0
     wino_flops = None
@@ -930,8 +920,8 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     that double-buffers its results; every scene's lengths are read, the last one inside the timed region.
     emulate = (r, W) + gathered = a full scene's gathered table: rank r's share of a W-rank run on this GPU alone -- its own chunks
     (one graph launch when it owns one chunk per pipeline), its rows written over the table, the merge of the FULL table.
-    streamed: the rank's chunks sit in PINNED HOST memory and every scene uploads all of them (SceneRunner's double-buffered feed:
-    copy stream, one chunk ahead per pipeline; the next scene's first chunks are prefetched under the current scene's compute).
+    streamed: the rank's chunks sit in PINNED HOST memory and every scene uploads all of them (the first node of each pipeline's graph
+    pulls its chunk across PCIe: ChunkEngine.submit / ops.Mailbox).
     runner: reuse a SceneRunner (its captured graphs) from a previous call with the same sharding."""
     import torch
     from sis3d import parallel, synthetic
@@ -961,10 +951,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         runner.calibrate(chunks, gathered=gathered)
 
     def one():
-        r = runner.infer(chunks, with_masks=args.masks, gathered=gathered, lazy=lazy)
-        if streamed:
-            runner.prefetch(chunks)         # the next scene's first chunk of every pipeline: uploaded under this scene's compute
-        return r
+        return runner.infer(chunks, with_masks=args.masks, gathered=gathered, lazy=lazy)
 
     def done(r):
         return r.resolve() if lazy else r
@@ -992,12 +979,6 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         extra["masks_on_this_rank"] = len(res[2])
         extra["mask_voxels_on_this_rank"] = int(sum(m.numel() for _, m in res[2].values()))
     out = dict(dt=dt, vox_per_step=n_chunks * VOXELS, single_ms=None, extra=extra, steps=steps, runner=runner)
-    if streamed:
-        torch.cuda.synchronize()
-        for e in range(len(runner.pipes.engines)):          # drain the chunks the last prefetch staged
-            while runner.pipes.pending(e):
-                runner.pipes.consume(e, runner.pipes.streams[e])
-        torch.cuda.synchronize()
     if want_table:
         with torch.no_grad():
             out["table"] = parallel.gather_blocks(runner.run_chunks(chunks), n_chunks, runner.k_rows, solo=True).clone()
@@ -1250,9 +1231,9 @@ def main(argv=None):
                     "ratio_to_resident": sc["dt"] / sc["steps"] / (ss["dt"] / ss["steps"]),
                     "host_bytes_per_scene_per_gpu": n_local * 2 * VOXELS * 4,
                     "records_gathered": ss["extra"]["records_gathered"], "kept_after_scene_nms": ss["extra"]["kept_after_scene_nms"],
-                    "how": "every scene uploads this rank's %d chunks (3.54 MB each, pinned host memory) through SceneRunner's "
-                           "double-buffered feed: copy stream, one chunk ahead per pipeline, the next scene's first chunks prefetched "
-                           "under the current scene's compute" % n_local}
+                    "how": "every scene uploads this rank's %d chunks (3.54 MB each, pinned host memory): the first node of each "
+                           "pipeline's captured graph pulls its chunk across PCIe (mailbox slot written by the host, sis3d_mail_upload); "
+                           "the host's only call per chunk is the graph launch" % n_local}
             except Exception as e:
                 side["scene"]["streamed"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world > 1 and rank == 0:

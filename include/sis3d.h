@@ -181,6 +181,28 @@ int sis3d_tsdf_encode(const float *sdf, int X, int Y, int Z, int Yout, float tru
  * wave waiting on the link must not sit on many CUs, see csrc/pool_misc.hip). */
 int sis3d_upload_f32(const float *src_host_mapped, float *dst, int64_t n, int workgroups, sis3d_stream_t stream);
 
+/* ---- host -> graph MAILBOX (r5): per-chunk inputs of a captured pipeline without a single per-chunk command ----------------------
+ * On this runtime a command enqueued on a stream whose last command is a graph launch that has not finished can BLOCK THE HOST
+ * until that graph drains -- an upload kernel, a hipMemcpyAsync, even the 12-byte copy of a chunk origin (profiles/r05_feed_probe.txt:
+ * 0.16 -> 1.45 ms of host time per step, bimodal).  A pipeline that replays a captured graph per chunk therefore takes everything
+ * that changes from chunk to chunk through a ring of 32-byte slots in PINNED host memory, which kernels INSIDE the graph read:
+ *     slot = { u64 src; u64 dst; f32 origin[3]; u32 flags }       flags bit 0: origin valid, bit 1: src is DEVICE memory
+ * The host writes slot (k mod ring_size) with plain CPU stores and replays the graph: hipGraphLaunch is the ONLY call per chunk.
+ *   sis3d_mail_fetch   first node of the graph: ONE read of slot k = state[0] (device counter of consumed slots) across PCIe into
+ *                      state[8..15] -- small uncached reads over the link are slow and serialise, so no other kernel touches the ring.
+ *   sis3d_mail_upload  second node: copies n floats from the fetched slot's src -- a pinned host pointer (pulled across PCIe by 8
+ *                      workgroups with 256 KB in flight, as sis3d_upload_f32) or a device pointer (flags bit 1: copied by the whole
+ *                      grid at HBM speed); 0 = the input buffer already holds the chunk -- to `input_dst` (n % 4 == 0, 16-byte aligned),
+ *                      and the slot's origin to `origin_dst` (3 floats; may be NULL).  Replaces `blobs['data'].cuda()`
+ *                      (lib/nets/network.py:191).
+ *   sis3d_mail_post    last node: copies n floats of `block_src` (the chunk's record block) to the slot's dst (0 = nowhere) and
+ *                      consumes the slot: state[0] = k + 1, *progress = k + 1 (pinned host word the producer polls before it laps
+ *                      the ring).
+ * state: 16 uint32 of device memory, zero-initialised, owned by the pipeline. */
+int sis3d_mail_fetch(const void *ring_host_mapped, int ring_size, uint32_t *state, sis3d_stream_t stream);
+int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, int workgroups, sis3d_stream_t stream);
+int sis3d_mail_post(uint32_t *state, const float *block_src, int64_t n, uint64_t *progress_host_mapped, sis3d_stream_t stream);
+
 /* ------------------------------------------------------- proposal decoding --
  * Replaces proposal_layer.py:96-103 + bbox_transform_inv / clip_boxes
  * (lib/utils/bbox_transform.py:59-99,4-21) for one level:

@@ -391,77 +391,88 @@ print("RCCL_WORLD1_OK", len(calls), tuple(want_r.shape), int(want_k.numel()))
     report("RCCL world-of-one: gather_blocks' nccl branch ran 3 scenes, %s" % p.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("copy", ["kernel", "own", "per_pipeline"])
+@pytest.mark.parametrize("copy", ["mailbox", "kernel", "own", "per_pipeline"])
 def test_streamed_inputs_equal_resident_inputs(copy):
     """r5 (the reference's forward owns the upload, lib/nets/network.py:191): chunks that arrive in PINNED HOST
-    memory -- as the encoded grid or as the raw SDF block of a .chunk file -- through PipelinedEngines.feed / run_fed give the
-    outputs of the same chunks loaded into the static buffers, bit for bit, for every upload method; a whole scene fed from host
-    memory (per-chunk launches, the one-launch round, lazy results with a prefetch in between) gives the resident scene's records."""
+    memory -- as the encoded grid or as the raw SDF block of a .chunk file -- give the outputs of the same chunks loaded into the
+    static buffers, bit for bit, for every upload method: 'mailbox' (the default: engines captured with the upload as the first
+    node of their graph, the host pointer travels in a ring of pinned slots, ONE call per chunk) and the eager variants of
+    PipelinedEngines.feed / run_fed (upload kernel / hipMemcpyAsync on the pipeline's stream, copy stream per pipeline)."""
     from sis3d.engine import PipelinedEngines
-    from sis3d.scene import SceneRunner
     from sis3d import ops
     net, cfg = _small_net()
     dims = (48, 24, 40)
     n = 3
-    eng = PipelinedEngines(net, n, dims=dims, stage="rpn").prepare()
+    ref = PipelinedEngines(net, n, dims=dims, stage="rpn").prepare()
     ids = [[30 + 10 * i + r for r in range(3)] for i in range(n)]
     want = {}
     for i in range(n):
         for cid in ids[i]:
-            eng.load(i, synthetic.synth_chunk(cid, dims))
-            out = eng.run(i)
-            with torch.cuda.stream(eng.streams[i]):                  # the clone must sit behind the replay, on the pipeline's stream
+            ref.load(i, synthetic.synth_chunk(cid, dims))
+            out = ref.run(i)
+            with torch.cuda.stream(ref.streams[i]):                  # the clone must sit behind the replay, on the pipeline's stream
                 want[cid] = {k: v.clone() for k, v in out.items()}
             torch.cuda.synchronize()
     for mode in ("grid", "sdf"):
         host = {cid: (synthetic.synth_chunk(cid, dims) if mode == "grid" else synthetic.synth_sdf(cid, dims)).contiguous().pin_memory()
                 for row in ids for cid in row}
-        eng.enable_feed(mode, copy=copy)
+        if copy == "mailbox":
+            eng = PipelinedEngines(net, n, dims=dims, stage="rpn", mailbox=True, mail_input=mode).prepare()
+            eng.enable_feed(mode)
+        else:
+            eng = ref
+            eng.enable_feed(mode, copy=copy)
         for r in range(3):
             got = {}
             for i in range(n):
                 o = eng.run_fed(i, host[ids[i][r]])
                 with torch.cuda.stream(eng.streams[i]):              # outputs copied out behind the replay, before the look-ahead upload
                     got[i] = {k: v.clone() for k, v in o.items()}
-                if copy != "own" and r + 1 < 3:
-                    assert eng.feed(i, host[ids[i][r + 1]])          # one chunk ahead, right behind the replay
+                if copy not in ("own",) and r + 1 < 3:
+                    assert eng.feed(i, host[ids[i][r + 1]])          # one chunk ahead
             torch.cuda.synchronize()
             for i in range(n):
                 for k, v in want[ids[i][r]].items():
                     assert torch.equal(got[i][k], v), (mode, copy, i, r, k)
-        for i in range(n):
-            while eng.pending(i):
-                eng.consume(i, eng.streams[i])
+        if copy != "mailbox":
+            for i in range(n):
+                while eng.pending(i):
+                    eng.consume(i, eng.streams[i])
         torch.cuda.synchronize()
+        if copy == "mailbox":
+            mb = eng.engines[0].mail
+            assert mb.head == int(mb.progress[0]) and mb.head >= 3    # every slot written was consumed by exactly one pass
     with pytest.raises(ops._lib.Sis3dError):
         eng.feed(0, synthetic.synth_chunk(1, dims))                  # pageable host memory is refused
-    # ---- a scene fed from pinned host memory
-    os_env = __import__("os").environ
-    old = os_env.get("SIS3D_FEED_COPY")
-    os_env["SIS3D_FEED_COPY"] = copy
-    try:
-        res_chunks = [(c, (40.0 * (c % 2), 0.0, 32.0 * (c // 2)), synthetic.synth_chunk(20 + c, dims).cuda()) for c in range(8)]
-        host_chunks = [(c, o, p.cpu().contiguous().pin_memory()) for c, o, p in res_chunks]
-        for nfl, nch in ((3, 8), (4, 4)):                            # per-chunk launches with look-ahead; one chunk per pipeline (round graph)
-            runner = SceneRunner(net, dims, inflight=nfl)
-            recs, keep = runner.infer(res_chunks[:nch])
+    print("[parity] streamed inputs (%s): run_fed grid + sdf bit-identical to loaded chunks" % copy)
+
+
+@pytest.mark.parametrize("mailbox", ["1", "0"])
+def test_scene_from_pinned_host_chunks_equals_resident_scene(mailbox, monkeypatch):
+    """a whole scene whose chunks sit in PINNED HOST memory (per-chunk launches; one chunk per pipeline = the one-launch round;
+    lazy / pipelined results) gives the resident scene's records bit for bit -- through the mailbox engines (default) and through
+    engines without a mailbox (SIS3D_SCENE_MAILBOX=0: eager copies, the r4 path); pageable host chunks take the ordinary copy"""
+    from sis3d.scene import SceneRunner
+    monkeypatch.setenv("SIS3D_SCENE_MAILBOX", mailbox)
+    net, cfg = _small_net()
+    dims = (48, 24, 40)
+    res_chunks = [(c, (40.0 * (c % 2), 0.0, 32.0 * (c // 2)), synthetic.synth_chunk(20 + c, dims).cuda()) for c in range(8)]
+    host_chunks = [(c, o, p.cpu().contiguous().pin_memory()) for c, o, p in res_chunks]
+    pageable = [(c, o, p.cpu()) for c, o, p in res_chunks]
+    for nfl, nch in ((3, 8), (4, 4)):                                # per-chunk launches; one chunk per pipeline (round graph)
+        runner = SceneRunner(net, dims, inflight=nfl)
+        assert (runner.pipes.engines[0].mail is not None) == (mailbox == "1")
+        recs, keep = runner.infer(res_chunks[:nch])
+        for chunks in (host_chunks, pageable):
             for _ in range(2):
-                r2, k2 = runner.infer(host_chunks[:nch])
-                assert torch.equal(r2, recs) and torch.equal(k2, keep), (copy, nfl)
-            lz = []
-            for _ in range(3):
-                lz.append(runner.infer(host_chunks[:nch], lazy=True))
-                runner.prefetch(host_chunks[:nch])
-            for x in lz:
-                r3, k3 = x.resolve()
-                assert torch.equal(r3, recs) and torch.equal(k3, keep), (copy, nfl, "lazy")
-            torch.cuda.synchronize()
-    finally:
-        if old is None:
-            os_env.pop("SIS3D_FEED_COPY", None)
-        else:
-            os_env["SIS3D_FEED_COPY"] = old
-    print("[parity] streamed inputs (%s): run_fed grid + sdf bit-identical to loaded chunks; host-fed scenes bit-identical" % copy)
+                r2, k2 = runner.infer(chunks[:nch])
+                assert torch.equal(r2, recs) and torch.equal(k2, keep), (mailbox, nfl)
+        lz = [runner.infer(host_chunks[:nch], lazy=True) for _ in range(3)]
+        for x in lz:
+            r3, k3 = x.resolve()
+            assert torch.equal(r3, recs) and torch.equal(k3, keep), (mailbox, nfl, "lazy")
+        torch.cuda.synchronize()
+    print("[parity] host-fed scenes (mailbox %s): per-chunk, round graph and pipelined results bit-identical to the resident scene" % mailbox)
 
 
 def test_stream_window_calibration_keeps_results():
