@@ -55,7 +55,7 @@ def pooled_stream(role, index=0, device=None):
 
 class ChunkEngine:
     def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1,
-                 mask_boxes=0, shared_chip=False, brick_cap=0, mailbox=False, mail_input="grid", truncated=3.0):
+                 mask_boxes=0, shared_chip=False, brick_cap=0, mailbox=False, mail_input="grid", truncated=3.0, mail_ring=256):
         """stage: 'backbone' (the two pyramid levels only), 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect'
         (+ proposals, RoI pooling, classifier).
         from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
@@ -121,7 +121,7 @@ class ChunkEngine:
         if mailbox:
             if G != 1 or mail_input not in ("grid", "sdf"):
                 raise ops._lib.Sis3dError("mailbox engines: one chunk per graph, mail_input 'grid' or 'sdf'")
-            self.mail = ops.Mailbox(self.device)
+            self.mail = ops.Mailbox(self.device, ring=mail_ring)
             if mail_input == "sdf":
                 self._sdf_stage = torch.zeros(self.dims[0] * self.dims[1] * self.dims[2], device=self.device)
 

@@ -475,6 +475,42 @@ def test_scene_from_pinned_host_chunks_equals_resident_scene(mailbox, monkeypatc
     print("[parity] host-fed scenes (mailbox %s): per-chunk, round graph and pipelined results bit-identical to the resident scene" % mailbox)
 
 
+def test_mailbox_ring_wraps_and_never_laps_the_device():
+    """a mailbox of FOUR slots, 30 passes submitted back to back without a host sync: the producer waits for a free slot instead of
+    overwriting one the device has not read (progress word), every pass sees ITS chunk (device or pinned host source, origin, block
+    row), resident passes (src=None) leave the input alone"""
+    from sis3d.engine import ChunkEngine
+    net, cfg = _small_net()
+    dims = (48, 24, 40)
+    plain = ChunkEngine(net, dims=dims, stage="detect")
+    mbx = ChunkEngine(net, dims=dims, stage="detect", mailbox=True, mail_ring=4)
+    cids = [60 + k for k in range(5)]
+    grids = {c: synthetic.synth_chunk(c, dims) for c in cids}
+    plain.prepare()
+    want = {}
+    for c in cids:
+        plain.load(grids[c])
+        plain.set_origin((float(c), 0.0, 2.0 * c))
+        want[c] = plain.run()["block"].clone()
+    torch.cuda.synchronize()
+    mbx.prepare()
+    srcs = {c: (grids[c].contiguous().pin_memory() if c % 2 else grids[c].cuda()) for c in cids}
+    rows = torch.zeros(30, want[cids[0]].numel(), device="cuda")
+    for k in range(30):
+        c = cids[k % 5]
+        mbx.submit(src=srcs[c], block_dst=rows[k], origin=(float(c), 0.0, 2.0 * c))
+    torch.cuda.synchronize()
+    for k in range(30):
+        assert torch.equal(rows[k], want[cids[k % 5]]), k
+    mb = mbx.mail
+    assert mb.ring_size == 4 and mb.head == int(mb.progress[0]) >= 30
+    # a resident pass: no source in the slot, the static input keeps the last chunk; no destination: nothing is written
+    before = rows.clone()
+    out = mbx.submit(src=None, block_dst=None, origin=(float(cids[4]), 0.0, 2.0 * cids[4]))
+    torch.cuda.synchronize()
+    assert torch.equal(out["block"], want[cids[4]]) and torch.equal(rows, before)
+
+
 def test_stream_window_calibration_keeps_results():
     """PipelinedEngines.calibrate / SceneRunner.calibrate move the pipelines onto other streams of the pool: same graphs, same results"""
     from sis3d.scene import SceneRunner
