@@ -377,6 +377,16 @@ for _ in range(3):
     r, k = runner.infer(chunks)
     assert torch.equal(r, want_r) and torch.equal(k, want_k)
 assert calls == [(1, 4, parallel.block_floats(runner.k_rows))] * 3, calls
+# r5: the PIPELINED path (infer(lazy=True)): join, the collective and the merge are enqueued on the merge stream, three scenes in
+# flight before the first length is read -- the same all_gather_into_tensor, on a stream that is not the caller's
+lz = [runner.infer(chunks, lazy=True) for _ in range(3)]
+for x in lz:
+    r, k = x.resolve()
+    assert torch.equal(r, want_r) and torch.equal(k, want_k)
+assert len(calls) == 6 and calls[-1] == (1, 4, parallel.block_floats(runner.k_rows)), calls
+host = [(c, o, p.cpu().contiguous().pin_memory()) for c, o, p in chunks]
+r, k = runner.infer(host, lazy=True).resolve()
+assert torch.equal(r, want_r) and torch.equal(k, want_k)
 torch.cuda.synchronize(); dist.destroy_process_group()
 print("RCCL_WORLD1_OK", len(calls), tuple(want_r.shape), int(want_k.numel()))
 ''' % ([p for p in sys.path if p],))
@@ -386,9 +396,9 @@ print("RCCL_WORLD1_OK", len(calls), tuple(want_r.shape), int(want_k.numel()))
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script), str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert p.returncode == 0 and "RCCL_WORLD1_OK 3" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert p.returncode == 0 and "RCCL_WORLD1_OK 7" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
     from parity import report
-    report("RCCL world-of-one: gather_blocks' nccl branch ran 3 scenes, %s" % p.stdout.strip().splitlines()[-1])
+    report("RCCL world-of-one: gather_blocks' nccl branch ran 3 eager + 3 pipelined + 1 host-fed scenes, %s" % p.stdout.strip().splitlines()[-1])
 
 
 @pytest.mark.parametrize("copy", ["mailbox", "kernel", "own", "per_pipeline"])
