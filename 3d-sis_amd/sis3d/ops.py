@@ -382,8 +382,14 @@ class Mailbox(object):
     def write(self, src=None, dst=None, origin=None):
         """the slot of the NEXT pass: src = tensor to copy into the pipeline's input (pinned host or device memory; None: the input
         buffer already holds the chunk), dst = tensor that receives the pass's record block (None: nowhere), origin = (x, y, z)"""
-        while self.head - int(self.progress[0]) >= self.ring_size - 1:
-            pass                                       # the producer is a whole ring ahead of the device: wait for a slot (rare)
+        if self.head - int(self.progress[0]) >= self.ring_size - 1:
+            # the producer is a whole ring ahead of the device: wait for a slot (rare); a device that never consumes is an error
+            import time
+            t_end = time.monotonic() + 60.0
+            while self.head - int(self.progress[0]) >= self.ring_size - 1:
+                if time.monotonic() > t_end:
+                    raise _lib.Sis3dError("mailbox: the device has not consumed a slot for 60 s (%d written, %d consumed)"
+                                          % (self.head, int(self.progress[0])))
         k = self.head % self.ring_size
         self.u64[k, 0] = src.data_ptr() if src is not None else 0
         self.u64[k, 1] = dst.data_ptr() if dst is not None else 0

@@ -482,7 +482,13 @@ def test_scene_from_pinned_host_chunks_equals_resident_scene(mailbox, monkeypatc
             r3, k3 = x.resolve()
             assert torch.equal(r3, recs) and torch.equal(k3, keep), (mailbox, nfl, "lazy")
         torch.cuda.synchronize()
-    print("[parity] host-fed scenes (mailbox %s): per-chunk, round graph and pipelined results bit-identical to the resident scene" % mailbox)
+    # without captured graphs (use_graph=False) the same launches go out eagerly -- the mailbox kernels included -- same records
+    eager = SceneRunner(net, dims, inflight=2, use_graph=False)
+    recs8, keep8 = SceneRunner(net, dims, inflight=3).infer(res_chunks)
+    for chunks in (res_chunks, host_chunks):
+        r5, k5 = eager.infer(chunks)
+        assert torch.equal(r5, recs8) and torch.equal(k5, keep8), (mailbox, "eager")
+    print("[parity] host-fed scenes (mailbox %s): per-chunk, round graph, pipelined and eager results bit-identical to the resident scene" % mailbox)
 
 
 def test_mailbox_ring_wraps_and_never_laps_the_device():
