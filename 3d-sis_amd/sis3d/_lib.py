@@ -41,6 +41,10 @@ SIGNATURES = {
     "sis3d_proposal_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_topk_desc": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "sis3d_pack_records": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    "sis3d_pack_records_post": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                        c_vp, c_vp]),
+    "sis3d_proposal_decode2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32,
+                                       c_vp, c_vp, c_vp, c_vp]),
     "sis3d_softmax2": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "sis3d_classifier_workspace_floats": (c_sz, [c_int, c_int, c_int]),
     "sis3d_classifier_forward": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp,

@@ -144,7 +144,7 @@ class ChunkEngine:
 
     def _finish(self, d, g):
         """pack one chunk's detections: records + the fixed-size block in scene coordinates (one kernel)"""
-        d["records"], d["block"] = ops.pack_records(d, self.dims, self.origins[g])
+        d["records"], d["block"] = ops.pack_records(d, self.dims, self.origins[g], mail=self.mail if self.mask_plan is None else None)
         return d
 
     def _mail_commit(self):
@@ -163,7 +163,7 @@ class ChunkEngine:
                 else:
                     ops.mail_upload(self.mail, self.scenes[0], self.origins[0])
             out = self._step_body()
-            if self.mail is not None:
+            if self.mail is not None and not (isinstance(out, dict) and out.pop("_mail_posted", False)):
                 ops.mail_post(self.mail, out["block"] if isinstance(out, dict) and "block" in out else None)
             return out
 

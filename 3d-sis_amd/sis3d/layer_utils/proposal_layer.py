@@ -54,14 +54,19 @@ class ProposalEngine:
         boxes = torch.empty(M, 6, device=device)
         scores = torch.empty(M, device=device)
         lvl = torch.empty(M, device=device)
-        off = 0
-        for (lid, prob, bbox, _), (anc, inside) in zip(levels, tabs):
-            n = int(inside.numel())
+        for lid, prob, bbox, _ in levels:
             if not prob.is_contiguous() or not bbox.is_contiguous():
                 raise ops._lib.Sis3dError("rpn maps must be contiguous (1,2,X,Y,Z,A) / (1,X,Y,Z,6A)")
-            prob_fg = prob[0, 1]
-            ops.proposal_decode(anc, bbox, prob_fg, inside, dims, lid, boxes[off:off + n], scores[off:off + n], lvl[off:off + n])
-            off += n
+        if len(levels) == 2:
+            # r5: both levels in one launch (a kernel boundary costs a pipeline a wait for a free CU when several chunks are in flight)
+            (l1, p1, b1, _), (l2, p2, b2, _) = levels
+            ops.proposal_decode2(tabs[0][0], b1, p1[0, 1], tabs[0][1], l1, tabs[1][0], b2, p2[0, 1], tabs[1][1], l2, dims, boxes, scores, lvl)
+        else:
+            off = 0
+            for (lid, prob, bbox, _), (anc, inside) in zip(levels, tabs):
+                n = int(inside.numel())
+                ops.proposal_decode(anc, bbox, prob[0, 1], inside, dims, lid, boxes[off:off + n], scores[off:off + n], lvl[off:off + n])
+                off += n
         # stable descending sort: the tie rule pinned in the oracle (SURVEY.md 7 'Sort tie order')
         n_pre = min(pre_n, M) if pre_n > 0 else M
         if 0 < n_pre <= 1024 and M <= 40960:

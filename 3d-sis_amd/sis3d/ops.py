@@ -462,17 +462,35 @@ def proposal_decode(anchors, deltas, prob_fg, inside, dims, level_id, out_boxes,
                                       _stream()), "sis3d_proposal_decode")
 
 
+def proposal_decode2(a1, d1, p1, in1, lid1, a2, d2, p2, in2, lid2, dims, out_boxes, out_scores, out_levels):
+    """both pyramid levels in one launch (sis3d_proposal_decode2): level 1 -> rows [0, n1), level 2 -> rows [n1, n1 + n2)"""
+    n1, n2 = int(in1.numel()), int(in2.numel())
+    check(lib().sis3d_proposal_decode2(_ptr(a1), _ptr(d1), _ptr(p1), _ptr(in1), n1, float(lid1), _ptr(a2), _ptr(d2), _ptr(p2), _ptr(in2),
+                                       n2, float(lid2), float(dims[0]), float(dims[1]), float(dims[2]), _ptr(out_boxes), _ptr(out_scores),
+                                       _ptr(out_levels), _stream()), "sis3d_proposal_decode2")
+
+
 RECORD_WIDTH = 16
 
 
-def pack_records(d, dims, origin=None, want_block=True):
-    """detect() output dict -> (records (K,16), block (1+16K) | None): sis3d_pack_records (include/sis3d.h)"""
+def pack_records(d, dims, origin=None, want_block=True, mail=None):
+    """detect() output dict -> (records (K,16), block (1+16K) | None): sis3d_pack_records (include/sis3d.h).
+    mail (an ops.Mailbox; needs want_block and K <= 256): the launch is also the LAST node of a mailbox pipeline
+    (sis3d_pack_records_post): the block goes to the slot's destination row and the slot is consumed -> `d["_mail_posted"]` = True"""
     rois = d["rois"].contiguous()
     K = rois.shape[0]
     rec = torch.empty(K, RECORD_WIDTH, device=rois.device)
     blk = torch.empty(1 + K * RECORD_WIDTH, device=rois.device) if want_block else None
     has = "cls_pred" in d
     NC = d["cls_prob"].shape[1] if has else 0
+    if mail is not None and want_block and K <= 256:
+        check(lib().sis3d_pack_records_post(_ptr(rois), _ptr(d["scores"].contiguous()), _ptr(d["levels"].contiguous()),
+                                            _ptr(d["cls_pred"].contiguous()) if has else None, _ptr(d["cls_prob"].contiguous()) if has else None,
+                                            _ptr(d["bbox_pred"].contiguous()) if has else None, _ptr(d["num"]), _ptr(origin), K, NC,
+                                            float(dims[0]), float(dims[1]), float(dims[2]), _ptr(rec), _ptr(blk), _ptr(mail.state),
+                                            _ptr(mail._progress_t), _stream()), "sis3d_pack_records_post")
+        d["_mail_posted"] = True
+        return rec, blk
     check(lib().sis3d_pack_records(_ptr(rois), _ptr(d["scores"].contiguous()), _ptr(d["levels"].contiguous()),
                                    _ptr(d["cls_pred"].contiguous()) if has else None, _ptr(d["cls_prob"].contiguous()) if has else None,
                                    _ptr(d["bbox_pred"].contiguous()) if has else None, _ptr(d["num"]), _ptr(origin), K, NC,

@@ -943,7 +943,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     steps = steps or args.steps
     # late reads only where a scene is ONE graph launch (a share of <= 4 chunks, one per pipeline); with tens of per-chunk graph
     # launches per scene, letting the host run a whole scene ahead was measured slower (10.2 vs 8.65 ms for the 32-chunk scene)
-    lazy = not args.masks and n_local == nfl and not args.no_graph
+    lazy = not args.masks and not args.no_graph and (n_local == nfl or os.environ.get("SIS3D_BENCH_SCENE_LAZY", "0") == "1")
     if lazy:
         runner.prepare_round()              # the one-launch round graph is captured here, not inside the first timed / pipelined call
     if not args.no_calibrate and not args.no_graph and not args.masks and runner.calibration is None and not streamed:

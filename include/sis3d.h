@@ -213,6 +213,12 @@ int sis3d_mail_post(uint32_t *state, const float *block_src, int64_t n, uint64_t
 int sis3d_proposal_decode(const float *anchors, const float *deltas, const float *prob_fg, const int32_t *inside,
                           int n_inside, float dim_x, float dim_y, float dim_z, float level_id, float *out_boxes,
                           float *out_scores, float *out_levels, sis3d_stream_t stream);
+/* both pyramid levels in ONE launch (r5): level 1 -> rows [0, n1), level 2 -> rows [n1, n1 + n2) of the outputs: exactly what two calls
+ * of sis3d_proposal_decode into the two slices write. */
+int sis3d_proposal_decode2(const float *anchors1, const float *deltas1, const float *prob_fg1, const int32_t *inside1, int n1,
+                           float level1, const float *anchors2, const float *deltas2, const float *prob_fg2, const int32_t *inside2,
+                           int n2, float level2, float dim_x, float dim_y, float dim_z, float *out_boxes, float *out_scores,
+                           float *out_levels, sis3d_stream_t stream);
 /* Replaces `scores.sort(descending=True)` + `[:pre_nms_topN]` (proposal_layer.py:181-186): the k (<= 1024) largest
  * of scores [n] in descending order, ties by ascending index (== torch.sort(stable=True, descending=True)[:k]).
  * out_scores [k], out_idx [k] int64.  One launch (radix select + bitonic sort in LDS); k > n is clamped to n;
@@ -229,6 +235,13 @@ int sis3d_topk_desc(const float *scores, int n, int k, float *out_scores, int64_
 int sis3d_pack_records(const float *rois, const float *scores, const float *levels, const int64_t *cls_pred, const float *cls_prob,
                        const float *bbox_pred, const int32_t *num, const float *origin, int K, int NC, float dim_x, float dim_y,
                        float dim_z, float *records, float *block, sis3d_stream_t stream);
+/* the same + sis3d_mail_post in one launch (r5; K <= 256, `block` required): the last node of a mailbox pipeline's detection graph --
+ * the finished block goes to the fetched slot's destination row and the slot is consumed.  SIS3D_EUNSUPPORTED for K > 256 (the caller
+ * launches sis3d_pack_records and sis3d_mail_post). */
+int sis3d_pack_records_post(const float *rois, const float *scores, const float *levels, const int64_t *cls_pred, const float *cls_prob,
+                            const float *bbox_pred, const int32_t *num, const float *origin, int K, int NC, float dim_x, float dim_y,
+                            float dim_z, float *records, float *block, uint32_t *mail_state, uint64_t *mail_progress_host_mapped,
+                            sis3d_stream_t stream);
 /* softmax over dim 1 of (1,2,...) score maps (network.py:546): n = elements per class plane */
 int sis3d_softmax2(const float *score, float *prob, int64_t n, sis3d_stream_t stream);
 
