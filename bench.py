@@ -941,10 +941,12 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         chunks.append((c, scene_origin(c, args.scene_stride), payload))
     torch.cuda.synchronize()
     steps = steps or args.steps
-    # late reads only where a scene is ONE graph launch (a share of <= 4 chunks, one per pipeline); with tens of per-chunk graph
-    # launches per scene, letting the host run a whole scene ahead was measured slower (10.2 vs 8.65 ms for the 32-chunk scene)
-    lazy = not args.masks and not args.no_graph and (n_local == nfl or os.environ.get("SIS3D_BENCH_SCENE_LAZY", "0") == "1")
-    if lazy:
+    # results are read one scene LATE (SceneRunner.infer(lazy=True): join, gather and merge of scene k on the merge stream, scene k + 1's
+    # chunks already enqueued).  r4 measured this slower for the 32-chunk scene (10.2 vs 8.65 ms: the host ran a scene ahead and hit the
+    # runtime's blocking enqueue behind unfinished graph launches); with the mailbox engines of r5 a chunk is one graph launch and the
+    # pipelined form wins there too (7.19 vs 7.48 ms, SIS3D_BENCH_SCENE_LAZY=0 restores the eager reads for shares of > 1 chunk per pipeline)
+    lazy = not args.masks and not args.no_graph and (n_local == nfl or os.environ.get("SIS3D_BENCH_SCENE_LAZY", "1") == "1")
+    if lazy and n_local == nfl:
         runner.prepare_round()              # the one-launch round graph is captured here, not inside the first timed / pipelined call
     if not args.no_calibrate and not args.no_graph and not args.masks and runner.calibration is None and not streamed:
         runner.infer(chunks, gathered=gathered)
@@ -972,7 +974,8 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     recs, keep = res[0], res[1]
     extra = {"scene_chunks": n_chunks, "scene_stride": args.scene_stride, "chunks_on_this_rank": n_local, "streams_per_gpu": nfl,
              "records_gathered": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel()),
-             "one_graph_launch_per_scene": runner._round is not None and runner._use_round}
+             "one_graph_launch_per_scene": runner._round is not None and runner._use_round and n_local == nfl,
+             "results_read_one_scene_late": bool(lazy)}
     if runner.calibration:
         extra["calibration"] = runner.calibration
     if args.masks:
