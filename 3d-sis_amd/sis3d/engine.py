@@ -429,9 +429,10 @@ class PipelinedEngines:
                           event handshake; the upload of chunk k + 1 sits behind the replay of chunk k in stream order, i.e. a
                           pipeline pauses for its own upload (71 us for 3.54 MB at the measured 50 GB/s) while the other pipelines
                           keep the chip busy;
-          'per_pipeline'  on a copy stream of the pipeline's own, double-buffered: the upload of chunk k + 1 runs under chunk k;
-          'shared'        one copy stream for all pipelines (measured: the handshakes of four pipelines on one stream serialise
-                          them -- 0.77 -> 1.13 ms per step before a single byte is copied; kept for the A/B).
+          'per_pipeline'  on a copy stream of the pipeline's own, double-buffered: the upload of chunk k + 1 runs under chunk k
+                          (nine live streams on eight hardware queues: measured slower, kept as a tested A/B).
+        (ONE copy stream shared by all pipelines was measured too -- its event handshakes serialise the pipelines, 0.77 -> 1.13 ms per
+        step before a single byte is copied, profiles/r05_stream_probe.txt -- and is not offered.)
         Measured (profiles/r05_stream_probe.txt, four backbone + RPN pipelines, ms per step): resident 0.770, own 0.831,
         per_pipeline 0.829, shared 1.38."""
         if mode not in ("grid", "sdf"):
@@ -444,8 +445,8 @@ class PipelinedEngines:
             self._feed_mode, self._feed_copy = mode, "mailbox"
             self._mail_q = [[] for _ in self.engines]
             return self
-        if copy not in ("kernel", "own", "per_pipeline", "shared"):
-            raise ValueError("copy must be 'kernel', 'own', 'per_pipeline' or 'shared'")
+        if copy not in ("kernel", "own", "per_pipeline"):
+            raise ValueError("copy must be 'kernel', 'own' or 'per_pipeline'")
         if any(e.group != 1 or e.use_images for e in self.engines):
             raise ops._lib.Sis3dError("streamed inputs: geometry-only engines of one chunk per graph")
         torch.cuda.synchronize()
@@ -458,7 +459,7 @@ class PipelinedEngines:
             # encode kernel reads (an encode that reads the host block itself puts a link-bound wave on every CU: measured slower)
             direct = mode == "grid" and copy in ("kernel", "own")
             nbuf = 1 if copy in ("own", "kernel") else 2
-            cs = self.streams[i] if copy in ("own", "kernel") else pooled_stream("copy", i if copy == "per_pipeline" else 0)
+            cs = self.streams[i] if copy in ("own", "kernel") else pooled_stream("copy", i)
             self._feed.append({"stage": [e.scenes[0]] if direct else [torch.empty(shape, device=e.device) for _ in range(nbuf)],
                                "direct": direct, "nbuf": nbuf, "stream": cs,
                                "ready": [torch.cuda.Event() for _ in range(nbuf)], "free": [torch.cuda.Event() for _ in range(nbuf)],
