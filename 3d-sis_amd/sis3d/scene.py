@@ -16,6 +16,9 @@ import os as _os
 ROUND_STAGGER = _os.environ.get("SIS3D_ROUND_STAGGER", "0") != "0"
 # lazy results: join + gather + whole-scene merge on their own stream, scenes overlap (A/B switch; on by default since r5)
 MERGE_STREAM = _os.environ.get("SIS3D_MERGE_STREAM", "1") != "0"
+# ... on the last pipeline's stream (default) or on a dedicated fifth stream (SIS3D_MERGE_ON_PIPELINE=0: faster when that stream happens to
+# land on a good hardware queue, 60 % slower when it does not)
+MERGE_ON_PIPELINE = _os.environ.get("SIS3D_MERGE_ON_PIPELINE", "1") != "0"
 
 
 def fused_merge(blocks, k_rows, thresh, score_col, box_col, max_keep):
@@ -179,12 +182,13 @@ class SceneRunner:
                     send[j].copy_(out["block"], non_blocking=True)     # out of the graph's static buffer before its next replay
             if post is not None:
                 for st in self.pipes.streams:
-                    post.wait_stream(st)
+                    if st is not post:
+                        post.wait_stream(st)
             else:
                 self.pipes.join()
         return send[:len(mine)]
 
-    def calibrate(self, chunks, group=None, reps=2, count=16, gathered=None):
+    def calibrate(self, chunks, group=None, reps=2, count=16, gathered=None, lazy=False):
         """choose the pipelines' streams -- and, for a share of exactly one chunk per pipeline, between the one-launch round graph
         and per-chunk launches -- by timing infer() on `chunks` (PipelinedEngines.calibrate; one-time cost: ~13 x 3 scenes).
         -> dict describing the choice"""
@@ -192,9 +196,18 @@ class SceneRunner:
         use_round_saved = self._use_round
         self._use_round = False
 
+        pending = []
+
         def once():
-            self.infer(chunks, group=group, gathered=gathered)
+            # the caller's mode: lazy results are resolved one scene late, as a pipelined consumer does
+            r = self.infer(chunks, group=group, gathered=gathered, lazy=lazy)
+            if lazy:
+                pending.append(r)
+                if len(pending) > 1:
+                    pending.pop(0).resolve()
         best, times = self.pipes.calibrate(once, reps=reps, warm=1, count=count)
+        while pending:
+            pending.pop(0).resolve()
         out = {"stream_window": best, "ms_per_scene_by_window": {str(k): round(v, 3) for k, v in times.items()}}
         self._use_round = use_round_saved
         rank, world = self._rank_world(group)
@@ -273,9 +286,15 @@ class SceneRunner:
         ONE collective), whole-scene merge -- is enqueued on the merge stream, ordered behind the pipelines only.  The current stream
         carries nothing of a scene, so scene k + 1's chunks do not wait for scene k's slowest pipeline, gather or merge: consecutive
         scenes overlap on the chip."""
-        if self._merge_stream is None:
-            self._merge_stream = pooled_stream("merge", 0)
-        ms = self._merge_stream
+        if MERGE_ON_PIPELINE:
+            # the scene's serial part rides on the LAST pipeline's stream (that pipeline's next chunk queues ~85 us behind it): a fifth
+            # stream that carries kernels while four pipelines run is at the mercy of the stream -> hardware-queue placement (measured:
+            # the same scene 7.2 or 12.0 ms depending on where a dedicated merge stream landed), four streams are what the chip serves
+            ms = self.pipes.streams[-1]
+        else:
+            if self._merge_stream is None:
+                self._merge_stream = pooled_stream("merge", 0)
+            ms = self._merge_stream
         n_chunks = len(chunks)
         with torch.no_grad():
             ms.wait_stream(torch.cuda.current_stream())        # `gathered` / process-group state produced on the caller's stream
@@ -307,10 +326,15 @@ class SceneRunner:
         the table, already resolved otherwise (with_masks, > 8192 rows, CPU tables) -- whose resolve() gives the eager tuple."""
         thresh = float(self.net.cfg.TEST.RPN_NMS_THRESH) if thresh is None else thresh
         n_chunks = len(chunks)
-        pipelined = (lazy and MERGE_STREAM and not with_masks and n_chunks * self.k_rows <= 8192
+        # every table the fused merge serves takes the pipelined path -- also for eager callers, who resolve at once: nothing of a scene
+        # is enqueued on the caller's (usually the null) stream, whose hardware queue the pipelines may share (r5: with the serial part
+        # on the null stream the same scene took 7.5 or 12 ms depending on the pipelines' stream window; on the pipelined path 10 of 13
+        # windows are within 3 % of the best)
+        pipelined = (MERGE_STREAM and not with_masks and n_chunks * self.k_rows <= 8192
                      and self.pipes.engines[0].device.type == "cuda")
         if pipelined:
-            return self._infer_pipelined(chunks, thresh, group, max_keep, gathered)
+            r = self._infer_pipelined(chunks, thresh, group, max_keep, gathered)
+            return r if lazy else r.resolve()
         with torch.no_grad():
             local = self.run_chunks(chunks, group)
             if gathered is not None:

@@ -950,7 +950,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
         runner.prepare_round()              # the one-launch round graph is captured here, not inside the first timed / pipelined call
     if not args.no_calibrate and not args.no_graph and not args.masks and runner.calibration is None and not streamed:
         runner.infer(chunks, gathered=gathered)
-        runner.calibrate(chunks, gathered=gathered)
+        runner.calibrate(chunks, gathered=gathered, lazy=lazy)
 
     def one():
         return runner.infer(chunks, with_masks=args.masks, gathered=gathered, lazy=lazy)

@@ -18,7 +18,8 @@ from sis3d.scene import SceneRunner  # noqa: E402
 
 def main():
     import sis3d.scene as _sc
-    print("WAIT_PER_CHUNK", _sc.WAIT_PER_CHUNK)
+    print("scene serial part: %s" % ("pipelined path, on the last pipeline's stream" if _sc.MERGE_STREAM and _sc.MERGE_ON_PIPELINE else
+                                      "pipelined path, dedicated merge stream" if _sc.MERGE_STREAM else "on the caller's (null) stream"))
     torch.cuda.init()
     pool = [torch.cuda.Stream() for _ in range(32)]
     assert len({s.cuda_stream for s in pool}) == 32
