@@ -388,11 +388,19 @@ class PipelinedEngines:
                 # library, not a process-wide switch toggled around the captures)
                 self.engines.append(ChunkEngine(net, shared_chip=(n >= 2), brick_cap=cap, **kw))
 
-    def prepare(self, warmup=2):
+    def prepare(self, warmup=2, calibrate=None):
+        """warm up and capture every pipeline, then (calibrate: default on for >= 2 captured pipelines, SIS3D_NO_AUTO_CALIBRATE=1 turns
+        it off) choose the pipelines' streams by timing one pass of all pipelines on every window of the candidate streams -- ~40
+        replays, tens of milliseconds; a caller with a more specific workload calls `calibrate(run_once)` again"""
         for e, s in zip(self.engines, self.streams):
             with torch.cuda.stream(s):
                 e.prepare(warmup)
         torch.cuda.synchronize()
+        if calibrate is None:
+            import os
+            calibrate = os.environ.get("SIS3D_NO_AUTO_CALIBRATE", "0") in ("", "0")
+        if calibrate and len(self.engines) >= 2 and all(e.graph is not None for e in self.engines):
+            self.calibrate(self.run, reps=3, warm=1)
         return self
 
     def load(self, i, *a, wait=True, **kw):

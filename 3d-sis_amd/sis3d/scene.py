@@ -62,7 +62,7 @@ class SceneResult(object):
 
 
 class SceneRunner:
-    def __init__(self, net, dims, use_graph=True, inflight=3, solo=False, emulate=None):
+    def __init__(self, net, dims, use_graph=True, inflight=3, solo=False, emulate=None, round_graph=False):
         """solo: behave as a world of one even when a process group exists (the 1-GPU reference point bench.py takes on
         rank 0 inside an N-rank run); no collective is issued.
         emulate = (rank, world): shard the scene as that rank of that world WITHOUT a process group (implies solo); together with
@@ -83,7 +83,10 @@ class SceneRunner:
         self._round_ok, self._round_error = True, None
         self._merge_stream = None
         self._sends, self._consumed, self._scene_no, self._send_slot = [None, None], [None, None, None], 0, 0
-        self._use_round = True          # calibrate() may find per-chunk launches on well-placed streams faster than the round graph
+        # round_graph: a share of exactly one chunk per pipeline as ONE graph launch (PipelinedEngines.capture_round).  r4's default; since
+        # r5 per-chunk launches are (a chunk is one call, the streams are placed by measurement: 0.98 against 1.06 ms for a rank's share at
+        # N = 8) and the round graph is what calibrate() may still choose when it measures faster
+        self._use_round = bool(round_graph)
         self.calibration = None
 
     def mask_fn(self, payload, windows, classes, values=False):

@@ -319,7 +319,7 @@ def test_round_graph_lazy_result_and_emulated_rank_share():
     base = SceneRunner(net, dims, inflight=3)                    # 4 chunks on 3 pipelines: the per-chunk replays
     recs, keep = base.infer(chunks)
     assert recs.shape[0] > 0 and keep.numel() < recs.shape[0]    # the whole-scene NMS really suppresses across chunks
-    rnd = SceneRunner(net, dims, inflight=4)
+    rnd = SceneRunner(net, dims, inflight=4, round_graph=True)
     for _ in range(3):
         r2, k2 = rnd.infer(chunks)
         assert rnd._round is not None
@@ -332,7 +332,7 @@ def test_round_graph_lazy_result_and_emulated_rank_share():
     # (c) the gathered table of the whole scene, then each emulated rank of a world of 2 on its own two chunks
     table = parallel.gather_blocks(base.run_chunks(chunks), 4, base.k_rows, solo=True).clone()
     for r in range(2):
-        share = SceneRunner(net, dims, inflight=2, emulate=(r, 2))
+        share = SceneRunner(net, dims, inflight=2, emulate=(r, 2), round_graph=True)
         stale = table.clone()
         stale[r::2] = 0                                          # this rank's rows must come from its own fresh pass
         only_mine = [(c, o, p if c % 2 == r else None) for c, o, p in chunks]
@@ -470,7 +470,7 @@ def test_scene_from_pinned_host_chunks_equals_resident_scene(mailbox, monkeypatc
     host_chunks = [(c, o, p.cpu().contiguous().pin_memory()) for c, o, p in res_chunks]
     pageable = [(c, o, p.cpu()) for c, o, p in res_chunks]
     for nfl, nch in ((3, 8), (4, 4)):                                # per-chunk launches; one chunk per pipeline (round graph)
-        runner = SceneRunner(net, dims, inflight=nfl)
+        runner = SceneRunner(net, dims, inflight=nfl, round_graph=(nch == nfl))
         assert (runner.pipes.engines[0].mail is not None) == (mailbox == "1")
         recs, keep = runner.infer(res_chunks[:nch])
         for chunks in (host_chunks, pageable):
