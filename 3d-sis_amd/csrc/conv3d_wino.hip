@@ -124,6 +124,14 @@ struct WinoArgs {
     const float *w1n, *b1n;    // next conv1: pw16-packed [C2N/16][C3/16][64][4], bias
     float *out2;
     int out2_stride;
+    // r5 -- PIGGYBACK upload (template PIGGY; sis3d_conv3d_k3wino_piggyback): the launch has one more ROW of workgroups than it has
+    // problems (blockIdx.y == pig_row).  That row does not convolve: its first eight workgroups pull the pipeline's NEXT chunk (its
+    // address sits in the mailbox slot the graph's first node fetched: pig_state[16..17], include/sis3d.h) into pig_dst while the real
+    // workgroups compute, the others leave at once
+    unsigned *pig_state;
+    float *pig_dst;
+    long long pig_n4;
+    int pig_row;
 };
 
 // OFF: immediate byte offset of the instruction, added to BOTH the global and the LDS address (< 4096)
@@ -725,10 +733,35 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     }
 }
 
-template <int NC, int C3 = 0, int C2N = 0, bool MINI = false, int WC = 1>
+typedef float pig4 __attribute__((ext_vector_type(4)));
+
+template <int NC, int C3 = 0, int C2N = 0, bool MINI = false, int WC = 1, bool PIGGY = false>
 __global__ __launch_bounds__(NTHR * WC, 1) void conv3d_k3wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if constexpr (PIGGY) {
+        if ((int)blockIdx.y == a.pig_row) {
+            if (blockIdx.x >= 8) return;
+            const unsigned long long sp = *reinterpret_cast<const unsigned long long *>(a.pig_state + 16);     // MailSlot.next_src
+            // state[24..25]: whose chunk pig_dst holds when this launch has ended (0: nobody's)
+            if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned long long *>(a.pig_state + 24) = sp;
+            const pig4 *src = reinterpret_cast<const pig4 *>(sp);
+            if (!src) return;
+            pig4 *dst = reinterpret_cast<pig4 *>(a.pig_dst);
+            constexpr int U = 8;
+            const int64_t stride = (int64_t)8 * blockDim.x;
+            int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            for (; i + (U - 1) * stride < a.pig_n4; i += U * stride) {
+                pig4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+                for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+            }
+            for (; i < a.pig_n4; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+            return;
+        }
+    }
     // work list: cout group major, block minor; every XCD (block b runs on XCD b % 8, private L2) takes one contiguous range
     // of it, i.e. few cout groups x all blocks: its L2 holds 1/8 of U (8.4 MB for rpn_net) and the whole activation map
     int wid;
@@ -865,23 +898,31 @@ extern "C" int sis3d_conv3d_k3wino_prefer(int X, int Y, int Z, int cin, int cout
     return nprob >= 1 && wino_nc(X, Y, Z, cin, cout, shared_chip != 0) > 0 ? 1 : 0;
 }
 
-template <int NC, int C3, int C2N, bool MINI = false, int WC = 1>
+template <int NC, int C3, int C2N, bool MINI = false, int WC = 1, bool PIGGY = false>
 static int launch_wino_inst(const WinoArgs &a, int64_t nwg, int nprob, hipStream_t st)
 {
     constexpr size_t lds = (size_t)lds_floats_g<MINI>(NC * WC) * sizeof(float);
     static Sis3dLdsOnce once;                                       // once per instantiation AND device
-    auto kern = conv3d_k3wino_kernel<NC, C3, C2N, MINI, WC>;
+    auto kern = conv3d_k3wino_kernel<NC, C3, C2N, MINI, WC, PIGGY>;
     if (sis3d_grant_lds(once, (const void *)kern, (int)lds) != SIS3D_OK) return SIS3D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nprob), dim3(NTHR * WC), lds, st, a);
     return sis3d_check_launch();
 }
 
 // nc = cout tiles per WAVE, wc = waves along cout (cout tiles per workgroup = nc wc)
-static int launch_wino(WinoArgs &a, int nc, int wc, int64_t nwg, int nprob, hipStream_t st)
+static int launch_wino(WinoArgs &a, int nc, int wc, int64_t nwg, int nprob, hipStream_t st, unsigned *pig_state = nullptr,
+                       float *pig_dst = nullptr, long long pig_n4 = 0)
 {
     if (nwg <= 0 || nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     a.w3p = a.b3 = a.res = a.w1n = a.b1n = nullptr; a.tout = a.out2 = nullptr;
     a.res_stride = a.tout_stride = a.tout_coff = a.out2_stride = 0;
+    a.pig_state = pig_state; a.pig_dst = pig_dst; a.pig_n4 = pig_n4; a.pig_row = -1;
+    if (pig_state) {
+        // one more row of workgroups carries the upload; only the two-cout-tile form of the plain conv has the branch
+        if (nc != 2 || wc != 1 || nwg < 8) return SIS3D_EUNSUPPORTED;
+        a.pig_row = nprob;
+        return launch_wino_inst<2, 0, 0, false, 1, true>(a, nwg, nprob + 1, st);
+    }
 #ifdef WN_WC2_EXPERIMENT    // measured and left out of the library (r4): 56.5 us against 52.3 on rpn_net, bit-identical output -- see wino_wave
     if (wc == 2) return nc == 1 ? launch_wino_inst<1, 0, 0, false, 2>(a, nwg, nprob, st) : SIS3D_EUNSUPPORTED;
 #else
@@ -890,9 +931,9 @@ static int launch_wino(WinoArgs &a, int nc, int wc, int64_t nwg, int nprob, hipS
     return nc == 2 ? launch_wino_inst<2, 0, 0>(a, nwg, nprob, st) : launch_wino_inst<1, 0, 0>(a, nwg, nprob, st);
 }
 
-extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
-                                   const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
-                                   int out_stride, int out_coff, sis3d_stream_t stream)
+static int conv3d_k3wino_impl(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                              const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                              int out_stride, int out_coff, unsigned *pig_state, float *pig_dst, long long pig_n4, sis3d_stream_t stream)
 {
     if (nprob < 1 || nprob > WN_MAXP || !ins || !packed_ws || !outs) return SIS3D_EINVAL;
     if (X <= 0 || Y <= 0 || Z <= 0 || cin <= 0 || cout <= 0 || cin_stride < cin || (cin_stride % 4)) return SIS3D_EINVAL;
@@ -920,7 +961,26 @@ extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, in
     a.flags = flags; a.out_stride = out_stride; a.out_coff = out_coff;
     a.nbx = cdiv(X, VX); a.nby = cdiv(Y, VY); a.nbz = cdiv(Z, VZ);
     a.rag = nullptr; a.nrag = 0;
-    return launch_wino(a, nc, wc, (int64_t)a.nbx * a.nby * a.nbz * a.ngroups, nprob, as_stream(stream));
+    return launch_wino(a, nc, wc, (int64_t)a.nbx * a.nby * a.nbz * a.ngroups, nprob, as_stream(stream), pig_state, pig_dst, pig_n4);
+}
+
+extern "C" int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                   const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                                   int out_stride, int out_coff, sis3d_stream_t stream)
+{
+    return conv3d_k3wino_impl(nprob, ins, X, Y, Z, cin, cin_stride, packed_ws, biases, cout, flags, outs, out_stride, out_coff, nullptr, nullptr, 0,
+                              stream);
+}
+
+// the same launch + the PIGGYBACK upload of a mailbox pipeline's next chunk (include/sis3d.h)
+extern "C" int sis3d_conv3d_k3wino_piggyback(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                             const float *const *packed_ws, const float *const *biases, int cout, int flags,
+                                             float *const *outs, int out_stride, int out_coff, uint32_t *mail_state, float *upload_dst,
+                                             int64_t n, sis3d_stream_t stream)
+{
+    if (!mail_state || !upload_dst || n <= 0 || (n & 3) || ((uintptr_t)upload_dst & 15)) return SIS3D_EINVAL;
+    return conv3d_k3wino_impl(nprob, ins, X, Y, Z, cin, cin_stride, packed_ws, biases, cout, flags, outs, out_stride, out_coff,
+                              (unsigned *)mail_state, upload_dst, (long long)(n / 4), stream);
 }
 
 // ---- ragged batch: every detected box's mask-head crop (lib/nets/network.py:303-317, backbones.py:243-249) through ONE launch per k3
@@ -979,6 +1039,7 @@ extern "C" int sis3d_conv3d_k3wino_ragged_mini(const float *in, int cin, int cin
     a.rag = (const WinoRagged *)desc_dev; a.nrag = ndesc;
     a.w3p = a.b3 = a.res = a.w1n = a.b1n = nullptr; a.tout = a.out2 = nullptr;
     a.res_stride = a.tout_stride = a.tout_coff = a.out2_stride = 0;
+    a.pig_state = nullptr; a.pig_dst = nullptr; a.pig_n4 = 0; a.pig_row = -1;
 #ifdef WN_DEV_PLAIN_ONLY
     return SIS3D_EUNSUPPORTED;
 #else
@@ -1020,6 +1081,7 @@ extern "C" int sis3d_bottleneck_wino(const float *y1, int X, int Y, int Z, int p
     a.rag = nullptr; a.nrag = 0;
     a.w3p = w3_pw16; a.b3 = b3; a.res = residual; a.res_stride = res_stride; a.tout = out; a.tout_stride = out_stride; a.tout_coff = out_coff;
     a.w1n = w1n_pw16; a.b1n = b1n; a.out2 = out2; a.out2_stride = c2n;
+    a.pig_state = nullptr; a.pig_dst = nullptr; a.pig_n4 = 0; a.pig_row = -1;
     const int64_t nwg = (int64_t)a.nbx * a.nby * a.nbz;
     if (nwg > 0x7fffffff) return SIS3D_EUNSUPPORTED;
     const hipStream_t st = as_stream(stream);

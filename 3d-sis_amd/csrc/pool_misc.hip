@@ -225,29 +225,36 @@ __global__ __launch_bounds__(256) void upload_kernel(const upl4 *__restrict__ sr
 }
 
 // ---- host -> graph mailbox (include/sis3d.h): kernels inside a captured graph read what changes per chunk from a pinned host ring
-struct MailSlot { unsigned long long src, dst; float origin[3]; unsigned flags; };
-static_assert(sizeof(MailSlot) == 32, "mail slot layout");
-constexpr int MAIL_SLOT_WORD = 8;          // state[8..15]: the fetched slot
+struct MailSlot { unsigned long long src, dst; float origin[3]; unsigned flags; unsigned long long next_src, pad[3]; };
+static_assert(sizeof(MailSlot) == 64, "mail slot layout");
+constexpr int MAIL_SLOT_WORD = 8;          // state[8..23]: the fetched slot
 
 // ONE read of the slot across the link (two 16-byte loads), parked in device memory for the launches behind it
 __global__ __launch_bounds__(64) void mail_fetch_kernel(const upl4 *__restrict__ ring, int ring_size, unsigned *__restrict__ state)
 {
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 4) {
         const unsigned k = state[0];
-        const upl4 v = __builtin_nontemporal_load(ring + (size_t)(k % (unsigned)ring_size) * 2 + threadIdx.x);
+        const upl4 v = __builtin_nontemporal_load(ring + (size_t)(k % (unsigned)ring_size) * 4 + threadIdx.x);
         reinterpret_cast<upl4 *>(state + MAIL_SLOT_WORD)[threadIdx.x] = v;
     }
 }
 
+constexpr int MAIL_STAGED_WORD = 24;       // state[24..25]: the source whose chunk the staging buffer holds (the piggyback row of conv3d_wino.hip)
+
 __global__ __launch_bounds__(256) void mail_upload_kernel(const unsigned *__restrict__ state, upl4 *__restrict__ dst, int64_t n4,
-                                                          float *__restrict__ origin_dst)
+                                                          float *__restrict__ origin_dst, const upl4 *__restrict__ staged)
 {
     const MailSlot s = *reinterpret_cast<const MailSlot *>(state + MAIL_SLOT_WORD);      // device memory, uniform
     if (blockIdx.x == 0 && threadIdx.x < 3 && origin_dst && (s.flags & 1u)) origin_dst[threadIdx.x] = s.origin[threadIdx.x];
     const upl4 *src = reinterpret_cast<const upl4 *>(s.src);
+    // the previous pass already pulled this chunk into the staging buffer (slot flag bit 2: the host announced it as that pass's
+    // next_src and has not touched it since): copy it from there at HBM speed
+    const bool from_stage = staged && src && (s.flags & 4u) &&
+                            *reinterpret_cast<const unsigned long long *>(state + MAIL_STAGED_WORD) == s.src;
+    if (from_stage) src = staged;
     // a HOST source is pulled across the link by the first 8 workgroups only (a wave that waits on the link must not sit on many CUs:
-    // see upload_kernel); a DEVICE source (flags bit 1) is copied by the whole grid at HBM speed
-    const int active = (s.flags & 2u) ? (int)gridDim.x : (gridDim.x < 8 ? (int)gridDim.x : 8);
+    // see upload_kernel); a DEVICE source (flags bit 1, or the staged copy) is copied by the whole grid at HBM speed
+    const int active = ((s.flags & 2u) || from_stage) ? (int)gridDim.x : (gridDim.x < 8 ? (int)gridDim.x : 8);
     if (!src || (int)blockIdx.x >= active) return;
     constexpr int U = 8;
     const int64_t stride = (int64_t)active * blockDim.x;
@@ -287,13 +294,15 @@ extern "C" int sis3d_mail_fetch(const void *ring, int ring_size, uint32_t *state
     return sis3d_check_launch();
 }
 
-extern "C" int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, int workgroups, sis3d_stream_t stream)
+extern "C" int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, const float *staged, int workgroups,
+                                 sis3d_stream_t stream)
 {
-    if (!state || !input_dst || n <= 0 || (n & 3) || ((uintptr_t)input_dst & 15) || workgroups < 0) return SIS3D_EINVAL;
+    if (!state || !input_dst || n <= 0 || (n & 3) || ((uintptr_t)input_dst & 15) || ((uintptr_t)staged & 15) || workgroups < 0)
+        return SIS3D_EINVAL;
     static const int env_wg = [] { const char *e = getenv("SIS3D_MAIL_WGS"); return e ? atoi(e) : 0; }();      // tuning hook
     const int wg = workgroups > 0 ? workgroups : (env_wg > 0 ? env_wg : 64);
     hipLaunchKernelGGL(mail_upload_kernel, dim3(wg), dim3(256), 0, as_stream(stream), (const unsigned *)state, (upl4 *)input_dst, n / 4,
-                       origin_dst);
+                       origin_dst, (const upl4 *)staged);
     return sis3d_check_launch();
 }
 

@@ -35,7 +35,7 @@ SIGNATURES = {
                                          c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sis3d_upload_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     "sis3d_mail_fetch": (c_int, [c_vp, c_int, c_vp, c_vp]),
-    "sis3d_mail_upload": (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
+    "sis3d_mail_upload": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_vp]),
     "sis3d_mail_post": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "sis3d_tsdf_encode": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "sis3d_proposal_decode": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
@@ -87,6 +87,8 @@ SIGNATURES = {
     "sis3d_conv_k3wino_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3wino_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d_k3wino": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "sis3d_conv3d_k3wino_piggyback": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int,
+                                              c_vp, c_vp, c_i64, c_vp]),
     "sis3d_ragged_tiling_k3wino": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "sis3d_conv3d_k3wino_ragged": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),
     "sis3d_conv3d_k3wino_ragged_mini": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp]),

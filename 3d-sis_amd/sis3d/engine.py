@@ -55,7 +55,8 @@ def pooled_stream(role, index=0, device=None):
 
 class ChunkEngine:
     def __init__(self, net, dims=CHUNK_DIMS, stage="detect", use_graph=True, n_views=0, device=None, from_depth=False, group=1,
-                 mask_boxes=0, shared_chip=False, brick_cap=0, mailbox=False, mail_input="grid", truncated=3.0, mail_ring=256):
+                 mask_boxes=0, shared_chip=False, brick_cap=0, mailbox=False, mail_input="grid", truncated=3.0, mail_ring=256,
+                 stage_ahead=None):
         """stage: 'backbone' (the two pyramid levels only), 'rpn' (backbone + RPN maps, BASELINE config 1) or 'detect'
         (+ proposals, RoI pooling, classifier).
         from_depth (USE_IMAGES): the chunk's views arrive as depth maps + poses (the dataloader's
@@ -78,9 +79,15 @@ class ChunkEngine:
         # row that receives the record block -- reaches the captured graph through a ring of slots in pinned host memory
         # (ops.Mailbox), read by kernels INSIDE the graph: `submit()` is CPU stores + ONE graph launch.  mail_input 'sdf': the source is
         # the raw SDF block of a .chunk file, TSDF-encoded by the graph's second node (lib/datasets/dataset.py:54-70).
+        # stage_ahead (default on; SIS3D_MAIL_STAGE_AHEAD=0 / stage_ahead=False: off): a slot may also name the chunk of the pass AFTER
+        # its own (submit(next_src=)); one more row of workgroups of the pass's longest conv launch (the rpn_net pair,
+        # ops.piggyback / sis3d_conv3d_k3wino_piggyback) pulls it across PCIe into `_ahead` while the pass computes, and the next pass's
+        # upload node copies it from there at HBM speed instead of waiting on the link.  (Measured alternatives, profiles/
+        # r05_stage_ahead.txt: the same copy as a parallel BRANCH of the captured graph makes every replay 2.4x slower.)
         self.mail = None
         self.mail_input, self._trunc = mail_input, float(truncated)
         self._slot = None
+        self._ahead, self._carry_ahead, self.piggybacked = None, True, False
         self.mask_boxes = int(mask_boxes)
         self.mask_plan = None
         self.net, self.dims, self.stage, self.use_graph = net, tuple(dims), stage, use_graph
@@ -124,6 +131,11 @@ class ChunkEngine:
             self.mail = ops.Mailbox(self.device, ring=mail_ring)
             if mail_input == "sdf":
                 self._sdf_stage = torch.zeros(self.dims[0] * self.dims[1] * self.dims[2], device=self.device)
+            if stage_ahead is None:
+                import os
+                stage_ahead = os.environ.get("SIS3D_MAIL_STAGE_AHEAD", "1") not in ("0", "")
+            if stage_ahead:
+                self._ahead = torch.zeros_like(self._sdf_stage if mail_input == "sdf" else self.scenes[0].view(-1))
 
     # slot-0 views of the static buffers (the single-chunk API)
     scene = property(lambda self: self.scenes[0])
@@ -148,8 +160,8 @@ class ChunkEngine:
         return d
 
     def _mail_commit(self):
-        src, dst, origin = self._slot or (None, None, None)
-        self.mail.write(src, dst, origin)
+        src, dst, origin, nxt = self._slot or (None, None, None, None)
+        self.mail.write(src, dst, origin, nxt if self.piggybacked else None)
         self._slot = None
 
     def _step(self):
@@ -158,21 +170,30 @@ class ChunkEngine:
         with ops.dispatch_regime(self.shared_chip, self.brick_cap):
             if self.mail is not None:
                 if self.mail_input == "sdf":
-                    ops.mail_upload(self.mail, self._sdf_stage, self.origins[0])
+                    ops.mail_upload(self.mail, self._sdf_stage, self.origins[0], staged=self._ahead)
                     ops.tsdf_encode(self._sdf_stage, self.dims, self._trunc, "abs", None, out=self.scenes[0])
                 else:
-                    ops.mail_upload(self.mail, self.scenes[0], self.origins[0])
-            out = self._step_body()
+                    ops.mail_upload(self.mail, self.scenes[0].view(-1), self.origins[0], staged=self._ahead)
+            # the pass's longest conv launch also pulls the NEXT chunk across the link (not inside the round graph: its slots announce
+            # no next chunk); piggybacked: did a launch of this pass / of the captured graph take the upload on board
+            with ops.piggyback(self.mail, self._ahead if self._carry_ahead else None) as took:
+                out = self._step_body()
+            if self._carry_ahead:
+                self.piggybacked = bool(took[0])
             if self.mail is not None and not (isinstance(out, dict) and out.pop("_mail_posted", False)):
                 ops.mail_post(self.mail, out["block"] if isinstance(out, dict) and "block" in out else None)
             return out
 
-    def submit(self, src=None, block_dst=None, origin=None):
+    def submit(self, src=None, block_dst=None, origin=None, next_src=None):
         """mailbox engines: one pass on the chunk `src` points at (pinned host or device tensor; None = the static input as it is),
-        record block to `block_dst`, boxes shifted by `origin`: CPU stores into the next mailbox slot + one graph launch"""
+        record block to `block_dst`, boxes shifted by `origin`: CPU stores into the next mailbox slot + one graph launch.
+        next_src: the pinned host chunk this engine will be given NEXT, if the caller knows it -- pulled across the link while this pass
+        computes (stage_ahead); it must stay unchanged until that pass has run.  Ignored when it is not pinned host memory."""
         if self.mail is None:
             raise ops._lib.Sis3dError("submit() needs an engine built with mailbox=True")
-        self._slot = (src, block_dst, origin)
+        if next_src is not None and (self._ahead is None or next_src.is_cuda or ops.mail_source(next_src, self._ahead.numel()) is None):
+            next_src = None
+        self._slot = (src, block_dst, origin, next_src)
         return self.run()
 
     def _step_body(self):
@@ -550,7 +571,8 @@ class PipelinedEngines:
             if not self._mail_q[i]:
                 raise ops._lib.Sis3dError("streamed inputs: nothing was fed to pipeline %d" % i)
             with torch.cuda.stream(self.streams[i]):
-                return self.engines[i].submit(src=self._mail_q[i].pop(0))
+                src = self._mail_q[i].pop(0)
+                return self.engines[i].submit(src=src, next_src=self._mail_q[i][0] if self._mail_q[i] else None)
         st = self.streams[i]
         self.consume(i, st)
         with torch.cuda.stream(st):
@@ -590,10 +612,12 @@ class PipelinedEngines:
                             s.wait_event(prev_ev)
                         ev = torch.cuda.Event()
                         eng.net._after_level1 = ev.record
+                        eng._carry_ahead = False
                         try:
                             out = eng._step()
                         finally:
                             eng.net._after_level1 = None
+                            eng._carry_ahead = True
                         prev_ev = ev
                         send[e].copy_(out["block"])
                 for s in self.streams:

@@ -358,30 +358,35 @@ def upload(host, out, workgroups=0):
 
 
 class Mailbox(object):
-    """Host side of the host -> graph mailbox (include/sis3d.h, sis3d_mail_upload / sis3d_mail_post): a ring of 32-byte slots in
+    """Host side of the host -> graph mailbox (include/sis3d.h, sis3d_mail_upload / sis3d_mail_post): a ring of 64-byte slots in
     PINNED host memory that kernels inside a captured graph read, the device counter of consumed slots and the pinned progress
     word the device writes back.  `write()` is plain CPU stores -- no HIP call -- so a pipeline's only call per chunk is the graph
     launch (a command enqueued behind a graph launch that has not finished can block the host on this runtime).
-    slot = { u64 src; u64 dst; f32 origin[3]; u32 flags }."""
+    slot = { u64 src; u64 dst; f32 origin[3]; u32 flags; u64 next_src; u64 pad[3] }."""
     RING = 256
+    SLOT = 64
 
     def __init__(self, device, ring=RING):
         import numpy as np
         self.ring_size = int(ring)
-        self.buf = torch.zeros(self.ring_size * 32, dtype=torch.uint8).pin_memory()
+        self.buf = torch.zeros(self.ring_size * self.SLOT, dtype=torch.uint8).pin_memory()
         a = self.buf.numpy()
-        self.u64 = a.view(np.uint64).reshape(self.ring_size, 4)
-        self.f32 = a.view(np.float32).reshape(self.ring_size, 8)
-        self.u32 = a.view(np.uint32).reshape(self.ring_size, 8)
-        self.state = torch.zeros(16, dtype=torch.int32, device=device)      # [0] consumed slots, [8..15] the slot of the running pass
+        self.u64 = a.view(np.uint64).reshape(self.ring_size, self.SLOT // 8)
+        self.f32 = a.view(np.float32).reshape(self.ring_size, self.SLOT // 4)
+        self.u32 = a.view(np.uint32).reshape(self.ring_size, self.SLOT // 4)
+        # [0] consumed slots, [8..23] the slot of the running pass, [24..25] the source whose chunk the staging buffer holds
+        self.state = torch.zeros(32, dtype=torch.int32, device=device)
         self._progress_t = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.progress = self._progress_t.numpy()
         self.head = 0                                  # slots written so far (the device has consumed progress[0] of them)
         self.keep = [None] * self.ring_size            # the tensors behind the pointers of the outstanding slots stay alive
+        self._announced = 0                            # next_src of the slot written last
 
-    def write(self, src=None, dst=None, origin=None):
+    def write(self, src=None, dst=None, origin=None, next_src=None):
         """the slot of the NEXT pass: src = tensor to copy into the pipeline's input (pinned host or device memory; None: the input
-        buffer already holds the chunk), dst = tensor that receives the pass's record block (None: nowhere), origin = (x, y, z)"""
+        buffer already holds the chunk), dst = tensor that receives the pass's record block (None: nowhere), origin = (x, y, z),
+        next_src = the PINNED HOST chunk of the pass after this one, if known: the piggyback row of this pass's longest conv launch
+        pulls it into the staging buffer (sis3d_conv3d_k3wino_piggyback) -- the caller leaves it unchanged until that pass has run"""
         if self.head - int(self.progress[0]) >= self.ring_size - 1:
             # the producer is a whole ring ahead of the device: wait for a slot (rare); a device that never consumes is an error
             import time
@@ -394,11 +399,15 @@ class Mailbox(object):
         self.u64[k, 0] = src.data_ptr() if src is not None else 0
         self.u64[k, 1] = dst.data_ptr() if dst is not None else 0
         flags = 2 if (src is not None and src.is_cuda) else 0          # bit 1: a device source is copied by the whole grid
+        if src is not None and not src.is_cuda and self._announced == src.data_ptr():
+            flags |= 4                                                 # bit 2: the previous pass was told to stage this very chunk
         if origin is not None:
             self.f32[k, 4] = origin[0]; self.f32[k, 5] = origin[1]; self.f32[k, 6] = origin[2]
             flags |= 1
+        self._announced = next_src.data_ptr() if (next_src is not None and not next_src.is_cuda) else 0
+        self.u64[k, 4] = self._announced
         self.u32[k, 7] = flags
-        self.keep[k] = (src, dst)
+        self.keep[k] = (src, dst, next_src)
         self.head += 1
 
 
@@ -412,13 +421,34 @@ def mail_source(t, numel):
     return None
 
 
-def mail_upload(mb, input_dst, origin_dst=None, workgroups=0):
+def mail_upload(mb, input_dst, origin_dst=None, workgroups=0, staged=None):
     """first two nodes of a pipeline's graph: fetch the slot of this pass across PCIe (sis3d_mail_fetch), then slot.src -> input_dst and
-    slot.origin -> origin_dst (sis3d_mail_upload)"""
+    slot.origin -> origin_dst (sis3d_mail_upload).  staged: the piggyback staging buffer (same numel as input_dst) -- copied instead
+    of slot.src when the previous pass already pulled this chunk into it"""
     _dev(input_dst, "input_dst")
+    if staged is not None and (_dev(staged, "staged").numel() != input_dst.numel()):
+        raise _lib.Sis3dError("mail_upload: the staging buffer must have the input's size")
     check(lib().sis3d_mail_fetch(_ptr(mb.buf), mb.ring_size, _ptr(mb.state), _stream()), "sis3d_mail_fetch")
-    check(lib().sis3d_mail_upload(_ptr(mb.state), _ptr(input_dst), input_dst.numel(), _ptr(origin_dst), int(workgroups), _stream()),
-          "sis3d_mail_upload")
+    check(lib().sis3d_mail_upload(_ptr(mb.state), _ptr(input_dst), input_dst.numel(), _ptr(origin_dst), _ptr(staged), int(workgroups),
+                                  _stream()), "sis3d_mail_upload")
+
+
+# piggyback upload (r5): inside `with piggyback(mb, stage)` the first LONG Winograd launch (>= PIGGY_MIN_FLOPS: the rpn_net pair, ~50 us
+# alone, ~110 us on a shared chip) carries one more row of workgroups, eight of which pull the mailbox slot's next_src into `stage`
+# (sis3d_conv3d_k3wino_piggyback).  Thread-local, like the dispatch regime: engines are prepared concurrently.
+PIGGY_MIN_FLOPS = 8e9
+
+
+@_contextlib.contextmanager
+def piggyback(mb, stage):
+    """-> a one-element list: [True] once a launch has taken the upload on board"""
+    prev = getattr(_REGIME, "piggy", None)
+    took = [False]
+    _REGIME.piggy = (mb, _dev(stage, "stage"), took) if mb is not None and stage is not None else None
+    try:
+        yield took
+    finally:
+        _REGIME.piggy = prev
 
 
 def mail_post(mb, block_src):
@@ -719,8 +749,14 @@ def conv3d_k3wino(xs, pcs, relu=True, outs=None, out_coff=0):
     bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
     os_ = arr(*[o.data_ptr() for o in outs])
     flags = (EPI_RELU if relu else 0) | (DISPATCH_SHARED_CHIP if regime()[0] else 0)
-    rc = lib().sis3d_conv3d_k3wino(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, flags, os_, outs[0].shape[1],
-                                   int(out_coff), _stream())
+    pig, rc = getattr(_REGIME, "piggy", None), -4
+    if pig is not None and not pig[2][0] and 2.0 * n * X * Y * Z * p0.cin * p0.cout * 27 >= PIGGY_MIN_FLOPS:
+        rc = lib().sis3d_conv3d_k3wino_piggyback(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, flags, os_, outs[0].shape[1],
+                                                 int(out_coff), _ptr(pig[0].state), _ptr(pig[1]), pig[1].numel(), _stream())
+        pig[2][0] = rc == 0
+    if rc == -4:                                     # no piggyback asked for, or this launch has no room for it
+        rc = lib().sis3d_conv3d_k3wino(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, flags, os_, outs[0].shape[1],
+                                       int(out_coff), _stream())
     if rc == -4:
         raise Sis3dUnsupported("conv3d_k3wino: unsupported shape")
     check(rc, "sis3d_conv3d_k3wino")

@@ -172,8 +172,12 @@ class SceneRunner:
                         src = ops.mail_source(payload, nfloat)
                         if src is None:
                             self.pipes.load(e, payload, wait=False)       # pageable / strided / non-fp32 grids: an ordinary copy
+                    # the chunk this pipeline gets NEXT (n chunks on): if it sits in pinned host memory it is pulled across the link
+                    # while this one computes (piggyback row of the rpn_net conv launch, ChunkEngine.submit)
+                    nxt = chunks[mine[j + n]][2] if (src is not None and j + n < len(mine)) else None
+                    nxt = nxt if isinstance(nxt, torch.Tensor) and not nxt.is_cuda else None
                     with torch.cuda.stream(self.pipes.streams[e]):
-                        eng.submit(src=src, block_dst=send[j], origin=org)
+                        eng.submit(src=src, block_dst=send[j], origin=org, next_src=nxt)
                     continue
                 if isinstance(payload, (tuple, list)):
                     self.pipes.load(e, *payload, wait=False)

@@ -700,9 +700,15 @@ def time_streamed(net, stage, args, rank, nfl, barrier, mode):
     eng.enable_feed(mode)
     k = [0]
 
+    # the loader runs ONE chunk ahead of the device (the reference's DataLoader prefetches whole batches): a pipeline knows its next
+    # chunk when it starts a pass, so that chunk crosses the link during the pass (piggyback row of the rpn_net conv launch)
+    for i in range(nfl):
+        eng.feed(i, ring[i][0])
+
     def step():
         for i in range(nfl):
-            eng.run_fed(i, ring[i][k[0] % RING])
+            eng.feed(i, ring[i][(k[0] + 1) % RING])
+            eng.run_fed(i)
         k[0] += 1
     if not args.no_calibrate and nfl >= 2:
         preheat(step, min(args.preheat_ms, 60.0))
@@ -718,7 +724,7 @@ def time_streamed(net, stage, args, rank, nfl, barrier, mode):
     barrier()
     dt = time.perf_counter() - t0
     return dict(dt=dt, bytes_per_chunk=ring[0][0].numel() * 4, ring=RING, host_ms_per_step=t_host / args.steps * 1e3, copy="mailbox",
-                stream_window=eng.stream_window)
+                stream_window=eng.stream_window, stage_ahead=all(e.piggybacked for e in eng.engines))
 
 
 def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
@@ -734,9 +740,11 @@ def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
                    "mailbox: the first node of a pipeline's graph reads the chunk's host pointer from a ring of slots in pinned memory "
                    "(CPU stores by the host, no HIP call) and pulls the chunk across PCIe itself (sis3d_mail_upload: 8 workgroups, 256 KB "
                    "in flight; sdf: + sis3d_tsdf_encode as the second node), so the host's ONLY call per chunk is the graph launch -- a "
-                   "command enqueued behind a graph launch that has not finished can block the host on this runtime.  A pipeline pauses for "
-                   "its own upload while the other pipelines keep the CUs busy; ring of %d distinct host chunks per pipeline; the timed "
-                   "region contains every upload" % (nfl, st["ring"])}
+                   "command enqueued behind a graph launch that has not finished can block the host on this runtime.  The loader runs one "
+                   "chunk ahead: a pass's slot also names the pipeline's NEXT chunk, which one more row of workgroups of the pass's rpn_net "
+                   "conv launch pulls across the link into a staging buffer while the pass computes (sis3d_conv3d_k3wino_piggyback: "
+                   "`stage_ahead`), so the next pass starts with a device copy instead of waiting on PCIe; ring of %d distinct host "
+                   "chunks per pipeline; the timed region contains every upload" % (nfl, st["ring"]), "stage_ahead": st.get("stage_ahead")}
 
 
 def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):

@@ -185,22 +185,28 @@ int sis3d_upload_f32(const float *src_host_mapped, float *dst, int64_t n, int wo
  * On this runtime a command enqueued on a stream whose last command is a graph launch that has not finished can BLOCK THE HOST
  * until that graph drains -- an upload kernel, a hipMemcpyAsync, even the 12-byte copy of a chunk origin (profiles/r05_feed_probe.txt:
  * 0.16 -> 1.45 ms of host time per step, bimodal).  A pipeline that replays a captured graph per chunk therefore takes everything
- * that changes from chunk to chunk through a ring of 32-byte slots in PINNED host memory, which kernels INSIDE the graph read:
- *     slot = { u64 src; u64 dst; f32 origin[3]; u32 flags }       flags bit 0: origin valid, bit 1: src is DEVICE memory
+ * that changes from chunk to chunk through a ring of 64-byte slots in PINNED host memory, which kernels INSIDE the graph read:
+ *     slot = { u64 src; u64 dst; f32 origin[3]; u32 flags; u64 next_src; u64 pad[3] }
+ *     flags bit 0: origin valid, bit 1: src is DEVICE memory, bit 2: src was the next_src of the PREVIOUS slot and has not changed since;
+ *     next_src: the chunk of the pipeline's NEXT pass (0 = unknown) -- the extra row of workgroups of sis3d_conv3d_k3wino_piggyback
+ *     pulls it into a staging buffer while this pass computes, and records whose chunk the buffer holds in state[24..25]
  * The host writes slot (k mod ring_size) with plain CPU stores and replays the graph: hipGraphLaunch is the ONLY call per chunk.
  *   sis3d_mail_fetch   first node of the graph: ONE read of slot k = state[0] (device counter of consumed slots) across PCIe into
- *                      state[8..15] -- small uncached reads over the link are slow and serialise, so no other kernel touches the ring.
+ *                      state[8..23] -- small uncached reads over the link are slow and serialise, so no other kernel touches the ring.
  *   sis3d_mail_upload  second node: copies n floats from the fetched slot's src -- a pinned host pointer (pulled across PCIe by 8
  *                      workgroups with 256 KB in flight, as sis3d_upload_f32) or a device pointer (flags bit 1: copied by the whole
  *                      grid at HBM speed); 0 = the input buffer already holds the chunk -- to `input_dst` (n % 4 == 0, 16-byte aligned),
- *                      and the slot's origin to `origin_dst` (3 floats; may be NULL).  Replaces `blobs['data'].cuda()`
+ *                      and the slot's origin to `origin_dst` (3 floats; may be NULL).  `staged` (may be NULL): the staging buffer of
+ *                      sis3d_conv3d_k3wino_piggyback -- taken instead of src when flags bit 2 is set and state[24..25] == src, i.e. the
+ *                      previous pass already pulled this chunk across the link.  Replaces `blobs['data'].cuda()`
  *                      (lib/nets/network.py:191).
  *   sis3d_mail_post    last node: copies n floats of `block_src` (the chunk's record block) to the slot's dst (0 = nowhere) and
  *                      consumes the slot: state[0] = k + 1, *progress = k + 1 (pinned host word the producer polls before it laps
  *                      the ring).
- * state: 16 uint32 of device memory, zero-initialised, owned by the pipeline. */
+ * state: 32 uint32 of device memory, zero-initialised, owned by the pipeline. */
 int sis3d_mail_fetch(const void *ring_host_mapped, int ring_size, uint32_t *state, sis3d_stream_t stream);
-int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, int workgroups, sis3d_stream_t stream);
+int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, const float *staged, int workgroups,
+                      sis3d_stream_t stream);
 int sis3d_mail_post(uint32_t *state, const float *block_src, int64_t n, uint64_t *progress_host_mapped, sis3d_stream_t stream);
 
 /* ------------------------------------------------------- proposal decoding --
@@ -438,6 +444,16 @@ int sis3d_conv_k3wino_pack_weight(const float *w, int cout, int cin, float *pack
 int sis3d_conv3d_k3wino(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
                         const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
                         int out_stride, int out_coff, sis3d_stream_t stream);
+/* the same launch with ONE MORE ROW of workgroups that do not convolve (r5): the first eight of them copy n floats from the `next_src`
+ * of the mailbox slot this graph's first node fetched (mail_state, sis3d_mail_fetch) into upload_dst (the STAGING buffer
+ * sis3d_mail_upload of the next pass is given) and record next_src in mail_state[24..25], the others leave at once -- the pipeline's
+ * NEXT chunk is pulled across PCIe while the real workgroups compute, so the upload hides under the longest kernel of a chunk
+ * instead of stalling the pipeline in front of it.  Only the two-cout-tile form has the branch (the rpn_net pair):
+ * SIS3D_EUNSUPPORTED otherwise -- the caller launches sis3d_conv3d_k3wino and the next pass uploads at its head. */
+int sis3d_conv3d_k3wino_piggyback(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
+                                  const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
+                                  int out_stride, int out_coff, uint32_t *mail_state, float *upload_dst, int64_t n,
+                                  sis3d_stream_t stream);
 /* ragged batch (the mask head's crops, lib/nets/network.py:303-317): one launch per k3 layer for all boxes.  Work items are
  * (crop, 8 x 4 x 8 block, group of two cout tiles); desc_dev = ndesc descriptors {int X,Y,Z, nbx,nby,nbz, block0, pad; int64 in_off,
  * out_off} (the layout of sis3d_conv3d_k3t16_ragged) with block0 counting blocks x groups, total_blocks their sum.

@@ -542,3 +542,73 @@ def test_stream_window_calibration_keeps_results():
         out = runner.infer(chunks, lazy=lazy)
         r2, k2 = out.resolve() if lazy else out
         assert torch.equal(r2, recs) and torch.equal(k2, keep)
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_stage_ahead_pulls_the_next_chunk_and_changes_nothing(full, monkeypatch):
+    """r5: a mailbox slot may name the pipeline's NEXT pinned host chunk; one more row of workgroups of the pass's longest Winograd launch
+    (sis3d_conv3d_k3wino_piggyback) pulls it into a staging buffer and the next pass's upload node copies it from there.  Results are those of
+    resident passes bit for bit -- when the announcement is right, when the caller then submits ANOTHER chunk, when the chunk comes
+    from device memory -- and the staged copy really is what the next pass reads (white box: the host block is changed after the
+    staging pass, against the contract, and the pass still sees the staged contents)."""
+    from sis3d import ops
+    from sis3d.engine import ChunkEngine
+    net, cfg = _small_net()
+    dims, stage = ((96, 48, 96), "rpn") if full else ((48, 24, 40), "detect")
+    if not full:
+        monkeypatch.setattr(ops, "PIGGY_MIN_FLOPS", 0.0)      # small chunk: whichever Winograd launch comes first carries the upload
+    key = "rpn_bbox_pred_level1" if stage == "rpn" else "block"
+    plain = ChunkEngine(net, dims=dims, stage=stage)
+    plain.prepare()
+    cids = [70 + k for k in range(5)]
+    grids = {c: synthetic.synth_chunk(c, dims) for c in cids}
+    want = {}
+    for c in cids:
+        plain.load(grids[c])
+        want[c] = plain.run()[key].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(want[cids[0]], want[cids[1]])
+    host = {c: grids[c].contiguous().pin_memory() for c in cids}
+    for use_graph in (True, False):
+        mbx = ChunkEngine(net, dims=dims, stage=stage, mailbox=True, use_graph=use_graph)
+        off = ChunkEngine(net, dims=dims, stage=stage, mailbox=True, use_graph=use_graph, stage_ahead=False)
+        mbx.prepare()
+        off.prepare()
+        assert off._ahead is None and mbx._ahead is not None and not off.piggybacked
+        if full:
+            assert mbx.piggybacked, "the rpn_net launch of the full-size chunk must carry the upload"
+
+        def one(eng, c, nxt):
+            out = eng.submit(src=c if isinstance(c, torch.Tensor) else host[c], next_src=None if nxt is None else host[nxt])[key]
+            torch.cuda.synchronize()
+            return out.clone()
+        # right announcements, back to back
+        for k, c in enumerate(cids):
+            nxt = cids[k + 1] if k + 1 < len(cids) else None
+            assert torch.equal(one(mbx, c, nxt), want[c]), (use_graph, "announced", k)
+            assert torch.equal(one(off, c, nxt), want[c]), (use_graph, "stage_ahead off", k)
+        # announced cids[1], submitted cids[3]; then a device source; then the announced chunk after an unrelated pass
+        assert torch.equal(one(mbx, cids[0], cids[1]), want[cids[0]])
+        assert torch.equal(one(mbx, cids[3], cids[2]), want[cids[3]]), (use_graph, "another chunk than the announced one")
+        assert torch.equal(one(mbx, grids[cids[2]].cuda(), None), want[cids[2]]), (use_graph, "device source")
+        assert torch.equal(one(mbx, cids[2], None), want[cids[2]])
+        if mbx.piggybacked:
+            # white box: the pass below stages a copy of cids[4]; the host block then changes (a caller must not do this) and the next
+            # pass still computes on the staged copy -- the link is not crossed again
+            spare = host[cids[4]].clone().pin_memory()
+            host["spare"] = spare
+            one(mbx, cids[0], "spare")
+            spare.copy_(host[cids[1]])
+            assert torch.equal(one(mbx, spare, None), want[cids[4]]), (use_graph, "the staged copy is what the pass reads")
+            # unannounced, the same block is read from the host again
+            assert torch.equal(one(mbx, spare, None), want[cids[1]])
+        # back-to-back passes without a host sync in between (the branch of pass k and the upload node of pass k + 1 are ordered)
+        rows = []
+        for k in range(12):
+            c, nxt = cids[k % 5], cids[(k + 1) % 5]
+            out = mbx.submit(src=host[c], next_src=host[nxt])[key]
+            rows.append(out.clone())                  # on the stream of the pass: ordered behind it
+        torch.cuda.synchronize()
+        for k in range(12):
+            assert torch.equal(rows[k], want[cids[k % 5]]), (use_graph, "back to back", k)
+    print("[parity] stage-ahead upload (full=%s): staged / mis-announced / device / unannounced chunks all bit-identical to resident passes" % full)
