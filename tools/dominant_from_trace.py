@@ -14,8 +14,9 @@ def main():
     wino = "--direct" not in sys.argv
     argv = [a for a in sys.argv if a != "--direct"]
     sys.argv = argv
-    # r4: the template grew parameters (NC, C3, C2N, MINI): the plain k3 conv is <2, 0, 0, false>
-    names, wgs = (("conv3d_k3wino_kernel<2>", "conv3d_k3wino_kernel<2, 0, 0, false>", "conv3d_k3wino_kernel<2, 0, 0, false, 1>"), 216) if wino \
+    # r4/r5: the template grew parameters (NC, C3, C2N, MINI, WC, PIGGY): the plain k3 conv is <2, 0, 0, false, 1, false>
+    names, wgs = (("conv3d_k3wino_kernel<2>", "conv3d_k3wino_kernel<2, 0, 0, false>", "conv3d_k3wino_kernel<2, 0, 0, false, 1>",
+                   "conv3d_k3wino_kernel<2, 0, 0, false, 1, false>"), 216) if wino \
         else (("conv3d_k3t16_kernel<6, 6, 12",), 256)
     rows = []
     for r in csv.DictReader(open(sys.argv[1])):
