@@ -226,6 +226,35 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
     asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The same operations for the epilogue: NOT volatile -- the output transform is a tree of short dependent chains, and a lone wave
+// stalls on every back-to-back dependent pair unless hipcc is free to interleave the chains (volatile asm keeps program order)
+__device__ __forceinline__ f32x2 epk_add(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 epk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// - a - b  =  (-a) + (-b), one rounding: the scalar code's  -a - b
+__device__ __forceinline__ f32x2 epk_nsub(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a 16-byte store at (uniform base + 32-bit byte offset): asm, so that hipcc neither splits it nor folds it into the scalar fallback
+__device__ __forceinline__ void store16_asm(f32x4 v, unsigned byte_off, float *base)
+{
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    float *sbase = (float *)(((unsigned long long)hi << 32) | lo);
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(sbase) : "memory");
+}
 // B^T along z on a row held as a = (t0, t1), b = (t2, t3):  (t0 - t2, t1 + t2)  and  (t2 - t1, t1 - t3)
 __device__ __forceinline__ f32x2 pk_bt_lo(f32x2 a, f32x2 b)
 {
@@ -342,11 +371,11 @@ struct NextV {
 // its 8 %.  Kept as a template parameter (the default WC = 1 is the shipped kernel); not instantiated in the library.
 template <int H, int NC, int C3 = 0, int C2N = 0, bool MINI = false, int WC = 1>
 __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int prob, int brick, int grp, int gX, int gY, int gZ, int nby, int nbz,
-                                          int64_t in_off, int64_t out_off)
+                                          int64_t in_off, int64_t out_off, [[maybe_unused]] unsigned long long t_entry = 0)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsp[4] = {0, 0, 0, 0}, tse[5] = {0, 0, 0, 0, 0};
     if constexpr (WN_EXP & 64) ts0 = wall_clock64();       // experiment: 100 MHz timestamps of the phases, written instead of the output
     const int g = wave & 1;
     const int wc = WC == 1 ? 0 : (wave >> 2);              // which NC cout tiles of the workgroup's NC WC
@@ -374,18 +403,47 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     }
     const float *__restrict__ p_in = a.in[prob] + in_off;
     const float *__restrict__ p_wp = a.wp[prob];
-    const int nk = a.nk;
+    // the launch's scalars: read from the kernel-argument segment ONCE, here.  Left alone, hipcc treats a kernel argument as free to
+    // re-load and does so inside the staging plan's branches and in every iteration of the store tail -- each time a scalar-cache round
+    // trip the wave sits out (r6, in-kernel timestamps: 2.35 us from entry to the first loads issued, 1.2 us for eight stores); the
+    // empty asm makes the value opaque, so it stays in its SGPR
+    int nk = a.nk, cin_stride = a.cin_stride;
+    asm volatile("" : "+s"(nk), "+s"(cin_stride));
 
     float *raw = lds;                                   // [NRAW][4][CHS]
     constexpr int B_STAGE = NC * WC * B_TILE;           // floats of one K-step's U stage: NC WC cout tiles
     float *bst = lds + NRAW * RAW_STAGE;                // [NBST][NC][16][64][4]
+
+    // U stage of K-step k: 16 NC WC wave-instructions of 1 KB, 4 NC per wave: block n = 4 NC wave + i = (cout tile n >> 4, xi quad n & 15)
+    constexpr int NFILL = 4 * NC;
+    const float *wbase = p_wp + (size_t)(NC * WC * grp) * nk * B_TILE;
+    const int woff = lane * 4;
+    // a wave's NFILL blocks are consecutive in the packed weights and in the stage (NFILL divides 16): one global base and one LDS
+    // base (M0) per four instructions, the 1 KB steps in between as the instructions' immediate offsets
+    const int n0 = wave * NFILL;
+    const float *wwave = wbase + (size_t)(n0 >> 4) * nk * B_TILE + (n0 & 15) * 256;
+    auto fill_b_item = [&](auto I, int k, int buf) {
+        constexpr int i = decltype(I)::value;
+        glds16<(i & 3) * 1024>(wwave + (size_t)k * B_TILE + (i >> 2) * 1024 + woff, bst + buf * B_STAGE + (n0 + (i >> 2) * 4) * 256);
+    };
+    // ---- prologue (r6 order): everything that crosses the memory system goes out FIRST -- U stages 0 and 1 need only the cout group,
+    // the raw stages 0 and 1 of a staging item go out as soon as that item's offset is known -- and the work that needs no memory
+    // (zero-filling the halo outside the grid, clearing 128 NC accumulator registers) runs under the loads' latency instead of in front
+    // of them
+    static_for<0, NFILL>([&](auto I) { fill_b_item(I, 0, 0); });
+    [[maybe_unused]] unsigned long long tsq = 0;
+    if constexpr (WN_EXP & 64) tsq = wall_clock64();       // U stages 0, 1 issued
 
     // ---- staging plan: item = halo voxel (4 channels = one float4 of its channels-last row).  Branch-free and VALU-free (an
     // fp32 VALU instruction costs the wave a 4-cycle issue slot that the matrix pipe cannot overlap): addresses are a uniform
     // base pointer that advances with k (scalar adds) plus a 32-bit per-lane offset fixed for the whole launch; a halo voxel
     // outside the grid (the same voxels in every K-step) is zeroed once in all three ring stages and its item loads from
     // offset 0 and stores to a dump slot in the pad behind the last x-plane of each channel, as do the items past the brick
-    int goff[NIT], loff[NIT];
+    int goff[NIT], loff[NIT], zpos[NIT];
+    // In the loop the loads are inline asm: hipcc waits vmcnt(0) -- i.e. also for every LDS-DMA in flight -- at the first use of an
+    // ordinary load's result; here the only wait is the counted one in front of the LDS stores (step()).
+    f32x4 sv[NIT], sw[NIT];
+    const float *p_in1 = p_in + (nk > 1 ? 4 : 0);
     static_for<0, NIT>([&](auto I) {
         constexpr int it = decltype(I)::value;
         const int v = tid + it * NTHR;
@@ -404,15 +462,22 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
             lpos = hx * PS + hy * HZS + hz;
         }
         const bool inside = v < NVOX && (unsigned)gx < (unsigned)gX && (unsigned)gy < (unsigned)gY && (unsigned)gz < (unsigned)gZ;
-        goff[it] = inside ? ((gx * gY + gy) * gZ + gz) * a.cin_stride : 0;
+        goff[it] = inside ? ((gx * gY + gy) * gZ + gz) * cin_stride : 0;
         loff[it] = 4 * (inside ? lpos : G_::dump + (lane & 31));    // BYTES; dump: 32 floats of the pad behind the last plane of a channel
-        if (v < NVOX && !inside) {
-            static_for<0, NRAW * 4>([&](auto C) { raw[decltype(C)::value * CHS + lpos] = 0.f; });
+        zpos[it] = (v < NVOX && !inside) ? lpos : -1;
+        load16_asm(sv[it], goff[it] * 4, p_in);
+        load16_asm(sw[it], goff[it] * 4, p_in1);
+    });
+    // U stage 1 LAST: step 0 needs it only at its sixth quad, and the step's own counted wait (slot 40) covers it -- the wait below
+    // leaves these NFILL pieces in flight (a CU takes in ~24 B per clock: the 32 KB would hold the first MFMA up by ~0.5 us)
+    static_for<0, NFILL>([&](auto I) { fill_b_item(I, nk > 1 ? 1 : 0, 1); });
+    if constexpr (WN_EXP & 64) tsp[0] = wall_clock64();    // setup + loads issued
+    static_for<0, NIT>([&](auto I) {
+        constexpr int it = decltype(I)::value;
+        if (zpos[it] >= 0) {
+            static_for<0, NRAW * 4>([&](auto C) { raw[decltype(C)::value * CHS + zpos[it]] = 0.f; });
         }
     });
-    // In the loop the loads are inline asm: hipcc waits vmcnt(0) -- i.e. also for every LDS-DMA in flight -- at the first use of an
-    // ordinary load's result; here the only wait is the counted one in front of the LDS stores (step()).
-    f32x4 sv[NIT];
     auto stage_load_item = [&](auto I, int k) {
         constexpr int it = decltype(I)::value;
         const float *base = p_in + 4 * k;
@@ -427,18 +492,6 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
         dst[2 * CHS] = sv[it][2];
         dst[3 * CHS] = sv[it][3];
     };
-    // U stage of K-step k: 16 NC WC wave-instructions of 1 KB, 4 NC per wave: block n = 4 NC wave + i = (cout tile n >> 4, xi quad n & 15)
-    constexpr int NFILL = 4 * NC;
-    const float *wbase = p_wp + (size_t)(NC * WC * grp) * nk * B_TILE;
-    const int woff = lane * 4;
-    // a wave's NFILL blocks are consecutive in the packed weights and in the stage (NFILL divides 16): one global base and one LDS
-    // base (M0) per four instructions, the 1 KB steps in between as the instructions' immediate offsets
-    const int n0 = wave * NFILL;
-    const float *wwave = wbase + (size_t)(n0 >> 4) * nk * B_TILE + (n0 & 15) * 256;
-    auto fill_b_item = [&](auto I, int k, int buf) {
-        constexpr int i = decltype(I)::value;
-        glds16<(i & 3) * 1024>(wwave + (size_t)k * B_TILE + (i >> 2) * 1024 + woff, bst + buf * B_STAGE + (n0 + (i >> 2) * 4) * 256);
-    };
 
     f32x4 acc[NC][32];                                   // [cout tile c][xi of this half]
     static_for<0, 32 * NC>([&](auto I) { acc[decltype(I)::value >> 5][decltype(I)::value & 31] = (f32x4){0.f, 0.f, 0.f, 0.f}; });
@@ -450,23 +503,23 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
                            : kq * CHS + (2 * (2 * g + txl)) * PS + (2 * ty) * HZS + 2 * tz;
     const int bbase = wc * NC * B_TILE + H * 8 * 256 + lane * 4;
 
-    // ---- prologue: U stages 0 and 1 and raw stages 0 and 1 all in flight together (one wait), then V of step 0
-    static_for<0, NFILL>([&](auto I) { fill_b_item(I, 0, 0); });
-    static_for<0, NIT>([&](auto I) { stage_load_item(I, 0); });
-    f32x4 sw[NIT];
-    static_for<0, NIT>([&](auto I) { load16_asm(sw[decltype(I)::value], goff[decltype(I)::value] * 4, p_in + (nk > 1 ? 4 : 0)); });
-    static_for<0, NFILL>([&](auto I) { fill_b_item(I, nk > 1 ? 1 : 0, 1); });
-    wait_vmcnt_all<0>(sv);
-    wait_vmcnt_all<0>(sw);
+    if constexpr (WN_EXP & 64) tsp[3] = tsp[0];
+    wait_vmcnt_all<NFILL>(sv);
+    wait_vmcnt_all<NFILL>(sw);
+    if constexpr (WN_EXP & 64) tsp[1] = wall_clock64();    // first loads landed
     static_for<0, NIT>([&](auto I) { stage_store_item(I, 0); });
     static_for<0, NIT>([&](auto I) { sv[decltype(I)::value] = sw[decltype(I)::value]; stage_store_item(I, 1); });
-    __syncthreads();
+    // not __syncthreads(): its fence waits vmcnt(0), i.e. for U stage 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     // raw stage 2 goes in flight now: in the loop, the loads of stage k + 3 are issued at the END of step k (behind the LDS stores of
     // stage k + 2) and waited for 54 MFMAs later, in front of the stores of step k + 1 -- an L2 round trip under load is longer than
     // the 35 MFMAs the loads had when they were issued at the start of the step that stores them
     if (!(WN_EXP & 2)) static_for<0, NIT>([&](auto I) { stage_load_item(I, nk > 2 ? 2 : nk - 1); });
     // V ping-pongs between two NextV objects (no register copies): step k multiplies with one while the other is being built
     NextV<H, MINI> va, vb;
+    if constexpr (WN_EXP & 64) tsp[2] = wall_clock64();    // stores + barrier
     static_for<0, 64>([&](auto M) { va.template unit<decltype(M)::value>(LdsRow(raw + rbase)); });
 
     // ---- main loop.  Step k: the 64 MFMAs of step k (32 xi x 2 cout tiles); behind them, in the gaps between MFMAs: the LDS-DMA of
@@ -551,76 +604,106 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
     // the matrix pipe a few cycles ago (an 8-pass MFMA needs up to 11 wait states before a VALU read of its result)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();                                     // quads 6, 7 of the last step ran behind the last in-loop barrier
+    if constexpr (WN_EXP & 64) tse[0] = wall_clock64();
 
     // ---- output transform A^T M A: per lane, cout tile c and row r (tile 4 (lane >> 4) + r, cout lane & 15): 32 xi -> 8 partial
     // outputs (this wave's xi_x half).  The halves meet through LDS (the U stages are free: the loop ended on a barrier, no DMA
     // is in flight): each wave FINISHES two of the four rows (H = 0: r = 0, 1; H = 1: r = 2, 3) and ships the partials of the
     // other two to its partner.
+    // r6: the rows are handled as PAIRS (r, r + 1) -- the two halves of an accumulator quad -- with packed adds: half the VALU
+    // instructions for bit-identical sums (same association, v_pk_add_f32 with neg modifiers = the scalar add / sub), 8-byte LDS
+    // traffic for the partner exchange; the bias is requested before the transform so that its L2 round trip is not waited for in
+    // front of the first finished row, and the launch's scalars come out of SGPRs (see the prologue)
     const int j = lane & 15, q4 = lane >> 4;
     float *__restrict__ p_out = a.out[prob] + out_off;
-    float P[NC][4][8];                                   // [cout tile][row r][ox oy oz]
-    static_for<0, NC>([&](auto C) {
-        constexpr int cc = decltype(C)::value;
-        static_for<0, 4>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            float t[2][4][2];
-            static_for<0, 2>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                static_for<0, 4>([&](auto Y) {
-                    constexpr int y = decltype(Y)::value;
-                    const float m0 = acc[cc][i * 16 + y * 4 + 0][r], m1 = acc[cc][i * 16 + y * 4 + 1][r], m2 = acc[cc][i * 16 + y * 4 + 2][r],
-                                m3 = acc[cc][i * 16 + y * 4 + 3][r];
-                    t[i][y][0] = (m0 + m1) + m2;
-                    t[i][y][1] = (m1 - m2) - m3;
-                });
+    int cout = a.cout, out_stride = a.out_stride, out_coff = a.out_coff, eflags = a.flags;
+    asm volatile("" : "+s"(cout), "+s"(out_stride), "+s"(out_coff), "+s"(eflags));
+    const int cobase = 16 * NC * (WC * grp + wc);
+    float bv[NC];
+    {
+        const float *bp = a.bias[prob];
+        static_for<0, NC>([&](auto C) {
+            const int co = cobase + 16 * decltype(C)::value + j;
+            bv[decltype(C)::value] = (bp && co < cout) ? bp[co] : 0.f;
+        });
+    }
+    auto rows2 = [&](auto C, auto PP, f32x2 (&P)[8]) {      // the 8 partial outputs (ox oy oz) of row pair PP of cout tile C
+        constexpr int cc = decltype(C)::value, pp = decltype(PP)::value;
+        f32x2 t[2][4][2];
+        static_for<0, 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            static_for<0, 4>([&](auto Y) {
+                constexpr int y = decltype(Y)::value;
+                const f32x4 q0 = acc[cc][i * 16 + y * 4 + 0], q1 = acc[cc][i * 16 + y * 4 + 1], q2 = acc[cc][i * 16 + y * 4 + 2], q3 = acc[cc][i * 16 + y * 4 + 3];
+                const f32x2 m0 = {q0[2 * pp], q0[2 * pp + 1]}, m1 = {q1[2 * pp], q1[2 * pp + 1]}, m2 = {q2[2 * pp], q2[2 * pp + 1]},
+                            m3 = {q3[2 * pp], q3[2 * pp + 1]};
+                t[i][y][0] = epk_add(epk_add(m0, m1), m2);                 // (m0 + m1) + m2
+                t[i][y][1] = epk_sub(epk_sub(m1, m2), m3);                 // (m1 - m2) - m3
             });
-            float s2[2][2][2];
-            static_for<0, 2>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                static_for<0, 2>([&](auto Z) {
-                    constexpr int z = decltype(Z)::value;
-                    s2[i][0][z] = (t[i][0][z] + t[i][1][z]) + t[i][2][z];
-                    s2[i][1][z] = (t[i][1][z] - t[i][2][z]) - t[i][3][z];
-                });
+        });
+        f32x2 s2[2][2][2];
+        static_for<0, 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            static_for<0, 2>([&](auto Z) {
+                constexpr int z = decltype(Z)::value;
+                s2[i][0][z] = epk_add(epk_add(t[i][0][z], t[i][1][z]), t[i][2][z]);
+                s2[i][1][z] = epk_sub(epk_sub(t[i][1][z], t[i][2][z]), t[i][3][z]);
             });
-            static_for<0, 4>([&](auto O) {
-                constexpr int o = decltype(O)::value, oy = o >> 1, oz = o & 1;
-                if constexpr (H == 0) {
-                    P[cc][r][0 * 4 + o] = s2[0][oy][oz] + s2[1][oy][oz];     // ox = 0: m0 + m1 (+ m2 from the other half)
-                    P[cc][r][1 * 4 + o] = s2[1][oy][oz];                      // ox = 1: m1 (- m2 - m3 from the other half)
-                } else {
-                    P[cc][r][0 * 4 + o] = s2[0][oy][oz];                      // m2
-                    P[cc][r][1 * 4 + o] = -s2[0][oy][oz] - s2[1][oy][oz];     // - m2 - m3
-                }
-            });
-            if constexpr ((r >> 1) != H) {               // the partner finishes this row
-                float *scr = bst + (((2 * wc + g) * NC + cc) * 4 + r) * (8 * 64) + lane;
-                static_for<0, 8>([&](auto O) { scr[decltype(O)::value * 64] = P[cc][r][decltype(O)::value]; });
+        });
+        static_for<0, 4>([&](auto O) {
+            constexpr int o = decltype(O)::value, oy = o >> 1, oz = o & 1;
+            if constexpr (H == 0) {
+                P[0 * 4 + o] = epk_add(s2[0][oy][oz], s2[1][oy][oz]);     // ox = 0: m0 + m1 (+ m2 from the other half)
+                P[1 * 4 + o] = s2[1][oy][oz];                             // ox = 1: m1 (- m2 - m3 from the other half)
+            } else {
+                P[0 * 4 + o] = s2[0][oy][oz];                             // m2
+                P[1 * 4 + o] = epk_nsub(s2[0][oy][oz], s2[1][oy][oz]);     // - m2 - m3
             }
         });
+    };
+    // partner scratch: [wave pair (wc, g)][cout tile][row pair][o][lane] x 8 B
+    f32x2 *scr2 = reinterpret_cast<f32x2 *>(bst) + (size_t)((2 * wc + g) * NC) * 2 * (8 * 64) + lane;
+    f32x2 P[NC][8];                                      // the row pair this wave finishes (pair H)
+    static_for<0, NC>([&](auto C) {                      // the partner's pair first: its LDS stores drain under the own pair's adds
+        constexpr int cc = decltype(C)::value;
+        f32x2 S[8];
+        rows2(C, std::integral_constant<int, 1 - H>{}, S);
+        static_for<0, 8>([&](auto O) { scr2[((cc * 2 + (1 - H)) * 8 + decltype(O)::value) * 64] = S[decltype(O)::value]; });
     });
+    static_for<0, NC>([&](auto C) { rows2(C, std::integral_constant<int, H>{}, P[decltype(C)::value]); });
+    if constexpr (WN_EXP & 64) tse[1] = wall_clock64();    // output transform + partner stores
     __syncthreads();
+    if constexpr (WN_EXP & 64) tse[2] = wall_clock64();
     // finish rows r = 2H, 2H + 1: + partner's partial, + bias, ReLU; transpose through LDS (second U stage) so that a lane
     // stores 16 B = four consecutive couts of one voxel: [cc][voxel = (r', tile quad q4, o)][cout 16] per wave
     float *tr = bst + B_STAGE + wave * (NC * 2 * 4 * 8 * 16);      // B_STAGE floats = the partner scratch above (2 WC NC x 4 rows x 512)
     static_for<0, NC>([&](auto C) {
         constexpr int cc = decltype(C)::value;
-        const int co = 16 * (NC * (WC * grp + wc) + cc) + j;
-        const float bv = (a.bias[prob] && co < a.cout) ? a.bias[prob][co] : 0.f;
-        static_for<0, 2>([&](auto RR) {
-            constexpr int rr = decltype(RR)::value, r = 2 * H + rr;
-            const float *scr = bst + (((2 * wc + g) * NC + cc) * 4 + r) * (8 * 64) + lane;
-            static_for<0, 8>([&](auto O) {
-                constexpr int o = decltype(O)::value;
-                float v = (P[cc][r][o] + scr[o * 64]) + bv;
-                if (a.flags & SIS3D_EPI_RELU) v = fmaxf(v, 0.f);
-                tr[(((cc * 2 + rr) * 4 + q4) * 8 + o) * 16 + j] = v;
-            });
+        const f32x2 bv2 = {bv[cc], bv[cc]};
+        static_for<0, 8>([&](auto O) {
+            constexpr int o = decltype(O)::value;
+            P[cc][o] = epk_add(epk_add(P[cc][o], scr2[((cc * 2 + H) * 8 + o) * 64]), bv2);
+        });
+    });
+    if (eflags & SIS3D_EPI_RELU) {                          // fmaxf(v, 0) as ONE instruction per value (hipcc's fmaxf: canonicalise + max + select)
+        static_for<0, NC * 8>([&](auto I) {
+            f32x2 &v = P[decltype(I)::value >> 3][decltype(I)::value & 7];
+            asm("v_max_f32 %0, 0, %0" : "+v"(v.x));
+            asm("v_max_f32 %0, 0, %0" : "+v"(v.y));
+        });
+    }
+    static_for<0, NC>([&](auto C) {
+        constexpr int cc = decltype(C)::value;
+        static_for<0, 8>([&](auto O) {
+            constexpr int o = decltype(O)::value;
+            tr[(((cc * 2 + 0) * 4 + q4) * 8 + o) * 16 + j] = P[cc][o].x;
+            tr[(((cc * 2 + 1) * 4 + q4) * 8 + o) * 16 + j] = P[cc][o].y;
         });
     });
     // wave-local exchange: every lane reads what other lanes of its own wave wrote
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (WN_EXP & 64) tse[3] = wall_clock64();    // rows finished, transposed in LDS
     if constexpr (C3 > 0) {
         // ---- fused Bottleneck tail, wave-local: this wave's 64 finished voxels x (16 NC = all) conv2 channels sit in `tr` as rows
         // [cout tile][voxel row][16]; a row IS the B operand of the transposed tile GEMM of mfma16.h (lane (voxel li, kq) reads the
@@ -694,41 +777,67 @@ __device__ __forceinline__ void wino_wave(const WinoArgs &a, float *lds, int pro
             }
         });
     }
-    if (C3 == 0 || a.out[prob] != nullptr)
-    static_for<0, 4 * NC>([&](auto S) {
-        constexpr int sidx = decltype(S)::value;                    // 64 NC voxel rows (cc, rr, q4, o) x 4 float4 pieces / 64 lanes
-        const int piece = sidx * 64 + lane, row = piece >> 2, c4 = piece & 3;
-        const int o = row & 7, tq = (row >> 3) & 3, rr = (row >> 5) & 1, cc = row >> 6;
-        const float4 v = *reinterpret_cast<const float4 *>(tr + row * 16 + c4 * 4);
-        const int tl = 4 * tq + 2 * H + rr;
-        int x, y, z;
-        if constexpr (MINI) {
-            const bool mb = (tl >> 3) & 1;                              // which of this wave's two minis (2 g, 2 g + 1)
-            const int sx = g ? (mb ? mox[3] : mox[2]) : (mb ? mox[1] : mox[0]);
-            const int sy = g ? (mb ? moy[3] : moy[2]) : (mb ? moy[1] : moy[0]);
-            const int sz = g ? (mb ? moz[3] : moz[2]) : (mb ? moz[1] : moz[0]);
-            x = sx + 2 * ((tl >> 2) & 1) + (o >> 2); y = sy + 2 * ((tl >> 1) & 1) + ((o >> 1) & 1); z = sz + 2 * (tl & 1) + (o & 1);
-        } else {
-            x = ox0 + 2 * (2 * g + (tl >> 3)) + (o >> 2); y = oy0 + 2 * ((tl >> 2) & 1) + ((o >> 1) & 1); z = oz0 + 2 * (tl & 3) + (o & 1);
-        }
-        const int co = 16 * (NC * (WC * grp + wc) + cc) + 4 * c4;
-        if (x < gX && y < gY && z < gZ && (!(WN_EXP & 32) || v.x == 123.456f)) {
-            float *dst = p_out + ((size_t)(x * gY + y) * gZ + z) * a.out_stride + a.out_coff + co;
-            if (co + 3 < a.cout && (((a.out_stride | a.out_coff) & 3) == 0)) {
-                *reinterpret_cast<float4 *>(dst) = v;
+    if (C3 == 0 || a.out[prob] != nullptr) {
+        // r6 store tail.  One instruction = 16 / NC voxel rows x (16 NC couts = 64 NC B contiguous: with two cout tiles a full 128-B line
+        // per voxel); a lane's address = the output base (SGPRs) + a 32-bit offset = [lane part: its voxel's place inside a tile, its
+        // cout piece] + [tile part: which tile of the block this instruction serves, uniform when NC = 2] -- both linear in (x, y, z), so
+        // they are built once / on the scalar unit instead of 64-bit multiply-adds per store; the partial-tile / unaligned form is ONE
+        // uniform branch, not a test per store
+        constexpr int LPR = 4 * NC, RPI = 64 / LPR;                 // lanes per voxel row, voxel rows per instruction
+        const int c4 = lane & 3, ccl = (lane >> 2) & (NC - 1), vr = lane / LPR;
+        auto lin = [&](int x, int y, int z) { return ((x * gY + y) * gZ + z) * out_stride; };
+        const bool fast = (((out_stride | out_coff) & 3) == 0) && cobase + 16 * NC <= cout;
+        // every row of the transposed tile first (one LDS round trip for the lot), then the stores
+        f32x4 rowv[4 * NC];
+        static_for<0, 4 * NC>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            rowv[sidx] = *reinterpret_cast<const f32x4 *>(tr + (ccl * 64 + RPI * sidx + vr) * 16 + c4 * 4);
+        });
+        const int co = cobase + 16 * ccl + 4 * c4;
+        static_for<0, 4 * NC>([&](auto S) {
+            constexpr int sidx = decltype(S)::value;
+            const int vrow = RPI * sidx + vr;                        // (rr, tq, o) of the wave's 64 finished voxels
+            const int o = vrow & 7, tq = (vrow >> 3) & 3, rr = vrow >> 5;
+            const int tl = 4 * tq + 2 * H + rr;
+            int x, y, z;
+            if constexpr (MINI) {
+                const bool mb = (tl >> 3) & 1;                              // which of this wave's two minis (2 g, 2 g + 1)
+                const int sx = g ? (mb ? mox[3] : mox[2]) : (mb ? mox[1] : mox[0]);
+                const int sy = g ? (mb ? moy[3] : moy[2]) : (mb ? moy[1] : moy[0]);
+                const int sz = g ? (mb ? moz[3] : moz[2]) : (mb ? moz[1] : moz[0]);
+                x = sx + 2 * ((tl >> 2) & 1); y = sy + 2 * ((tl >> 1) & 1); z = sz + 2 * (tl & 1);
             } else {
-                if (co < a.cout) dst[0] = v.x;
-                if (co + 1 < a.cout) dst[1] = v.y;
-                if (co + 2 < a.cout) dst[2] = v.z;
-                if (co + 3 < a.cout) dst[3] = v.w;
+                x = ox0 + 2 * (2 * g + (tl >> 3)); y = oy0 + 2 * ((tl >> 2) & 1); z = oz0 + 2 * (tl & 3);
             }
-        }
-    });
+            const int dx = o >> 2, dy = (o >> 1) & 1, dz = o & 1;
+            const bool ok = (int)(x + dx < gX) & (int)(y + dy < gY) & (int)(z + dz < gZ) & (int)(!(WN_EXP & 32) || rowv[sidx][0] == 123.456f);
+            const unsigned boff = 4u * (unsigned)(lin(x, y, z) + lin(dx, dy, dz) + out_coff + co);
+            if (fast) {
+                if (ok) store16_asm(rowv[sidx], boff, p_out);
+            } else if (ok) {
+                float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(p_out) + boff);
+                if (co < cout) dst[0] = rowv[sidx][0];
+                if (co + 1 < cout) dst[1] = rowv[sidx][1];
+                if (co + 2 < cout) dst[2] = rowv[sidx][2];
+                if (co + 3 < cout) dst[3] = rowv[sidx][3];
+            }
+        });
+    }
     if constexpr (WN_EXP & 64) {
         const unsigned long long ts3 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts4 = wall_clock64();       // stores drained
         if (tid == 0) {
-            float *d = p_out + (size_t)(brick * a.ngroups + grp) * 4;
-            d[0] = (float)(ts1 - ts0) * 10.f; d[1] = (float)(ts2 - ts1) * 10.f; d[2] = (float)(ts3 - ts2) * 10.f; d[3] = (float)(ts0 % 100000000ull) * 10.f;
+            // 20 floats per workgroup (ns) BEHIND the real output: phases, sub-phases of prologue / epilogue, start and end on the 100 MHz
+            // clock, which CU
+            float *d = p_out + (size_t)gX * gY * gZ * out_stride + (size_t)(brick * a.ngroups + grp) * 20;
+            d[0] = (float)(ts1 - ts0) * 10.f; d[1] = (float)(ts2 - ts1) * 10.f; d[2] = (float)(ts3 - ts2) * 10.f; d[3] = (float)(ts0 % 10000000ull) * 10.f;
+            d[4] = (float)(tsp[0] - ts0) * 10.f; d[5] = (float)(tsp[3] - tsp[0]) * 10.f; d[6] = (float)(tsp[1] - tsp[3]) * 10.f;
+            d[7] = (float)(tsp[2] - tsp[1]) * 10.f; d[8] = (float)(ts1 - tsp[2]) * 10.f;
+            d[9] = (float)(tse[0] - ts2) * 10.f; d[10] = (float)(tse[1] - tse[0]) * 10.f; d[11] = (float)(tse[2] - tse[1]) * 10.f;
+            d[12] = (float)(tse[3] - tse[2]) * 10.f; d[13] = (float)(ts3 - tse[3]) * 10.f; d[14] = (float)(ts4 - ts3) * 10.f;
+            d[15] = (float)(ts4 % 10000000ull) * 10.f; d[17] = (float)(tsq - ts0) * 10.f;
+            d[16] = (float)((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff00) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16));
         }
     }
 }
@@ -739,6 +848,7 @@ template <int NC, int C3 = 0, int C2N = 0, bool MINI = false, int WC = 1, bool P
 __global__ __launch_bounds__(NTHR * WC, 1) void conv3d_k3wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    [[maybe_unused]] unsigned long long t_entry = 0;
     if constexpr (PIGGY) {
         if ((int)blockIdx.y == a.pig_row) {
             if (blockIdx.x >= 8) return;
@@ -804,8 +914,8 @@ __global__ __launch_bounds__(NTHR * WC, 1) void conv3d_k3wino_kernel(const WinoA
     // waves (wc, h, g): h = xi_x half, g = tile group, wc = cout tile group (WC = 2: waves w and w + 4 share a SIMD); each wave serves
     // NC cout tiles
     const int h = __builtin_amdgcn_readfirstlane((threadIdx.x >> 7) & 1);
-    if (h == 0) wino_wave<0, NC, C3, C2N, MINI, WC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
-    else wino_wave<1, NC, C3, C2N, MINI, WC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off);
+    if (h == 0) wino_wave<0, NC, C3, C2N, MINI, WC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off, t_entry);
+    else wino_wave<1, NC, C3, C2N, MINI, WC>(a, lds, blockIdx.y, brick, grp, gX, gY, gZ, nby, nbz, in_off, out_off, t_entry);
 }
 
 // (Cout, Cin, 3, 3, 3) -> U = G g G^T per axis, packed [cout tile (even count)][K-step cin / 4][xi / 4][lane 64][4]:

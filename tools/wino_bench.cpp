@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "sis3d.h"
 
 int main(int argc, char **argv)
@@ -27,7 +28,7 @@ int main(int argc, char **argv)
     hipMemset(bias, 0, cout * 4);
     size_t np = sis3d_conv_k3wino_packed_floats(cout, cin);
     for (int p = 0; p < nprob; ++p) {
-        hipMalloc(&in[p], nin * 4); hipMalloc(&out[p], nout * 4); hipMalloc(&wp[p], np * 4);
+        hipMalloc(&in[p], nin * 4); hipMalloc(&out[p], (nout + 65536) * 4); hipMalloc(&wp[p], np * 4);
         for (size_t i = 0; i < nin; ++i) { float v = (rnd() - 1000) * 1e-3f; h[i] = v > 0 ? v : 0; }
         hipMemcpy(in[p], h.data(), nin * 4, hipMemcpyHostToDevice);
         for (size_t i = 0; i < nw; ++i) h[i] = (rnd() - 1000) * 5e-5f;
@@ -61,18 +62,40 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < nout; ++i) { unsigned u; memcpy(&u, &o[i], 4); hsh = (hsh ^ u) * 1099511628211ull; sum += o[i]; }
         printf("  output checksum %016llx  sum %.6f  first %g %g %g %g  in0 %g %g\n", hsh, sum, o[0], o[1], o[1000], o[nout - 1], h[0], h[1]);
     }
-    if (WN_EXP & 64) {          // phase timestamps (ns) written by thread 0 of every workgroup in place of the output
-        hipMemset(out[0], 0, nout * 4);
+    if (WN_EXP & 64) {          // phase timestamps (ns) written by thread 0 of every workgroup BEHIND the output: 20 floats each
         launch();
         hipDeviceSynchronize();
         int nwg = ((X + 7) / 8) * ((Y + 3) / 4) * ((Z + 7) / 8) * ((cout / 16 + 1) / 2);
-        std::vector<float> t(nwg * 4);
-        hipMemcpy(t.data(), out[0], nwg * 16, hipMemcpyDeviceToHost);
-        double s[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, t0min = 1e30, t0max = 0;
-        for (int i = 0; i < nwg; ++i) { for (int j = 0; j < 3; ++j) { s[j] += t[4 * i + j]; if (t[4 * i + j] > mx[j]) mx[j] = t[4 * i + j]; }
-                                        if (t[4 * i + 3] < t0min) t0min = t[4 * i + 3]; if (t[4 * i + 3] > t0max) t0max = t[4 * i + 3]; }
-        printf("  %d workgroups: prologue %.0f ns (max %.0f), loop %.0f (max %.0f), epilogue %.0f (max %.0f); start-time spread %.0f ns\n", nwg,
-               s[0] / nwg, mx[0], s[1] / nwg, mx[1], s[2] / nwg, mx[2], t0max - t0min);
+        const int R = 20;
+        std::vector<float> t((size_t)nwg * R * nprob);
+        for (int p = 0; p < nprob; ++p) hipMemcpy(t.data() + (size_t)p * nwg * R, out[p] + nout, (size_t)nwg * R * 4, hipMemcpyDeviceToHost);
+        const int n = nwg * nprob;
+        static const char *nm[15] = {"prologue", "loop", "epilogue", "", "pro:setup+loads issued", "pro:zero fill+acc clear", "pro:wait for loads", "pro:stores+barrier",
+                                     "pro:first V", "epi:wait+barrier", "epi:transform+partner stores", "epi:barrier", "epi:finish rows", "epi:tail+stores issued",
+                                     "epi:stores drained"};
+        static const int order[17] = {0, 1, 2, 18, 17, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, -1};
+        for (int q = 0; order[q] >= 0; ++q) {
+            const int j = order[q];
+            double s = 0, mx = 0;
+            for (int i = 0; i < n; ++i) { s += t[R * i + j]; if (t[R * i + j] > mx) mx = t[R * i + j]; }
+            printf("  %-30s %7.0f ns (max %.0f)\n", j == 18 ? "kernel entry -> wave body" : j == 17 ? "pro:(of setup) U DMA issued" : nm[j], s / n, mx);
+        }
+        // hand-over on a CU: workgroups that ran on the same CU, by start time: gap = next start - previous end (stores drained)
+        std::vector<int> idx(n);
+        for (int i = 0; i < n; ++i) idx[i] = i;
+        auto cu = [&](int i) { return (unsigned)t[R * i + 16]; };
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return cu(a) != cu(b) ? cu(a) < cu(b) : t[R * a + 3] < t[R * b + 3]; });
+        double gs = 0, gmx = 0, gmn = 1e30; int ng = 0, ncu = 0;
+        for (int k = 0; k < n; ++k) {
+            if (k == 0 || cu(idx[k]) != cu(idx[k - 1])) { ++ncu; continue; }
+            double gap = t[R * idx[k] + 3] - t[R * idx[k - 1] + 15];
+            if (gap < -5e7) gap += 1e8;
+            gs += gap; ++ng; if (gap > gmx) gmx = gap; if (gap < gmn) gmn = gap;
+        }
+        double t0min = 1e30, t1max = 0;
+        for (int i = 0; i < n; ++i) { if (t[R * i + 3] < t0min) t0min = t[R * i + 3]; if (t[R * i + 15] > t1max) t1max = t[R * i + 15]; }
+        printf("  %d workgroups on %d distinct CUs; %d hand-overs on a CU: gap mean %.0f ns (min %.0f, max %.0f); first start -> last end %.0f ns\n", n, ncu, ng,
+               ng ? gs / ng : 0.0, ng ? gmn : 0.0, gmx, t1max - t0min);
     }
     return 0;
 }
