@@ -170,11 +170,17 @@ __device__ __forceinline__ void load16_asm(f32x4 &dst, int byte_off, const float
 {
     // the base is uniform, but under SGPR pressure (the C3 = 128 Bottleneck tail keeps a dozen kernel-argument pointers live) hipcc parks
     // it in VGPRs and then hands the asm a VGPR pair for its "s" operand (an assembler error, not a readfirstlane); ask for the scalar
-    // copy explicitly -- folded away wherever the value already sits in SGPRs
+    // copy explicitly -- folded away wherever the value already sits in SGPRs.
+    // r6 -- the "s_nop 4": an SGPR written by a VALU instruction (v_readfirstlane) must not be read as a VMEM address within the next
+    // 5 wait states (gfx9 hazard).  hipcc pads that for instructions it knows, NOT for inline asm: with the readfirstlane pair one or two
+    // instructions in front of the load, the load went out with a STALE low half of the base ("Memory access fault" at hi << 32 + offset
+    // in every build of this kernel whose base needed the readfirstlane right there -- an offset kept in VGPRs, a spill-heavy build:
+    // r5's unexplained faults of the piggyback variants; found with tools/wino_bench.cpp variants, r6).  Between MFMAs the five idle
+    // issue cycles are free.
     const unsigned long long b = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     const float *sbase = (const float *)(((unsigned long long)hi << 32) | lo);
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt(f32x4 &a, f32x4 &b, f32x4 &c)
@@ -253,7 +259,7 @@ __device__ __forceinline__ void store16_asm(f32x4 v, unsigned byte_off, float *b
     const unsigned long long b = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     float *sbase = (float *)(((unsigned long long)hi << 32) | lo);
-    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(sbase) : "memory");      // s_nop: see load16_asm
 }
 // B^T along z on a row held as a = (t0, t1), b = (t2, t3):  (t0 - t2, t1 + t2)  and  (t2 - t1, t1 - t3)
 __device__ __forceinline__ f32x2 pk_bt_lo(f32x2 a, f32x2 b)
@@ -270,6 +276,14 @@ __device__ __forceinline__ f32x2 pk_bt_hi(f32x2 a, f32x2 b)
     asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+
+// r6 -- a PERSISTENT WORK LOOP (a launch of fewer workgroups than work items, workgroup b taking items b, b + G, ...: VERDICT r5 item 2)
+// was built and measured and is not in: same binary, same box, items strided over 216 workgroups against one workgroup per item
+// (profiles/r06_wino_persistent_loop_ab.txt): rpn_net pair 96.8 against 95.7 us, four problems 177.9 / 178.6, 32 -> 32 @48x24x48 x2
+// 36.1 / 36.7, x4 68.3 / 70.0 -- a wash (and the loop costs 13 more spilled registers).  The "~1.1 us between a workgroup's last store
+// and its successor's first instruction" that suggested it is the same with the successor INSIDE the workgroup: it is the item
+// decode (three integer divisions through v_rcp + readfirstlane), not a dispatch cost.  What would pay is the next item's loads in
+// flight under this item's output transform; that needs the staging plan of two items live at once on a 512-register kernel.
 
 // The input transform of the NEXT K-step as 28 units, issued behind MFMAs of the current step.  fp32 MFMA and fp32 VALU share
 // the SIMD's fp32 lanes on gfx950 (their cycles ADD: measured, tools/wino_bench.cpp), so the transform is not hidden -- it is

@@ -229,13 +229,38 @@ struct MailSlot { unsigned long long src, dst; float origin[3]; unsigned flags; 
 static_assert(sizeof(MailSlot) == 64, "mail slot layout");
 constexpr int MAIL_SLOT_WORD = 8;          // state[8..23]: the fetched slot
 
-// ONE read of the slot across the link (two 16-byte loads), parked in device memory for the launches behind it
+// r6 -- slot integrity (the kernels behind the fetch dereference raw 64-bit pointers a host thread wrote).  The producer
+// stamps every slot with its sequence number (pad[0] = slots written before it) and a check word over the pointers (pad[1]); the
+// fetch -- the only kernel that reads the ring -- accepts the slot only if the number is the consumed-slot count (a STALE slot the
+// host has not rewritten yet, or one it has LAPPED, carries another number) and the check word matches (a torn / half-written slot).
+// A rejected slot is parked with its three pointers zeroed, so the upload, the piggyback row and the post touch nothing, and the
+// reason goes to state[1] (sticky) -> progress[1] on the host, where ops.Mailbox raises.
+__host__ __device__ inline unsigned long long mail_check_word(unsigned long long src, unsigned long long dst, unsigned long long next_src,
+                                                              unsigned flags, unsigned long long seq)
+{
+    auto rotl = [](unsigned long long v, int r) { return (v << r) | (v >> (64 - r)); };
+    return src ^ rotl(dst, 17) ^ rotl(next_src, 31) ^ ((unsigned long long)flags << 40) ^ (seq * 0x9E3779B97F4A7C15ull) ^ 0x5151D3D3ull;
+}
+
+// ONE read of the slot across the link (four 16-byte loads), parked in device memory for the launches behind it
 __global__ __launch_bounds__(64) void mail_fetch_kernel(const upl4 *__restrict__ ring, int ring_size, unsigned *__restrict__ state)
 {
+    const unsigned k = state[0];
     if (threadIdx.x < 4) {
-        const unsigned k = state[0];
         const upl4 v = __builtin_nontemporal_load(ring + (size_t)(k % (unsigned)ring_size) * 4 + threadIdx.x);
         reinterpret_cast<upl4 *>(state + MAIL_SLOT_WORD)[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MailSlot *s = reinterpret_cast<MailSlot *>(state + MAIL_SLOT_WORD);
+        unsigned err = 0;
+        if ((unsigned)s->pad[0] != k || (s->pad[0] >> 32) != 0) err = 1;                                     // stale or lapped
+        else if (s->pad[1] != mail_check_word(s->src, s->dst, s->next_src, s->flags, s->pad[0])) err = 2;   // torn
+        if (err) {
+            s->src = s->dst = s->next_src = 0;
+            s->flags &= ~5u;                          // no origin, no staged copy
+            if (state[1] == 0) state[1] = err;
+        }
     }
 }
 
@@ -281,7 +306,10 @@ __global__ __launch_bounds__(256) void mail_post_kernel(unsigned *__restrict__ s
     if (threadIdx.x == 0) {
         const unsigned k = state[0] + 1u;
         state[0] = k;
-        if (progress) __hip_atomic_store(progress, (unsigned long long)k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (progress) {
+            if (state[1]) __hip_atomic_store(progress + 1, (unsigned long long)state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(progress, (unsigned long long)k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

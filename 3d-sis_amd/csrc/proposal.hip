@@ -169,7 +169,11 @@ __global__ __launch_bounds__(256) void pack_records_post_kernel(const PackArgs p
     if (threadIdx.x == 0) {
         const unsigned c = mail_state[0] + 1u;
         mail_state[0] = c;
-        if (mail_progress) __hip_atomic_store(mail_progress, (unsigned long long)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mail_progress) {
+            // state[1]: the fetch rejected a slot (stale / lapped / torn: csrc/pool_misc.hip) -> progress[1], where the producer raises
+            if (mail_state[1]) __hip_atomic_store(mail_progress + 1, (unsigned long long)mail_state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mail_progress, (unsigned long long)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

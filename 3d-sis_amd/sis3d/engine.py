@@ -6,6 +6,8 @@ classifier).  Per chunk the host does: async H2D copy of the 3.5 MB grid into th
 buffer, one graph launch, (optionally) one D2H of the fixed-size record block.  Launch-bound
 Python/ctypes overhead (~10 us per op) disappears from the steady state.
 """
+import threading
+
 import torch
 
 from . import ops
@@ -22,35 +24,51 @@ RECORD_WIDTH = ops.RECORD_WIDTH     # proposal box (6), rpn score, level, class 
 # device do not run concurrently with each other (they share the chip), so sharing their streams costs nothing, and the mapping of
 # streams onto the GPU_MAX_HW_QUEUES hardware queues stays the one the first engine set got.
 _STREAM_POOL = {}
+_POOL_LOCK = threading.RLock()          # guards _STREAM_POOL and _DEVICE_LOCKS
+_DEVICE_LOCKS = {}
+
+
+def device_lock(device=None):
+    """ONE lock per device for everything that warms up or captures on the device's shared ("capture", 0) / ("pipe", i) streams
+    (ChunkEngine.prepare, PipelinedEngines.prepare / capture_round / calibrate): two threads preparing engines on one GPU take turns
+    instead of recording into each other's graph.  Re-entrant: PipelinedEngines.prepare holds it around its engines'."""
+    dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    with _POOL_LOCK:
+        lk = _DEVICE_LOCKS.get(dev)
+        if lk is None:
+            lk = _DEVICE_LOCKS[dev] = threading.RLock()
+    return lk
 
 
 def candidate_streams(count=16, device=None):
     """up to `count` DISTINCT streams for the chunk pipelines to choose from (("pipe", 0 .. count-1) of the pool); stops early when
     torch's round-robin pool wraps around onto a stream this pool already holds"""
     dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
-    have = {st.cuda_stream for (d, _, _), st in _STREAM_POOL.items() if d == dev}
-    out = []
-    for j in range(int(count)):
-        key = (dev, "pipe", j)
-        st = _STREAM_POOL.get(key)
-        if st is None:
-            st = torch.cuda.Stream(device=dev)
-            if st.cuda_stream in have:
-                break                                    # wrapped around: no more distinct streams to be had
-            _STREAM_POOL[key] = st
-            have.add(st.cuda_stream)
-        out.append(st)
-    return out
+    with _POOL_LOCK:
+        have = {st.cuda_stream for (d, _, _), st in _STREAM_POOL.items() if d == dev}
+        out = []
+        for j in range(int(count)):
+            key = (dev, "pipe", j)
+            st = _STREAM_POOL.get(key)
+            if st is None:
+                st = torch.cuda.Stream(device=dev)
+                if st.cuda_stream in have:
+                    break                                    # wrapped around: no more distinct streams to be had
+                _STREAM_POOL[key] = st
+                have.add(st.cuda_stream)
+            out.append(st)
+        return out
 
 
 def pooled_stream(role, index=0, device=None):
     dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
     key = (dev, role, int(index))
-    st = _STREAM_POOL.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=dev)
-        _STREAM_POOL[key] = st
-    return st
+    with _POOL_LOCK:
+        st = _STREAM_POOL.get(key)
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            _STREAM_POOL[key] = st
+        return st
 
 
 class ChunkEngine:
@@ -73,7 +91,9 @@ class ChunkEngine:
         the capture.  `mask_stats()` reports the crop volumes and the mask-head FLOPs.
         shared_chip / brick_cap: the engine's DISPATCH REGIME (ops.dispatch_regime): every launch this engine makes -- warm-up, capture
         and eager passes alike -- is dispatched for a chip shared with other chunks' kernels / with the direct k3 kernel's brick capped.
-        An attribute of the engine, passed to the library per call: engines of different regimes can be prepared concurrently."""
+        An attribute of the engine, passed to the library per call (thread-local on the Python side): eager passes of engines of
+        different regimes may run concurrently from different threads.  prepare() itself -- warm-up and capture on the device's
+        shared capture stream -- is serialised per device (engine.device_lock): concurrent prepare() calls are safe, not parallel."""
         self.shared_chip, self.brick_cap = bool(shared_chip), int(brick_cap)
         # mailbox (r5): what changes per chunk -- the source of the input grid (pinned host or device memory), the chunk origin, the
         # row that receives the record block -- reaches the captured graph through a ring of slots in pinned host memory
@@ -191,6 +211,16 @@ class ChunkEngine:
         computes (stage_ahead); it must stay unchanged until that pass has run.  Ignored when it is not pinned host memory."""
         if self.mail is None:
             raise ops._lib.Sis3dError("submit() needs an engine built with mailbox=True")
+        # the upload kernel reads `n` floats from the raw pointer: a wrong-sized, strided or non-fp32 tensor would be an out-of-bounds
+        # read, not an exception (ADVICE r5)
+        want = self._sdf_stage.numel() if self.mail_input == "sdf" else self.scenes[0].numel()
+        if src is not None and ops.mail_source(src, want) is None:
+            raise ops._lib.Sis3dError("submit(): src must be a contiguous float32 tensor of %d elements on the device or in pinned host "
+                                      "memory (got %s)" % (want, "%s %s%s" % (tuple(src.shape), src.dtype, "" if src.is_contiguous() else " strided")
+                                                           if isinstance(src, torch.Tensor) else type(src).__name__))
+        if src is None and self.mail_input == "sdf":
+            raise ops._lib.Sis3dError("submit(): an engine with mail_input='sdf' encodes its input from the slot's source on every pass; "
+                                      "src=None would re-encode the previous chunk's SDF block over the input")
         if next_src is not None and (self._ahead is None or next_src.is_cuda or ops.mail_source(next_src, self._ahead.numel()) is None):
             next_src = None
         self._slot = (src, block_dst, origin, next_src)
@@ -221,7 +251,7 @@ class ChunkEngine:
 
     def prepare(self, warmup=2):
         """warm caches (weight repack, anchor tables) and capture the graph"""
-        with torch.no_grad():
+        with device_lock(self.device), torch.no_grad():
             self.net.eval()
             for _ in range(max(1, warmup)):
                 self.out = self._step()
@@ -413,15 +443,16 @@ class PipelinedEngines:
         """warm up and capture every pipeline, then (calibrate: default on for >= 2 captured pipelines, SIS3D_NO_AUTO_CALIBRATE=1 turns
         it off) choose the pipelines' streams by timing one pass of all pipelines on every window of the candidate streams -- ~40
         replays, tens of milliseconds; a caller with a more specific workload calls `calibrate(run_once)` again"""
-        for e, s in zip(self.engines, self.streams):
-            with torch.cuda.stream(s):
-                e.prepare(warmup)
-        torch.cuda.synchronize()
-        if calibrate is None:
-            import os
-            calibrate = os.environ.get("SIS3D_NO_AUTO_CALIBRATE", "0") in ("", "0")
-        if calibrate and len(self.engines) >= 2 and all(e.graph is not None for e in self.engines):
-            self.calibrate(self.run, reps=3, warm=1)
+        with device_lock(self.engines[0].device):
+            for e, s in zip(self.engines, self.streams):
+                with torch.cuda.stream(s):
+                    e.prepare(warmup)
+            torch.cuda.synchronize()
+            if calibrate is None:
+                import os
+                calibrate = os.environ.get("SIS3D_NO_AUTO_CALIBRATE", "0") in ("", "0")
+            if calibrate and len(self.engines) >= 2 and all(e.graph is not None for e in self.engines):
+                self.calibrate(self.run, reps=3, warm=1)
         return self
 
     def load(self, i, *a, wait=True, **kw):
@@ -598,7 +629,7 @@ class PipelinedEngines:
             raise ops._lib.Sis3dError("capture_round: engines of one chunk per graph only (group == 1)")
         main = pooled_stream("round", 0)
         main.wait_stream(torch.cuda.current_stream())
-        with torch.no_grad():
+        with device_lock(self.engines[0].device), torch.no_grad():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=main):
                 prev_ev = None

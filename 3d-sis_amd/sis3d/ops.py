@@ -376,10 +376,11 @@ class Mailbox(object):
         self.u32 = a.view(np.uint32).reshape(self.ring_size, self.SLOT // 4)
         # [0] consumed slots, [8..23] the slot of the running pass, [24..25] the source whose chunk the staging buffer holds
         self.state = torch.zeros(32, dtype=torch.int32, device=device)
-        self._progress_t = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._progress_t = torch.zeros(2, dtype=torch.int64).pin_memory()     # [0] consumed slots, [1] why the device rejected a slot
         self.progress = self._progress_t.numpy()
         self.head = 0                                  # slots written so far (the device has consumed progress[0] of them)
         self.keep = [None] * self.ring_size            # the tensors behind the pointers of the outstanding slots stay alive
+        self._released = 0                             # slots below this number have been consumed and released
         self._announced = 0                            # next_src of the slot written last
 
     def write(self, src=None, dst=None, origin=None, next_src=None):
@@ -387,6 +388,7 @@ class Mailbox(object):
         buffer already holds the chunk), dst = tensor that receives the pass's record block (None: nowhere), origin = (x, y, z),
         next_src = the PINNED HOST chunk of the pass after this one, if known: the piggyback row of this pass's longest conv launch
         pulls it into the staging buffer (sis3d_conv3d_k3wino_piggyback) -- the caller leaves it unchanged until that pass has run"""
+        self.check()
         if self.head - int(self.progress[0]) >= self.ring_size - 1:
             # the producer is a whole ring ahead of the device: wait for a slot (rare); a device that never consumes is an error
             import time
@@ -407,8 +409,31 @@ class Mailbox(object):
         self._announced = next_src.data_ptr() if (next_src is not None and not next_src.is_cuda) else 0
         self.u64[k, 4] = self._announced
         self.u32[k, 7] = flags
+        # integrity stamp (include/sis3d.h): sequence number + check word over the pointers, verified by the fetch kernel
+        self.u64[k, 5] = self.head
+        self.u64[k, 6] = self.check_word(int(self.u64[k, 0]), int(self.u64[k, 1]), self._announced, flags, self.head)
         self.keep[k] = (src, dst, next_src)
         self.head += 1
+        # the tensors behind CONSUMED slots are released (a streaming caller with freshly allocated chunks otherwise keeps
+        # ring_size chunks alive per pipeline); a consumed slot's next_src has been pulled or superseded by its successor's src
+        done = int(self.progress[0])
+        while self._released < done and self._released < self.head - 1:
+            self.keep[self._released % self.ring_size] = None
+            self._released += 1
+
+    @staticmethod
+    def check_word(src, dst, next_src, flags, seq):
+        m = (1 << 64) - 1
+        rotl = lambda v, r: ((v << r) | (v >> (64 - r))) & m
+        return (src ^ rotl(dst, 17) ^ rotl(next_src, 31) ^ ((flags << 40) & m) ^ ((seq * 0x9E3779B97F4A7C15) & m) ^ 0x5151D3D3) & m
+
+    def check(self):
+        """raise if the device has rejected a slot (stale / lapped: 1, torn: 2); the pass that fetched it copied nothing"""
+        e = int(self.progress[1])
+        if e:
+            raise _lib.Sis3dError("mailbox: the device rejected a slot (%s); %d written, %d consumed"
+                                  % ({1: "stale or lapped sequence number", 2: "check word mismatch"}.get(e, "code %d" % e), self.head,
+                                     int(self.progress[0])))
 
 
 def mail_source(t, numel):

@@ -52,7 +52,14 @@ class SceneResult(object):
             if self._done is not None:
                 self._done.synchronize()
                 # later work of the caller's stream that touches the tables is ordered behind the merge
-                torch.cuda.current_stream().wait_event(self._done)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(self._done)
+                # ... and the tables were ALLOCATED on the merge stream: tell the caching allocator that the caller's stream uses them
+                # too, or the blocks go back to the merge stream's pool when the caller drops its slices and the next scene's merge
+                # (already enqueued in lazy mode) may overwrite them under a kernel of the caller's that is still reading
+                for t in (self.recs, self.order, self.keep, self.counts):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
             total, kept = self.counts.tolist()
             out = (self.recs[:total], self.keep[:kept])
             if self.with_chunk_ids:
@@ -136,6 +143,12 @@ class SceneRunner:
             b = self._scene_no & 1
             self._scene_no += 1
             if self._sends[b] is None or self._sends[b].shape[0] != max(1, len(mine)):
+                old = self._sends[b]
+                if old is not None:
+                    # the buffer being replaced may still be read by the gather of the scene before last (on `post`) and written by
+                    # the pipelines: keep its block out of the allocator's hands until those streams have passed this point
+                    for st in list(self.pipes.streams) + [post]:
+                        old.record_stream(st)
                 self._sends[b] = torch.zeros(max(1, len(mine)), bf, device=dev)
                 self._consumed[b] = None
             send = self._sends[b]

@@ -186,7 +186,12 @@ int sis3d_upload_f32(const float *src_host_mapped, float *dst, int64_t n, int wo
  * until that graph drains -- an upload kernel, a hipMemcpyAsync, even the 12-byte copy of a chunk origin (profiles/r05_feed_probe.txt:
  * 0.16 -> 1.45 ms of host time per step, bimodal).  A pipeline that replays a captured graph per chunk therefore takes everything
  * that changes from chunk to chunk through a ring of 64-byte slots in PINNED host memory, which kernels INSIDE the graph read:
- *     slot = { u64 src; u64 dst; f32 origin[3]; u32 flags; u64 next_src; u64 pad[3] }
+ *     slot = { u64 src; u64 dst; f32 origin[3]; u32 flags; u64 next_src; u64 seq; u64 check; u64 pad }
+ *     seq = number of slots written before this one; check = src ^ rotl(dst, 17) ^ rotl(next_src, 31) ^ (flags << 40)
+ *           ^ (seq * 0x9E3779B97F4A7C15) ^ 0x5151D3D3 (r6): sis3d_mail_fetch accepts a slot only if seq == state[0] (a stale or lapped
+ *           slot carries another number) and the check word matches (a torn slot); a rejected slot is parked with its pointers
+ *           zeroed -- the pass runs on whatever the input buffer holds and copies nothing out -- and the reason (1 stale / lapped,
+ *           2 torn) goes to state[1] (sticky) and, with the next post, to progress[1]
  *     flags bit 0: origin valid, bit 1: src is DEVICE memory, bit 2: src was the next_src of the PREVIOUS slot and has not changed since;
  *     next_src: the chunk of the pipeline's NEXT pass (0 = unknown) -- the extra row of workgroups of sis3d_conv3d_k3wino_piggyback
  *     pulls it into a staging buffer while this pass computes, and records whose chunk the buffer holds in state[24..25]
@@ -201,9 +206,9 @@ int sis3d_upload_f32(const float *src_host_mapped, float *dst, int64_t n, int wo
  *                      previous pass already pulled this chunk across the link.  Replaces `blobs['data'].cuda()`
  *                      (lib/nets/network.py:191).
  *   sis3d_mail_post    last node: copies n floats of `block_src` (the chunk's record block) to the slot's dst (0 = nowhere) and
- *                      consumes the slot: state[0] = k + 1, *progress = k + 1 (pinned host word the producer polls before it laps
- *                      the ring).
- * state: 32 uint32 of device memory, zero-initialised, owned by the pipeline. */
+ *                      consumes the slot: state[0] = k + 1, progress[0] = k + 1 (pinned host word the producer polls before it laps
+ *                      the ring), progress[1] = state[1] when a slot was rejected.
+ * state: 32 uint32 of device memory, zero-initialised, owned by the pipeline.  progress: TWO uint64 of pinned host memory. */
 int sis3d_mail_fetch(const void *ring_host_mapped, int ring_size, uint32_t *state, sis3d_stream_t stream);
 int sis3d_mail_upload(const uint32_t *state, float *input_dst, int64_t n, float *origin_dst, const float *staged, int workgroups,
                       sis3d_stream_t stream);

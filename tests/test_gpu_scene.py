@@ -612,3 +612,89 @@ def test_stage_ahead_pulls_the_next_chunk_and_changes_nothing(full, monkeypatch)
         for k in range(12):
             assert torch.equal(rows[k], want[cids[k % 5]]), (use_graph, "back to back", k)
     print("[parity] stage-ahead upload (full=%s): staged / mis-announced / device / unannounced chunks all bit-identical to resident passes" % full)
+
+
+def test_mailbox_rejects_stale_and_torn_slots_and_validates_sources():
+    """r6 hardening: the fetch kernel accepts a slot only with the right sequence number and check
+    word -- a replay without a fresh slot (stale) or a slot with a flipped pointer bit (torn) copies NOTHING and the producer raises;
+    submit() refuses sources the upload kernel would read out of bounds; consumed slots release their tensors"""
+    import pytest as _pytest
+    from sis3d import _lib
+    from sis3d.engine import ChunkEngine
+    net, cfg = _small_net()
+    dims = (48, 24, 40)
+    eng = ChunkEngine(net, dims=dims, stage="detect", mailbox=True, mail_ring=8).prepare()
+    g = synthetic.synth_chunk(7, dims).cuda()
+    row = torch.zeros(eng.out["block"].numel(), device="cuda")
+    eng.submit(src=g, block_dst=row, origin=(1.0, 2.0, 3.0))
+    torch.cuda.synchronize()
+    good = row.clone()
+    assert good.abs().sum() > 0
+    mb = eng.mail
+    assert int(mb.progress[1]) == 0
+    # consumed slots do not pin their tensors (all but the newest slot of the ring)
+    assert sum(k is not None for k in mb.keep) <= 1
+    # sources the upload kernel must not be handed
+    for bad in (g.view(-1)[:-4], g.double(), g.permute(0, 1, 4, 3, 2)):
+        with _pytest.raises(_lib.Sis3dError):
+            eng.submit(src=bad, block_dst=row)
+    # STALE: the graph replayed without a new slot -> the fetch sees the previous slot's sequence number
+    row.zero_()
+    eng.graph.replay()
+    torch.cuda.synchronize()
+    assert int(mb.progress[1]) == 1 and float(row.abs().sum()) == 0.0, "a stale slot must not be acted on"
+    with _pytest.raises(_lib.Sis3dError):
+        mb.check()
+    # TORN: a slot whose destination pointer lost a bit after the stamp was computed
+    eng2 = ChunkEngine(net, dims=dims, stage="detect", mailbox=True, mail_ring=8).prepare()
+    mb2 = eng2.mail
+    row2 = torch.zeros_like(row)
+    mb2.write(src=g, dst=row2, origin=(1.0, 2.0, 3.0))
+    k = (mb2.head - 1) % mb2.ring_size
+    mb2.u64[k, 1] ^= 0x40                                       # plain CPU store into the pinned ring, as a racing writer would
+    eng2.graph.replay()
+    torch.cuda.synchronize()
+    assert int(mb2.progress[1]) == 2 and float(row2.abs().sum()) == 0.0
+    with _pytest.raises(_lib.Sis3dError):
+        mb2.write(src=g, dst=row2)
+    print("[parity] mailbox: stale slot -> code 1, torn slot -> code 2, nothing copied; submit() rejects 3 malformed sources")
+
+
+def test_two_threads_prepare_engines_on_one_gpu():
+    """prepare() warms up and captures on the device's shared capture stream -- two threads doing it at once used to
+    record into each other's graph.  Serialised by engine.device_lock: both engines capture, both replay their own chunk."""
+    import threading
+    from sis3d.engine import ChunkEngine
+    dims = (48, 24, 40)
+    nets = [_small_net()[0], _small_net()[0]]
+    engs = [ChunkEngine(nets[i], dims=dims, stage="detect", shared_chip=bool(i)) for i in range(2)]
+    grids = [synthetic.synth_chunk(70 + i, dims).cuda() for i in range(2)]
+    for e, g in zip(engs, grids):
+        e.load(g)
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            start.wait()
+            engs[i].prepare()
+        except Exception as ex:                                 # pragma: no cover
+            errors.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert all(e.graph is not None for e in engs)
+    blocks = [e.run()["block"].clone() for e in engs]
+    torch.cuda.synchronize()
+    # each graph is the engine's own pass: the same chunk through a freshly prepared engine of the same regime gives the same block
+    for i in range(2):
+        ref = ChunkEngine(nets[i], dims=dims, stage="detect", shared_chip=bool(i))
+        ref.load(grids[i])
+        ref.prepare()
+        assert torch.equal(ref.run()["block"], blocks[i]), i
+    assert not torch.equal(blocks[0], blocks[1])

@@ -40,9 +40,8 @@ def four_streams(fn, n=4):
     """capture fn() on each of n streams -> step() replaying all of them"""
     streams = [torch.cuda.Stream() for _ in range(n)]
     graphs = []
-    ops.lib().sis3d_conv3d_k3wino_set_shared_chip(1)
-    ops.lib().sis3d_conv3d_k3t16_set_brick_cap(108)
-    try:
+    # r5 ABI: the dispatch regime is a per-call argument of the library / a thread-local value on the Python side
+    with ops.dispatch_regime(shared_chip=True, brick_cap=108):
         for s in streams:
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s), torch.no_grad():
@@ -53,9 +52,6 @@ def four_streams(fn, n=4):
                     fn()
                 graphs.append(g)
         torch.cuda.synchronize()
-    finally:
-        ops.lib().sis3d_conv3d_k3wino_set_shared_chip(0)
-        ops.lib().sis3d_conv3d_k3t16_set_brick_cap(0)
 
     def step():
         for g, s in zip(graphs, streams):

@@ -54,7 +54,7 @@ def main():
         xs = [ops.new_act(cin, dims, dev).normal_().clamp_(min=0) for _ in range(nprob)]
         pcs = [ops.PackedConv(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05, torch.zeros(cout, device=dev)) for _ in range(nprob)]
         fl = nprob * 2.0 * dims[0] * dims[1] * dims[2] * cout * cin * 27
-        auto = ops.lib().sis3d_conv3d_k3t16_brick(dims[0], dims[1], dims[2], cin, cout, nprob)
+        auto = ops.lib().sis3d_conv3d_k3t16_brick(dims[0], dims[1], dims[2], cin, cout, nprob, ops.regime()[1])      # r5 ABI: max_voxels = the thread's brick cap
         for b in sorted(BRICKS):
             us = timeit(lambda: ops.conv3d_k3t16(xs, pcs, relu=True, brick=b))
             print("%-8s x%d brick %-7s %s %8.1f us  %6.1f TF  (%.0f %% of 157.3)" % (key, nprob, BRICKS[b], "*" if b == auto else " ", us,
