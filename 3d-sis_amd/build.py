@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "sis3d", "libsis3d_hip.so")
 OBJ = os.path.join(HERE, "build")
 
 EXACT = ["nms.hip", "roi_pool.hip", "projection.hip", "frustum.hip", "proposal.hip", "pool_misc.hip", "api.hip", "topk.hip"]
-FAST = ["conv3d.hip", "conv3d_wino.hip", "conv3d_t16.hip", "conv3d_b16.hip", "bottleneck.hip", "pointwise.hip", "mlp.hip", "mlp16.hip", "enet.hip", "proj_sparse.hip"]
+FAST = ["conv3d.hip", "conv3d_wino.hip", "conv3d_t16.hip", "bottleneck.hip", "pointwise.hip", "mlp.hip", "mlp16.hip", "enet.hip", "proj_sparse.hip"]
 
 
 def _newer(src, dst):

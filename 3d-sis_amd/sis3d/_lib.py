@@ -75,12 +75,6 @@ SIGNATURES = {
     "sis3d_rpn_heads": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int,
                                 c_int, c_vp]),
     "sis3d_conv3d_k3t16_set_trace": (c_int, [c_vp, c_int]),
-    "sis3d_conv_k3b16_packed_floats": (c_sz, [c_int, c_int]),
-    "sis3d_conv_k3b16_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
-    "sis3d_conv3d_k3b16_set_trace": (c_int, [c_vp, c_int]),
-    "sis3d_ragged_tiling_k3b16": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "sis3d_conv3d_k3b16_ragged": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp]),
-    "sis3d_conv3d_k3b16": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     "sis3d_conv_k3t16_packed_floats": (c_sz, [c_int, c_int]),
     "sis3d_conv_k3t16_pack_weight": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "sis3d_conv3d_k3wino_prefer": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -672,8 +672,6 @@ def conv3d_k3t16(xs, pcs, relu=True, outs=None, out_coff=0, brick=None):
     _, cin_t, X, Y, Z = x0.shape
     if cin_t != p0.cin:
         raise _lib.Sis3dError("conv3d_k3t16: activation has %d channels, packed weight expects %d" % (cin_t, p0.cin))
-    if SPLIT_BF16 and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs):
-        return conv3d_k3b16(xs, pcs, None, relu=relu, outs=outs, out_coff=out_coff)
     if WINOGRAD and brick is None and all(getattr(pc, "_w", None) is not None for pc in pcs) and \
             lib().sis3d_conv3d_k3wino_prefer(X, Y, Z, p0.cin, p0.cout, n, int(regime()[0])):
         try:
@@ -789,54 +787,6 @@ def conv3d_k3wino(xs, pcs, relu=True, outs=None, out_coff=0):
     return outs
 
 
-# set_split_bf16() / SIS3D_SPLIT_BF16=1: route the balanced k3 convs (conv3d_k3t16 calls) through the split-bf16 kernel
-SPLIT_BF16 = bool(int(_os.environ.get("SIS3D_SPLIT_BF16", "0") or 0))
-
-
-def set_split_bf16(on):
-    """OPT-IN numerics switch (default off = exact fp32): the k3 convs that run on conv3d_k3t16 -- rpn_net_level*, geometry2[0],
-    Bottleneck.conv2 of the unfused blocks -- take csrc/conv3d_b16.hip instead (bf16 matrix pipe, operands split hi + lo, three
-    products, fp32 accumulate: ~5e-6 of the output scale per layer, tests/test_gpu_conv_b16.py).  Read at launch / capture time."""
-    global SPLIT_BF16
-    SPLIT_BF16 = bool(on)
-
-
-def packed_b16(pc, weight=None):
-    """split-bf16 fragment pack of a k3 PackedConv's weight (sis3d_conv_k3b16_pack_weight), built on first use"""
-    if getattr(pc, "_packed_b16", None) is None:
-        weight = pc._w if weight is None else weight
-        w = _dev(weight.detach(), "weight").contiguous()
-        if w.shape[1] != pc.cin:
-            raise _lib.Sis3dError("split-bf16 conv: cin must be a multiple of 32")
-        n = lib().sis3d_conv_k3b16_packed_floats(pc.cout, pc.cin)
-        if n == 0:
-            raise Sis3dUnsupported("split-bf16 conv: cin % 32 != 0")
-        pc._packed_b16 = torch.empty(n, device=w.device)
-        check(lib().sis3d_conv_k3b16_pack_weight(_ptr(w), pc.cout, pc.cin, _ptr(pc._packed_b16), _stream()), "sis3d_conv_k3b16_pack_weight")
-    return pc._packed_b16
-
-
-def conv3d_k3b16(xs, pcs, weights=None, relu=True, outs=None, out_coff=0, brick=-1):
-    """OPTIONAL split-bf16 variant of conv3d_k3t16 (csrc/conv3d_b16.hip): same shapes and layouts, ~2^-16 relative error per
-    product instead of exact fp32.  weights: the fp32 nn.Conv3d weights the PackedConvs were made from."""
-    n = len(xs)
-    x0, p0 = xs[0], pcs[0]
-    _, cin_t, X, Y, Z = x0.shape
-    if outs is None:
-        outs, out_coff = [new_act(p0.cout, (X, Y, Z), x0.device) for _ in range(n)], 0
-    arr = ctypes.c_void_p * n
-    ins = arr(*[x.data_ptr() for x in xs])
-    wps = arr(*[packed_b16(pc, w).data_ptr() for pc, w in zip(pcs, weights or [None] * n)])
-    bs = arr(*[pc.bias.data_ptr() for pc in pcs]) if p0.bias is not None else None
-    os_ = arr(*[o.data_ptr() for o in outs])
-    rc = lib().sis3d_conv3d_k3b16(n, ins, X, Y, Z, p0.cin, cin_t, wps, bs, p0.cout, EPI_RELU if relu else 0, os_, outs[0].shape[1],
-                                  int(out_coff), int(brick), _stream())
-    if rc == -4:
-        raise Sis3dUnsupported("conv3d_k3b16: unsupported shape")
-    check(rc, "sis3d_conv3d_k3b16")
-    return outs
-
-
 BNECK_WINO = _os.environ.get("SIS3D_BNECK_WINO", "1") != "0"     # A/B switch: planes-32 Bottleneck bodies on the Winograd kernel (default on)
 BNECK_SPLIT = bool(_os.environ.get("SIS3D_BNECK_SPLIT"))  # A/B switch: Bottleneck body as k3t16 + pointwise launches
 
@@ -882,10 +832,6 @@ def bottleneck16(y1, pc2, pc3, residual, out=None, out_coff=0, stage=None, brick
         raise Sis3dUnsupported("no fused Bottleneck pack")
     if not is_cl(y1) or not is_cl(residual):
         raise _lib.Sis3dError("bottleneck16 expects channels-last activations")
-    if SPLIT_BF16 and y1.shape[2] * y1.shape[3] * y1.shape[4] >= 32768:
-        # split-bf16 mode: on the 48x24x48 maps conv2 on the bf16 pipe + the pointwise launch (15.6 + 9 us) beat the fused fp32
-        # body (31-34 us); the small-grid blocks stay on the fused kernel
-        raise Sis3dUnsupported("split-bf16 mode: two-launch Bottleneck body")
     _, pl, X, Y, Z = y1.shape
     od = (X, Y, Z)
     if (pc2.cin, pc2.cout, pc2.k, pc3.cin, pc3.k) != (pl, pl, 3, pl, 1) or tuple(residual.shape[2:]) != od or residual.shape[1] != pc3.cout:
@@ -1088,7 +1034,7 @@ class PackedConv:
                   "sis3d_conv_pw16_pack_weight")
         # second pack for the balanced k3 kernel (csrc/conv3d_t16.hip): [cout/16][cin/32][4][27][64][2]
         self.packed_t16 = None
-        self._w = w if k == 3 else None                       # kept for the Winograd pack (packed_wino) and the optional split-bf16 pack
+        self._w = w if k == 3 else None                       # kept for the Winograd pack (packed_wino)
         if k == 3 and self.cin % 32 == 0 and self.cout % 4 == 0 and not K3_LEGACY:
             nt = lib().sis3d_conv_k3t16_packed_floats(self.cout, self.cin)
             self.packed_t16 = torch.empty(nt, device=w.device)
@@ -1489,21 +1435,6 @@ class MaskPlan:
             d3m["out_off"] = voffs[:-1] * C
             self.items_mini = int(blm[-1])
             self.wino_mini = self.wino and self.items_mini < self.blocks_wino
-        # the same layers on the opt-in split-bf16 kernel (csrc/conv3d_b16.hip): 3x6x6 bricks, two cout tiles per workgroup
-        self.b16, self.brick_b16, self.blocks_b16 = False, 4, 0
-        d3b = np.zeros(0, dtype=rdt)
-        tb = [ctypes.c_int() for _ in range(4)]
-        if C % 32 == 0 and lib().sis3d_ragged_tiling_k3b16(C, C, self.brick_b16, *[ctypes.byref(v) for v in tb]) == 0:
-            bbx, bby, bbz, bng = (v.value for v in tb)
-            nbb = -(-ext // np.array([bbx, bby, bbz]))
-            blb = np.concatenate([[0], np.cumsum(nbb.prod(1) * bng)])
-            d3b = np.zeros(n, dtype=rdt)
-            d3b["X"], d3b["Y"], d3b["Z"] = ext[:, 0], ext[:, 1], ext[:, 2]
-            d3b["nbx"], d3b["nby"], d3b["nbz"] = nbb[:, 0], nbb[:, 1], nbb[:, 2]
-            d3b["block0"] = blb[:-1]
-            d3b["in_off"] = voffs[:-1] * C
-            d3b["out_off"] = voffs[:-1] * C
-            self.b16, self.blocks_b16 = True, int(blb[-1])
         dp["x0"], dp["y0"], dp["z0"] = w[:, 0], w[:, 1], w[:, 2]
         dp["dx"], dp["dy"], dp["dz"] = ext[:, 0], ext[:, 1], ext[:, 2]
         dp["t0"] = voffs[:-1] * (C // 4)
@@ -1513,7 +1444,7 @@ class MaskPlan:
         self.windows = [tuple(int(v) for v in r) for r in w]
         # ONE upload for the three descriptor tables (each is a blocking pageable copy)
         parts = [d3.view(np.uint8).reshape(-1), d1.view(np.uint8).reshape(-1), dp.view(np.uint8).reshape(-1),
-                 d3t.view(np.uint8).reshape(-1), d3b.view(np.uint8).reshape(-1), d3w.view(np.uint8).reshape(-1),
+                 d3t.view(np.uint8).reshape(-1), np.zeros(0, dtype=np.uint8), d3w.view(np.uint8).reshape(-1),
                  d3m.view(np.uint8).reshape(-1)]
         pad = [(-p.size) % 16 for p in parts]
         host = np.concatenate([np.concatenate([p, np.zeros(q, np.uint8)]) for p, q in zip(parts, pad)])
@@ -1525,7 +1456,7 @@ class MaskPlan:
         self.g3, self.g1, self.gp = self.devbuf[:o1], self.devbuf[o1:o2], self.devbuf[o2:o3]
         o5 = o4 + parts[4].size + pad[4]
         o6 = o5 + parts[5].size + pad[5]
-        self.g3t, self.g3b, self.g3w, self.g3m = self.devbuf[o3:o4], self.devbuf[o4:o5], self.devbuf[o5:o6], self.devbuf[o6:]
+        self.g3t, self.g3w, self.g3m = self.devbuf[o3:o4], self.devbuf[o5:o6], self.devbuf[o6:]       # (part 4 was the split-bf16 table, removed in r6)
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
         self.out = torch.empty(self.voxels, NC, device=device)
@@ -1553,10 +1484,7 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
           "sis3d_conv3d_planar2_ragged")
     src, dst = plan.a, plan.b
     for pc in pcs:
-        if SPLIT_BF16 and plan.b16 and getattr(pc, "_w", None) is not None:
-            check(lib().sis3d_conv3d_k3b16_ragged(_ptr(src), C, C, _ptr(packed_b16(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
-                                                  _ptr(plan.g3b), n, plan.blocks_b16, plan.brick_b16, _stream()), "sis3d_conv3d_k3b16_ragged")
-        elif WINOGRAD and plan.wino_mini and getattr(pc, "_w", None) is not None:
+        if WINOGRAD and plan.wino_mini and getattr(pc, "_w", None) is not None:
             check(lib().sis3d_conv3d_k3wino_ragged_mini(_ptr(src), C, C, _ptr(packed_wino(pc)), _ptr(pc.bias), C, EPI_RELU, _ptr(dst), C,
                                                         _ptr(plan.g3m), n, plan.items_mini, _stream()), "sis3d_conv3d_k3wino_ragged_mini")
             _tally_wino(2.0 * plan.voxels * C * C * 27)

@@ -50,28 +50,11 @@ sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
 # runtime when it initialises, i.e. before torch is imported anywhere below; an integrator sets the same variable in his launcher.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-VOXELS = 96 * 48 * 96
-# algorithmic work per chunk
-BACKBONE = dict(bytes=201.6e6, flops=17.72e9)
-RPN = dict(bytes=59.8e6, flops=24.86e9)
-ALGO = {
-    "backbone_rpn": dict(bytes=261.4e6, flops=42.58e9),
-    "detect": dict(bytes=261.4e6 + 2 * 3.54e6 + 200 * 32768 + 8.4e6, flops=42.58e9 + 0.9e9),
-    "images": dict(bytes=517e6 + 28.3e6 + 59.8e6 + 226.5e6, flops=29.1e9 + 24.86e9),
-    "scene": dict(bytes=261.4e6 + 2 * 3.54e6 + 200 * 32768 + 8.4e6, flops=42.58e9 + 0.9e9),
-}
-DOMINANT_FLOPS = 2.0 * 6912 * 256 * 128 * 27        # rpn_net_level{1,2}: 12.23 GFLOP per launch (ALGORITHMIC = direct-convolution count)
-WINOGRAD_REDUCTION = 27 * 8 / 64.0                  # F(2x2x2, 3x3x3): 64 products per 2x2x2 output block instead of 216
-FP32_PEAK_TF = 157.3
-HBM_PEAK_GBS = 8000.0
-WORKLOAD_TEXT = {
-    "backbone_rpn": "config[1]: one 96x48x96 chunk per pipeline, geometry-only, HIP 3D-conv backbone + RPN (convs, heads, "
-                    "softmax), weights seeded synthetic",
-    "detect": "config[2]: backbone + RPN + decode/sort/NMS + RoI pooling + classifier",
-    "images": "config[3]: 5-view back-projection gather + colour/geometry backbone + RPN",
-    "scene": "config[4]: 32-chunk scene sharded chunk->rank, per-chunk detection, one RCCL all-gather of record blocks, "
-             "whole-scene 3D NMS on every rank",
-}
+from benchlib.constants import *  # noqa: E402,F401,F403
+from benchlib.launch import free_port, launch_command, self_launch, emit  # noqa: E402,F401
+from benchlib.roofline import (time_dominant_kernel, executed_flops, wino_accounting, time_stages, pmc_traffic, live_pmc_traffic,  # noqa: E402,F401
+                               roofline_entry, fracs_above_one, DOMINANT_BYTES)
+from benchlib.cpu_baseline import cpu_model, cpu_threads_rule, _median_runs, cpu_baseline_reference, cpu_baseline  # noqa: E402,F401
 
 
 def parse(argv=None):
@@ -102,8 +85,6 @@ def parse(argv=None):
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE) over the "
                     "dominant kernel at the end of an N = 1 run; `roofline.traffic` then is the committed figure of profiles/")
-    ap.add_argument("--split-line", action="store_true", help="also time the opt-in split-bf16 variant of the k3 convs (separately "
-                    "reported, never the headline; off by default since r5: it does not beat the exact-fp32 path in throughput)")
     ap.add_argument("--no-calibrate", action="store_true", help="keep the pipelines on the first streams of the pool instead of choosing "
                     "the window of streams by measurement (PipelinedEngines.calibrate / SceneRunner.calibrate)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the streamed-input variants (fresh chunks from pinned host memory)")
@@ -111,52 +92,13 @@ def parse(argv=None):
                     "images_rgb sub-objects (BASELINE configs[2], [3])")
     ap.add_argument("--no-side-workloads", action="store_true", help="time only the headline workload (no chunk_pipeline / scene side keys)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dump-scene", default=None, help="scene workload: rank 0 writes the gathered record table and the whole-scene "
+                                                       "keep list of the last timed scene to this .npz (tests/test_gpu_multi.py)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # launch / rendezvous logic under gloo, no GPU
     return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------ launching N ranks --
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def launch_command(n, argv, port=None):
-    """the command that starts n ranks of this script on this node (one per GPU, rendezvous on the loopback address)"""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
-
-
-def self_launch(args, argv):
-    """`python bench.py --gpus N` without a launcher: check the box, then start the N ranks ourselves"""
-    if not args.selftest_cpu:
-        import torch
-        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if os.environ.get("SIS3D_BENCH_SHARE_GPU") and have >= 1:
-            have = args.gpus        # functional test hook: every rank on GPU 0, gloo instead of RCCL (see main())
-        if have < args.gpus:
-            sys.stderr.write("bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to run a smaller world\n"
-                             % (args.gpus, have))
-            return 2
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16) // args.gpus))))
-    return subprocess.call(launch_command(args.gpus, argv), env=env)
-
-
-def emit(line):
-    """the JSON line must be the LAST thing on stdout: RCCL printf()s a version banner into C stdio's buffer, which would
-    otherwise be flushed at exit, after our line"""
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
-    print(json.dumps(line), flush=True)
 
 
 def scene_origin(c, stride):
@@ -263,397 +205,6 @@ def build_net(workload, masks=False, rgb=False):
     return net.cuda().eval(), cfg, sd
 
 
-def time_dominant_kernel(net, iters=50):
-    """mean duration of the rpn_net k3 128->256 conv launch (12.23 algorithmic GFLOP; the default route is the fp32 Winograd kernel,
-    ops.set_winograd(False) = the direct fp32 MFMA kernel), HIP events on the launch (current) stream.
-    Runs before any graph is captured, on its own input, so the timed launches have the chip to themselves.  (The round-1/2 fault of
-    "eager launches between graph replays" was a HIP-graph memset node, removed in round 3: DESIGN.md section 7.)"""
-    import torch
-    from sis3d import ops
-    x = ops.new_act(128, (24, 12, 24), torch.device("cuda"))
-    x.normal_().clamp_(min=0)                      # post-ReLU-like activations
-    conv = net.rpn_net_level1
-    for _ in range(100):                           # bring the clocks up: measured cold the same launch is ~10 % slower
-        conv(x)
-    torch.cuda.synchronize()
-    # five batches of `iters` back-to-back launches, HIP events around each batch; the MEDIAN batch mean is reported (a single
-    # batch swings 96-106 us with the box's clock state; the rocprofv3 trace of the same launches is in profiles/)
-    means = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            conv(x)
-        e1.record()
-        torch.cuda.synchronize()
-        means.append(e0.elapsed_time(e1) / iters * 1e-3)
-    return sorted(means)[len(means) // 2]
-
-
-def executed_flops(algorithmic, wino_algorithmic):
-    """FLOPs the matrix pipe executes: layers on the Winograd kernel issue 64 products per 2x2x2 output block instead of 216"""
-    return algorithmic - wino_algorithmic * (1.0 - 1.0 / WINOGRAD_REDUCTION)
-
-
-def wino_accounting(net, shared=False):
-    """ALGORITHMIC FLOPs of the launches that take the Winograd kernel, in the backbone proper and in backbone + RPN of one chunk:
-    one eager pass of each with ops.flop_tally on (whatever the dispatch rule sends there today is what gets counted).  shared: count
-    under the shared-chip dispatch (ops.dispatch_regime(shared_chip=True)), which is what pipelines of several chunks in flight capture --
-    more layers take the Winograd kernel there, so fewer FLOPs are executed."""
-    import torch
-    from sis3d import ops, synthetic
-    scene = synthetic.synth_chunk(0).cuda().float()
-    out = {}
-    with torch.no_grad(), ops.dispatch_regime(shared_chip=shared, brick_cap=(108 if shared else 0)):
-        for name, fn in (("backbone", net.backbone_only), ("backbone_rpn", net.backbone_rpn)):
-            ops.flop_tally(True)
-            try:
-                fn(scene)
-            finally:
-                out[name] = ops.flop_tally(False)["wino_algorithmic_flops"]
-    torch.cuda.synchronize()
-    return out
-
-
-def time_stages(net, wino, reps=60):
-    """ONE chunk alone on the GPU: captured graph of the backbone proper and of backbone+RPN, `reps` back-to-back replays
-    on one stream bracketed by HIP events -> ms per chunk.  The difference is the RPN (convs + heads + softmax)."""
-    import torch
-    from sis3d import synthetic
-    from sis3d.engine import ChunkEngine
-    out = {}
-    data = synthetic.synth_chunk(0)
-    for stage in ("backbone", "rpn"):
-        eng = ChunkEngine(net, stage=stage)
-        eng.load(data)
-        eng.prepare(warmup=2)
-        for _ in range(10):
-            eng.run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            eng.run()
-        e1.record()
-        torch.cuda.synchronize()
-        out[stage] = e0.elapsed_time(e1) / reps
-        del eng
-    b, full = out["backbone"], out["rpn"]
-    r = max(full - b, 1e-6)
-    wb, wf = wino["backbone"], wino["backbone_rpn"]
-
-    def frac(ms, algo, wino_flops):
-        ex = executed_flops(algo["flops"], wino_flops)
-        return {"ms": ms, "fp32_frac": ex / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
-                "executed_gflop": ex / 1e9, "algorithmic_tflops": algo["flops"] / (ms * 1e-3) / 1e12,
-                "hbm_frac": algo["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "voxels_per_s": VOXELS / (ms * 1e-3)}
-    return {"backbone": dict(frac(b, BACKBONE, wb), algo_gflop=BACKBONE["flops"] / 1e9, algo_mb=BACKBONE["bytes"] / 1e6),
-            "rpn": dict(frac(r, RPN, wf - wb), algo_gflop=RPN["flops"] / 1e9, algo_mb=RPN["bytes"] / 1e6),
-            "backbone_rpn": frac(full, ALGO["backbone_rpn"], wf),
-            "how": "one chunk alone: captured graph, %d back-to-back replays on one stream, HIP events; rpn = backbone_rpn - backbone; "
-                   "fp32_frac = EXECUTED MFMA FLOPs / time / 157.3 TF (layers on the Winograd kernel issue their algorithmic count / "
-                   "3.375: executed_gflop; counted per launch by ops.flop_tally in one eager pass), algorithmic_tflops = the "
-                   "direct-convolution count / time (not a fraction of the roof); hbm_frac is against 8 TB/s with the algorithmic "
-                   "bytes; the binding roof is fp32 MFMA" % reps}
-
-
-PMC_FILES = {True: ("r02_pmc_rpn_net.json", "r01_pmc_rpn_net.json"),
-             False: ("r05_pmc_rpn_net_winograd.json", "r04_pmc_rpn_net_winograd.json", "r03_pmc_rpn_net_winograd.json")}
-DOMINANT_BYTES = (6912 * 128 + 6912 * 256 + 256 * 128 * 27) * 4.0      # in + out + weights once: 14.16 MB per launch (SURVEY 8d)
-
-
-def pmc_traffic(direct=False):
-    """(HBM bytes per launch of the dominant kernel, file it comes from): the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, KB -> B).  Counters cannot be read from inside the bench: the figure belongs to the round and the
-    kernel revision the file names, NOT to this run."""
-    for name in PMC_FILES[bool(direct)]:
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name
-        except Exception:
-            continue
-    return None, None
-
-
-def live_pmc_traffic(timeout_s=90):
-    """HBM bytes per launch of the dominant kernel measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE -- each in its
-    own pass, with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over 40 eager launches of the rpn_net layer (tools/wino_pmc.py), as
-    child processes of rank 0 after the timed regions.  -> (bytes | None, dict describing the collection)."""
-    import csv
-    import glob
-    import shutil
-    import tempfile
-    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(rp):
-        return None, {"error": "rocprofv3 not found"}
-    vals, info = {}, {"tool": "rocprofv3 --kernel-trace --pmc <counter> -- python tools/wino_pmc.py rpn", "launches": 40}
-    env = dict(os.environ, TMPDIR="/tmp")
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="sis3d_pmc_", dir="/tmp")
-        try:
-            subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
-                            os.path.join(ROOT, "tools", "wino_pmc.py"), "rpn"], cwd="/tmp", env=env, timeout=timeout_s,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            v = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if "k3wino" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
-                        v.append(float(r["Counter_Value"]))
-            if not v:
-                return None, dict(info, error="no %s rows for the Winograd kernel" % ctr)
-            v.sort()
-            vals[ctr] = v[len(v) // 2]
-        except Exception as e:
-            return None, dict(info, error="%s pass: %s: %s" % (ctr, type(e).__name__, e))
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    info.update({"FETCH_SIZE_KB_median": vals["FETCH_SIZE"], "WRITE_SIZE_KB_median": vals["WRITE_SIZE"],
-                 "formula": "2 x FETCH_SIZE (gfx950: the counter takes 64 B per 128 B request) + WRITE_SIZE, KB -> B"})
-    return int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024), info
-
-
-def roofline_entry(kt, kt_direct, winograd):
-    """Dominant kernel against the fp32 MFMA roof.  `frac` / `achieved` / `flops_per_launch` are the FLOPs the matrix pipe EXECUTES
-    (what a roofline fraction means: <= 1 by construction).  The Winograd kernel issues 3.375x fewer multiplications than the
-    direct-convolution count of SURVEY 8d (12.23 GFLOP); that count and the rate it gives are flat sibling keys
-    (`algorithmic_*`), never a fraction."""
-    tb, tsrc = pmc_traffic(direct=not winograd)
-    red = WINOGRAD_REDUCTION if winograd else 1.0
-    ex = DOMINANT_FLOPS / red
-    e = {"bound": "mfma",
-         "kernel": ("rpn_net k3 128->256 conv, Winograd F(2x2x2,3x3x3) in exact fp32 (binary32 adds + fp32 MFMA, csrc/conv3d_wino.hip)"
-                    if winograd else "rpn_net k3 128->256 conv, direct implicit GEMM (exact fp32 MFMA, csrc/conv3d_t16.hip)"),
-         "achieved": ex / kt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ex / kt / 1e12 / FP32_PEAK_TF,
-         "launch_us": kt * 1e6, "flops_per_launch": ex,
-         "flops_are": "executed MFMA FLOPs (v_mfma_f32_16x16x4_f32 count x 512)",
-         "algorithmic_gflop_per_launch": DOMINANT_FLOPS / 1e9, "algorithmic_tflops": DOMINANT_FLOPS / kt / 1e12,
-         "algorithmic_speedup_vs_direct_count": red,
-         "traffic": tb, "traffic_source": tsrc, "algorithmic_bytes_per_launch": DOMINANT_BYTES,
-         "traffic_ratio": (tb / DOMINANT_BYTES) if tb else None}
-    if winograd and kt_direct > 0:
-        db, dsrc = pmc_traffic(direct=True)
-        e["direct_kernel"] = {"launch_us": kt_direct * 1e6, "achieved": DOMINANT_FLOPS / kt_direct / 1e12,
-                              "frac": DOMINANT_FLOPS / kt_direct / 1e12 / FP32_PEAK_TF, "traffic": db, "traffic_source": dsrc,
-                              "what": "the same layer on the direct fp32 MFMA kernel (ops.set_winograd(False)), same run"}
-    return e
-
-
-def fracs_above_one(obj, path=""):
-    """every key whose name contains 'frac' must be a fraction of a roof: -> list of (path, value) above 1 (tests assert it is empty)"""
-    bad = []
-    if isinstance(obj, dict):
-        for k, v in obj.items():
-            q = path + "." + k if path else k
-            if "frac" in k and isinstance(v, (int, float)) and v > 1.0:
-                bad.append((q, v))
-            bad += fracs_above_one(v, q)
-    elif isinstance(obj, (list, tuple)):
-        for i, v in enumerate(obj):
-            bad += fracs_above_one(v, "%s[%d]" % (path, i))
-    return bad
-
-
-def cpu_model():
-    try:
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("model name"):
-                    return ln.split(":", 1)[1].strip()
-    except Exception:
-        pass
-    return "unknown"
-
-
-def cpu_threads_rule():
-    """ONE stated rule for the CPU baseline's thread count (the 16/32/64/128 sweep moved the figure 2x between
-    boxes): the physical cores of one socket of the host, capped at 64 -- oneDNN's 3D convolutions on a 0.1-GFLOP/voxel chunk stop
-    scaling there, SMT siblings and the second socket only add contention.  SIS3D_CPU_THREADS overrides."""
-    env = os.environ.get("SIS3D_CPU_THREADS")
-    if env:
-        return max(1, int(env)), "SIS3D_CPU_THREADS"
-    cores = os.cpu_count() or 1
-    try:
-        phys, sockets = set(), set()
-        with open("/proc/cpuinfo") as f:
-            pid = cid = None
-            for ln in f:
-                if ln.startswith("physical id"):
-                    pid = ln.split(":")[1].strip()
-                elif ln.startswith("core id"):
-                    cid = ln.split(":")[1].strip()
-                elif not ln.strip():
-                    if pid is not None and cid is not None:
-                        phys.add((pid, cid))
-                        sockets.add(pid)
-                    pid = cid = None
-        if phys:
-            per_socket = max(1, len(phys) // max(1, len(sockets)))
-            return min(64, per_socket), "physical cores of one socket (%d sockets x %d cores, %d logical), capped at 64" % (
-                len(sockets), per_socket, cores)
-    except Exception:
-        pass
-    return min(64, max(1, cores // 2)), "half of the logical CPUs, capped at 64 (no /proc/cpuinfo topology)"
-
-
-def _median_runs(fn, budget_s, min_runs=10, max_runs=200):
-    """median wall time of fn over >= min_runs runs (one untimed warm-up), stopping after budget_s once min_runs are in"""
-    fn()
-    ts, t_end = [], time.time() + budget_s
-    while len(ts) < min_runs or (time.time() < t_end and len(ts) < max_runs):
-        t0 = time.time()
-        fn()
-        ts.append(time.time() - t0)
-    ts.sort()
-    return ts[len(ts) // 2], len(ts), ts[0], ts[-1]
-
-
-def cpu_baseline_reference(workload, sd, cfg, seconds, threads):
-    """BASELINE config[0]: the REFERENCE's own `Network.forward(blobs, 'TEST', [])` (lib/nets/network.py:187-317) timed in place on
-    the host cores -- the README's MAX_VOLUME=0 CPU path in full (`.cuda()` neutralised, the reference's own roi_pooling.c for
-    RoIPoolFunction: oracle/ref_harness.py), same seeded weights and the same synthetic chunk as the GPU run.  Runs from
-    /root/reference in the build container and from the staged archive oracle/_ref/reference_tree.tgz on the GPU box (verified
-    against tests/golden/reference_tree.sha256 by ref_harness).  -> dict | None (reference not available)."""
-    import torch
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    try:
-        import ref_harness as rh
-    except Exception:
-        return None
-    if not rh.available() or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_roi_pooling.so")):
-        return None
-    from sis3d import synthetic
-    use_images = workload == "images"
-    ns = rh.install()
-    try:
-        net = rh.build_net(ns, seed=0, use_images=use_images, use_mask=False)
-        missing = [k for k in net.state_dict() if k not in sd]
-        if missing:
-            return {"error": "reference net has parameters the synthetic checkpoint lacks: %s" % missing[:3]}
-        net.load_state_dict({k: sd[k] for k in net.state_dict()})
-        data = synthetic.synth_chunk(0)
-        if use_images:
-            feats, i3d, i2d = synthetic.synth_views(0)
-            blobs = rh.make_blobs(data, feats, i3d, i2d)
-        else:
-            blobs = rh.make_blobs(data)
-        torch.set_num_threads(threads)
-        per, n, lo, hi = _median_runs(lambda: rh.forward(ns, net, blobs), seconds)
-        rois = int(net._predictions["rois"][0].shape[0]) if "rois" in net._predictions else None
-    finally:
-        rh.restore_cuda()
-    return {"value": VOXELS / per, "unit": "voxels/s", "cores": threads, "kind": "reference", "runs": n,
-            "ms_per_chunk_median": per * 1e3, "ms_per_chunk_min_max": [lo * 1e3, hi * 1e3], "rois": rois,
-            "reference_from": rh.REF_SOURCE,
-            "what": "the reference's unmodified Network.forward TEST branch (backbone + RPN + proposal_layer/cpu_nms + RoI pooling (its own "
-                    "roi_pooling.c) + classifier), torch-CPU operators, on one 96x48x96 synthetic chunk"}
-
-
-def cpu_baseline(workload, sd, cfg, seconds):
-    """CPU baseline beside the GPU number (reported, never the target).  kind "reference" = the reference itself run in place
-    (cpu_baseline_reference) when its tree is available, with the oracle port's figure of the SAME workload beside it under `port`;
-    kind "port" (the oracle, torch-CPU operators = what the reference's MAX_VOLUME=0 path runs) otherwise.  Thread count: one stated
-    rule (cpu_threads_rule), median of >= 10 runs; the single-thread figure and a per-stage table from the
-    port."""
-    import torch
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import sis3d_oracle as orc
-    from sis3d import config, synthetic
-    cores = os.cpu_count() or 1
-    threads, rule = cpu_threads_rule()
-    threads = max(1, min(threads, cores))
-    net = orc.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
-    data = synthetic.synth_chunk(0)
-    feats = i3d = i2d = None
-    if workload == "images":
-        feats, i3d, i2d = synthetic.synth_views(0)
-        if not cfg["USE_IMAGES_GT"]:
-            feats = synthetic.synth_images(0, cfg["NUM_IMAGES"])
-
-    def one():
-        with torch.no_grad():
-            if workload in ("detect", "scene") or not cfg["USE_IMAGES_GT"]:
-                net.forward(data, feats, i3d, i2d)
-            else:
-                imageft = orc.project_views_max(feats, i3d, i2d, data.shape[2:]) if workload == "images" else None
-                l1, l2 = net.backbone(data, imageft)
-                net.rpn(l1, 1)
-                net.rpn(l2, 2)
-
-    def timed(fn, budget, max_n=400):
-        fn()
-        n, t0 = 0, time.time()
-        while True:
-            fn()
-            n += 1
-            if time.time() - t0 >= budget or n >= max_n:
-                break
-        return (time.time() - t0) / n, n
-
-    ref = None
-    try:
-        ref = cpu_baseline_reference(workload, sd, cfg, seconds * 0.35, threads)
-    except Exception as e:                                   # the reported baseline must never take the line down
-        ref = {"error": "%s: %s" % (type(e).__name__, e)}
-    torch.set_num_threads(threads)
-    per, n, lo, hi = _median_runs(one, seconds * (0.25 if ref and "value" in ref else 0.5))
-    # per-stage table at the same thread count, then the whole forward at one thread
-    stages = {}
-    with torch.no_grad():
-        l1, l2 = net.backbone(data, None) if workload != "images" else net.backbone(data, orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
-        o = None
-        if not cfg["USE_IMAGES"]:
-            o = net.forward(data)
-        share = seconds * 0.25 / 6.0
-
-        def st(name, fn, unit_work=VOXELS):
-            d, k = timed(lambda: fn(), share, 50)
-            stages[name] = {"ms": d * 1e3, "threads": threads, "runs": k}
-        if workload != "images":
-            st("backbone", lambda: net.backbone(data, None))
-        st("rpn_convs_heads", lambda: (net.rpn(l1, 1), net.rpn(l2, 2)))
-        if o is not None:
-            levels = []
-            for lid, feat in ((1, l1), (2, l2)):
-                anchors = torch.from_numpy(orc.generate_anchors(feat.shape[2:], net.stride, net.anchor_sizes[lid]))
-                levels.append((lid, o["rpn_cls_prob_level%d" % lid], o["rpn_bbox_pred_level%d" % lid], anchors))
-            tc = cfg["TEST"]
-            st("proposal_layer_cpu_nms", lambda: orc.proposal_layer(levels, tuple(data.shape[2:]), tc["RPN_PRE_NMS_TOP_N"],
-                                                                    tc["RPN_POST_NMS_TOP_N"], tc["RPN_NMS_THRESH"], cfg["ALLOW_BORDER"]))
-            rois, lv = o["rois"][0], o["level_inds"][0]
-            st("roi_pool_c", lambda: net.roi_pool_layer(l1, l2, rois, lv))
-            stages["roi_pool_c"]["rois"] = int(rois.shape[0])
-            if "pool5" in o:
-                st("classifier", lambda: net.classify(o["pool5"]))
-            if any(k.startswith("mask_backbone") for k in net.sd):
-                crop = data[:, :, 8:38, 6:36, 10:46].contiguous()
-                st("mask_head_30x30x36_crop", lambda: net.mask_backbone(crop))
-        if feats is not None:
-            st("projection_view_max", lambda: orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
-    torch.set_num_threads(1)
-    per1, n1 = timed(one, seconds * 0.15, 3)
-    torch.set_num_threads(threads)
-    port = {"value": VOXELS / per, "unit": "voxels/s", "cores": threads, "kind": "port", "runs": n,
-            "ms_per_chunk_median": per * 1e3, "ms_per_chunk_min_max": [lo * 1e3, hi * 1e3],
-            "what": "the pinned oracle (oracle/sis3d_oracle.py: the reference's CPU operators via torch-CPU/oneDNN) on the GPU line's own "
-                    "workload (%s)" % workload}
-    head = ref if (ref and "value" in ref) else port
-    out = dict(value=head["value"], unit="voxels/s", cores=threads, kind=head["kind"], host_cores=cores, cpu=cpu_model(),
-               threads_rule=rule, runs=head["runs"], ms_per_chunk_median=head["ms_per_chunk_median"],
-               ms_per_chunk_min_max=head["ms_per_chunk_min_max"],
-               single_thread={"value": VOXELS / per1, "unit": "voxels/s", "cores": 1, "runs": n1, "kind": "port"},
-               stages=stages, port=port,
-               sample=("%d forward passes of one 96x48x96 chunk; value = MEDIAN of the runs at %d threads (%s); "
-                       % (head["runs"], threads, rule))
-               + ("kind reference: the reference's own Network.forward TEST branch run in place (config[0], full detection pass); "
-                  "`port` = the oracle on the GPU line's workload (%s); " % workload if head is ref else
-                  "kind port: the oracle on the GPU line's workload (%s) -- the reference tree was not available here; " % workload)
-               + "stages: per-stage means of the port at the same thread count; single_thread: %d passes of the port" % n1)
-    if ref is not None:
-        out["reference"] = ref
-    return out
-
-
 def ops_mod():
     from sis3d import ops
     return ops
@@ -736,15 +287,9 @@ def streamed_entry(st, resident_dt, steps, vox_per_step, nfl, world, mode):
             "host_enqueue_ms_per_step": st.get("host_ms_per_step"), "upload_by": st.get("copy"),
             "input": ("encoded (1,2,96,48,96) float32 grid = the reference's blobs['data'] (lib/nets/network.py:191)" if mode == "grid"
                       else "raw float32 SDF block in .chunk file order, TSDF-encoded on the device (sis3d_tsdf_encode; dataset.py:54-70)"),
-            "how": "every step each of the %d pipelines runs a FRESH chunk from pinned host memory.  The pipelines are captured with a "
-                   "mailbox: the first node of a pipeline's graph reads the chunk's host pointer from a ring of slots in pinned memory "
-                   "(CPU stores by the host, no HIP call) and pulls the chunk across PCIe itself (sis3d_mail_upload: 8 workgroups, 256 KB "
-                   "in flight; sdf: + sis3d_tsdf_encode as the second node), so the host's ONLY call per chunk is the graph launch -- a "
-                   "command enqueued behind a graph launch that has not finished can block the host on this runtime.  The loader runs one "
-                   "chunk ahead: a pass's slot also names the pipeline's NEXT chunk, which one more row of workgroups of the pass's rpn_net "
-                   "conv launch pulls across the link into a staging buffer while the pass computes (sis3d_conv3d_k3wino_piggyback: "
-                   "`stage_ahead`), so the next pass starts with a device copy instead of waiting on PCIe; ring of %d distinct host "
-                   "chunks per pipeline; the timed region contains every upload" % (nfl, st["ring"]), "stage_ahead": st.get("stage_ahead")}
+            "how": "every step each of the %d pipelines pulls a FRESH chunk from pinned host memory inside its captured graph (mailbox + "
+                   "piggyback upload, DESIGN.md section 4); ring of %d host chunks per pipeline; every upload is inside the timed region"
+                   % (nfl, st["ring"]), "stage_ahead": st.get("stage_ahead")}
 
 
 def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=False):
@@ -980,6 +525,11 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     barrier()
     dt = time.perf_counter() - t0
     recs, keep = res[0], res[1]
+    if getattr(args, "dump_scene", None) and rank == 0 and group != "solo" and emulate is None and not streamed:
+        # tests/test_gpu_multi.py: the gathered record table and the whole-scene keep list of the LAST timed scene, as rank 0 holds them
+        import numpy as _np
+        _np.savez(args.dump_scene, recs=recs.detach().cpu().numpy(), keep=keep.detach().cpu().numpy(), world=_np.int64(world),
+                  n_chunks=_np.int64(n_chunks), stride=_np.float64(args.scene_stride))
     extra = {"scene_chunks": n_chunks, "scene_stride": args.scene_stride, "chunks_on_this_rank": n_local, "streams_per_gpu": nfl,
              "records_gathered": int(recs.shape[0]), "kept_after_scene_nms": int(keep.numel()),
              "one_graph_launch_per_scene": runner._round is not None and runner._use_round and n_local == nfl,
@@ -1095,6 +645,105 @@ def side_configs(args, rank, world, barrier):
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
     return out
+
+
+def whole_scene_entry(steps=20, dims=(160, 64, 224)):
+    """SURVEY 8(f) row f2 on the line: ONE non-chunked whole-scene grid -- what the reference's benchmark / test
+    modes feed the network when a scene is not cut into chunks (lib/datasets/dataset.py:192-205) -- through the full detection
+    pass (backbone + RPN + proposals + RoI pooling + classifier), captured graph, one grid alone on the GPU"""
+    import torch
+    from sis3d import synthetic
+    from sis3d.engine import ChunkEngine
+    net, cfg, _ = build_net("detect")
+    eng = ChunkEngine(net, dims=dims, stage="detect")
+    eng.load(synthetic.synth_chunk(5, dims))
+    eng.prepare()
+    for _ in range(3):
+        eng.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    nv = dims[0] * dims[1] * dims[2]
+    n = int(eng.out["num"].item())
+    return {"grid": list(dims), "voxels": nv, "ms": ms, "value": nv / (ms * 1e-3), "unit": "voxels/s", "steps": steps, "rois": n,
+            "equivalent_chunks": nv / VOXELS, "how": "one %dx%dx%d grid, full detection pass, captured graph replayed back to back" % dims}
+
+
+def compute_projection_entry(seconds=4.0, dims=(96, 48, 96), views=5):
+    """SURVEY 8(f) row f1 on the line: the device compute_projection (lib/layer_utils/projection.py:52-121: frustum test, depth test,
+    ordered index lists) of `views` depth maps over one chunk grid, beside the CPU restatement of the same function on this box"""
+    import torch
+    from sis3d import config, ops, synthetic
+    from sis3d.layer_utils.projection import ProjectionHelper
+    c = config.scannet_benchmark_cfg()
+    h = ProjectionHelper(c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX, c.DEPTH_SHAPE, list(dims), c.VOXEL_SIZE)
+    depth, c2w, w2g = synthetic.synth_cameras(1, views, dims, c.VOXEL_SIZE)
+    d = depth.cuda()
+    params = torch.stack([h.view_params(c2w[v], w2g[v]) for v in range(views)]).cuda()
+    nvox = dims[0] * dims[1] * dims[2]
+    out = (torch.empty(views, nvox + 1, dtype=torch.int64, device="cuda"), torch.empty(views, nvox + 1, dtype=torch.int64, device="cuda"))
+    run = lambda: ops.compute_projection(d, params, dims, c.DEPTH_SHAPE, c.INTRINSIC, c.PROJ_DEPTH_MIN, c.PROJ_DEPTH_MAX, c.VOXEL_SIZE, out=out)  # noqa: E731
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    e = {"views": views, "grid": list(dims), "us": us, "visible_voxels_per_view": out[0][:, 0].tolist(),
+         "list_write_gbs": 2 * views * (nvox + 1) * 8 / us / 1e3,
+         "how": "%d views over one %dx%dx%d grid: all views in one launch sequence, no host sync, HIP events over 50 calls" % ((views,) + tuple(dims))}
+    try:
+        from benchlib.cpu_baseline import cpu_compute_projection
+        e["cpu"] = cpu_compute_projection(depth, c2w, w2g, c, dims, views, seconds)
+        e["speedup_vs_cpu"] = e["cpu"]["us"] / us
+    except Exception as ex:                                      # the CPU leg must never take the line down
+        e["cpu"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    return e
+
+
+def summary(line):
+    """every scalar result of the line in ONE flat dict under config.summary: the driver keeps `config` whole but only the key NAMES
+    of the other sub-objects and the last 8.8 KB of stdout"""
+    def g(*path):
+        o = line
+        for p in path:
+            if not isinstance(o, dict) or p not in o:
+                return None
+            o = o[p]
+        return round(o, 4) if isinstance(o, float) else o
+    s = {"value_G": round(line["value"] / 1e9, 4), "ms_per_step": round(line["ms_per_step"], 4),
+         "dominant_kernel_us": g("roofline", "launch_us"), "dominant_kernel_frac": g("roofline", "frac"),
+         "traffic_ratio": g("roofline", "traffic_ratio"),
+         "step_fp32_frac": g("step_roofline", "fp32_frac"), "step_hbm_frac": g("step_roofline", "hbm_frac"),
+         "backbone_ms": g("stages", "backbone", "ms"), "backbone_hbm_frac": g("stages", "backbone", "hbm_frac"),
+         "streamed_ratio": g("chunk_pipeline", "streamed", "ratio_to_resident"),
+         "streamed_sdf_ratio": g("chunk_pipeline", "streamed_sdf", "ratio_to_resident"),
+         "scene_ms": g("scene", "ms_per_scene"), "scene_streamed_ratio": g("scene", "streamed", "ratio_to_resident"),
+         "scene_kept": g("scene", "kept_after_scene_nms"), "scene_records": g("scene", "records_gathered"),
+         "share_at_8_ms": g("scene", "share_of_one_rank_at_8", "ms_with_collective"),
+         "ceiling_speedup_at_8": g("scene", "share_of_one_rank_at_8", "ceiling_speedup_at_8"),
+         "whole_scene_ms": g("whole_scene", "ms"), "whole_scene_G": (round(line["whole_scene"]["value"] / 1e9, 4)
+                                                                     if isinstance(line.get("whole_scene"), dict) and "value" in line["whole_scene"] else None),
+         "compute_projection_us": g("compute_projection", "us"), "compute_projection_cpu_us": g("compute_projection", "cpu", "us"),
+         "cpu_baseline_voxels_s": g("cpu_baseline", "value"), "cpu_port_voxels_s": g("cpu_baseline", "port", "value")}
+    for k in ("detect", "detect_masks", "images", "images_rgb"):
+        if isinstance(line.get(k), dict) and "value" in line[k]:
+            s[k + "_G"] = round(line[k]["value"] / 1e9, 4)
+            s[k + "_fp32_frac"] = g(k, "fp32_frac")
+            s[k + "_single_ms"] = g(k, "single_chunk_latency_ms")
+    s["mask_head_ms"] = g("detect_masks", "mask_head_ms")
+    s["mask_head_fp32_frac"] = g("detect_masks", "mask_head_fp32_frac")
+    s["enet_ms_5_views"] = g("images_rgb", "enet_ms_5_views")
+    return {k: v for k, v in s.items() if v is not None}
 
 
 def main(argv=None):
@@ -1242,9 +891,7 @@ def main(argv=None):
                     "ratio_to_resident": sc["dt"] / sc["steps"] / (ss["dt"] / ss["steps"]),
                     "host_bytes_per_scene_per_gpu": n_local * 2 * VOXELS * 4,
                     "records_gathered": ss["extra"]["records_gathered"], "kept_after_scene_nms": ss["extra"]["kept_after_scene_nms"],
-                    "how": "every scene uploads this rank's %d chunks (3.54 MB each, pinned host memory): the first node of each "
-                           "pipeline's captured graph pulls its chunk across PCIe (mailbox slot written by the host, sis3d_mail_upload); "
-                           "the host's only call per chunk is the graph launch" % n_local}
+                    "how": "every scene pulls this rank's %d chunks (3.54 MB each) from pinned host memory inside the pipelines' graphs" % n_local}
             except Exception as e:
                 side["scene"]["streamed"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world > 1 and rank == 0:
@@ -1284,11 +931,8 @@ def main(argv=None):
                 "one_graph_launch_per_scene": sh["extra"]["one_graph_launch_per_scene"],
                 "ceiling_speedup_at_8": (sc["dt"] / sc["steps"] * 1e3) / total_ms,
                 "ceiling_without_collective_term": (sc["dt"] / sc["steps"] * 1e3) / share_ms,
-                "how": "this GPU alone as rank 0 of 8: its scene_chunks/8 chunks (one graph launch), then the merge of the FULL scene's "
-                       "gathered table (its own rows fresh, the other ranks' rows from the 32-chunk run above), PLUS the latency of the "
-                       "scene's one collective measured in an RCCL world of one on this GPU (collective_us_world_of_one; serial in "
-                       "this sum, although on hardware it overlaps with the next scene's detect).  An emulation on one GPU, not a "
-                       "measurement of an 8-GPU run: no xGMI transfer, no launch skew between ranks"}
+                "how": "EMULATION on one GPU of rank 0 of 8: its 4 chunks + the merge of the full gathered table + the all-gather's latency in "
+                       "an RCCL world of one; no xGMI transfer, no skew between ranks"}
     if sc is not None:
         sc.pop("runner", None)                       # the scene's engines and graphs are not needed any more
     if both and rank == 0 and cp.get("wino_flops") is not None:
@@ -1301,45 +945,14 @@ def main(argv=None):
         gc.collect()
         torch.cuda.empty_cache()
         side.update(side_configs(args, rank, world, barrier))
-    if rank == 0 and world == 1 and not args.masks and args.split_line and not args.no_graph:
-        # SEPARATELY REPORTED (never the headline): the headline workload with the balanced k3 convs on the bf16 matrix
-        # pipe, operands split hi + lo (csrc/conv3d_b16.hip); `value` above stays on the exact-fp32 kernels
-        try:
-            ops.set_split_bf16(True)
-            st2 = None
+        for key, fn in (("whole_scene", lambda: whole_scene_entry(max(5, min(args.steps, 20)))),
+                        ("compute_projection", lambda: compute_projection_entry(min(4.0, args.cpu_seconds) if not args.no_cpu_baseline else 0.0))):
             try:
-                if workload == "scene":
-                    r2 = run_scene(net, args, rank, world, args.scene_chunks, barrier, steps=max(3, res["steps"] // 4))
-                else:
-                    r2 = run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=args.masks)
-                    r2["steps"] = args.steps
-                    if stages is not None:
-                        st2 = time_stages(net, {"backbone": 0.0, "backbone_rpn": 0.0})
-            finally:
-                ops.set_split_bf16(False)
-            diffs = {}
-            if res.get("snap") and r2.get("snap"):
-                for k in sorted(res["snap"]):
-                    if k in r2["snap"] and res["snap"][k].shape == r2["snap"][k].shape:
-                        diffs[k] = float((res["snap"][k] - r2["snap"][k]).abs().max())
-            v2 = r2["vox_per_step"] * r2["steps"] / r2["dt"]
-            side["split_bf16"] = {
-                "value": v2, "unit": "voxels/s", "ms_per_step": r2["dt"] / r2["steps"] * 1e3, "steps": r2["steps"],
-                "single_chunk_latency_ms": r2["single_ms"],
-                "speedup_vs_value": v2 / (res["vox_per_step"] * res.get("steps", args.steps) / res["dt"]),
-                "max_abs_diff_vs_fp32_path": diffs,
-                **({"records_gathered": r2["extra"]["records_gathered"], "kept_after_scene_nms": r2["extra"]["kept_after_scene_nms"]}
-                   if workload == "scene" else {}),
-                **({"stages": {k: (v if not isinstance(v, dict) else {"ms": v["ms"], "hbm_frac": v["hbm_frac"], "voxels_per_s": v["voxels_per_s"]})
-                               for k, v in st2.items() if k != "how"}} if st2 else {}),
-                "arithmetic": "k3 convs that run on conv3d_k3t16 (rpn_net x2, geometry2[0], Bottleneck conv2 of the unfused blocks): "
-                              "v_mfma_f32_16x16x32_bf16 on operands split x = hi + lo, products ah*bh + ah*bl + al*bh, fp32 accumulate; "
-                              "everything else exact fp32",
-                "status": "opt-in (ops.set_split_bf16), NOT the headline: not the reference's fp32 arithmetic; parity tests at the "
-                          "unchanged 1e-4 tolerances pass in this mode (tests/test_gpu_conv_b16.py)"}
-        except Exception as e:                       # the separately reported line must never take the headline down
-            ops.set_split_bf16(False)
-            side["split_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                side[key] = fn()
+            except Exception as e:                       # a side measurement must never take the headline down
+                side[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            gc.collect()
+            torch.cuda.empty_cache()
     steps_timed = res.get("steps", args.steps)
     ms = dt / steps_timed * 1e3
     value = res["vox_per_step"] * steps_timed / dt
@@ -1391,6 +1004,7 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        line["config"]["summary"] = summary(line)
         bad = fracs_above_one(line)
         if bad:
             line["frac_errors"] = ["%s = %.3f is not a fraction of a roof" % b for b in bad]

@@ -555,28 +555,6 @@ int sis3d_maxpool3d_3x3x3(const float *in, int X, int Y, int Z, int C, float *ou
 int sis3d_planar_to_cl(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
 int sis3d_cl_to_planar(const float *in, int C, int64_t nvox, float *out, sis3d_stream_t stream);
 
-/* ---------------------------------------------------------------- split-bf16 k3 conv (optional, NOT the default path) --
- * The same Conv3d(k3, p1) + bias (+ ReLU) as sis3d_conv3d_k3t16, computed on the bf16 matrix pipe with every fp32 operand split
- * into hi + lo bf16 and a product taken as ah*bh + ah*bl + al*bh (fp32 accumulation): ~2^-16 relative error per product, i.e. NOT
- * the exact-fp32 arithmetic of the default kernels -- callers opt in per layer (Network.rpn_split_bf16; bench.py --split-bf16
- * reports it as a separate line).  fp32 activations in and out; weights pre-split by sis3d_conv_k3b16_pack_weight (buffer of
- * sis3d_conv_k3b16_packed_floats floats).  cin % 32 == 0.  brick: -1 = chosen by size; 1 = 6x6x6, 2 = 3x6x6 (one 16-cout tile per
- * workgroup); 3 = 6x6x6, 4 = 3x6x6 with two cout tiles per workgroup; 5 = 3x6x6 with four. */
-size_t sis3d_conv_k3b16_packed_floats(int cout, int cin);
-int sis3d_conv_k3b16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);
-int sis3d_conv3d_k3b16(int nprob, const float *const *ins, int X, int Y, int Z, int cin, int cin_stride,
-                       const float *const *packed_ws, const float *const *biases, int cout, int flags, float *const *outs,
-                       int out_stride, int out_coff, int brick, sis3d_stream_t stream);
-/* ragged batch of crops (the mask head), as sis3d_conv3d_k3t16_ragged: descriptors {X,Y,Z,nbx,nby,nbz,block0,pad,in_off,out_off};
- * brick 2 = 3x6x6 with one cout tile per workgroup, 4 = 3x6x6 with two (sis3d_ragged_tiling_k3b16 gives workgroups per brick) */
-/* profiling hook (tools/b16_phases.py): later launches write wall_clock64() of every wave of their first capacity_blocks
- * workgroups at 16 phase boundaries into buf ([workgroup][4 waves][16] int64, device memory); NULL switches it off */
-int sis3d_conv3d_k3b16_set_trace(void *buf, int capacity_blocks);
-int sis3d_ragged_tiling_k3b16(int cin, int cout, int brick, int *bx, int *by, int *bz, int *ngroups);
-int sis3d_conv3d_k3b16_ragged(const float *in, int cin, int cin_stride, const float *packed_w, const float *bias, int cout,
-                              int flags, float *out, int out_stride, const void *desc_dev, int ndesc, int64_t total_blocks,
-                              int brick, sis3d_stream_t stream);
-
 /* ---------------------------------------------------------------- whole-scene merge --
  * New (the reference never chunks a scene; BASELINE config 5 / SURVEY 8e): what follows the all-gather of the per-chunk
  * record blocks.  blocks [n_chunks][1 + k_rows*width] fp32, slot 0 of a block = its valid row count.  The valid rows are
