@@ -188,24 +188,55 @@ __global__ __launch_bounds__(256) void roi_pool_slab_kernel(const float *__restr
     }
 }
 
-// ---- backward (training only).  Replaces ROIPoolBackward (roi_pooling_kernel.cu:137-248): the reference
-// visits EVERY input element and scans all RoIs x bins for argmax == index (O(voxels * R * bins)); the same sum is an atomic
-// scatter of grad_output through the saved argmax.  Sum order differs from the reference's (RoI-major) only in fp32 rounding.
-__global__ __launch_bounds__(256) void roi_pool_backward_kernel(const float *__restrict__ gout, const int32_t *__restrict__ argmax,
-                                                                int64_t total, int C, int nb, int64_t os_n, int64_t os_c, int64_t os_bin,
-                                                                int W, int H, int L, float *__restrict__ gin, int64_t gs_c, int64_t gs_w,
-                                                                int64_t gs_h, int64_t gs_l)
+// ---- backward (training only).  Replaces ROIPoolBackward (roi_pooling_kernel.cu:137-248): the reference visits
+// EVERY input element and scans all RoIs x bins for argmax == index, adding grad_output in (RoI, bin) ascending order.
+// r6 -- DETERMINISTIC and in the reference's order (r2-r5 scattered with float atomics: right to 1e-5, order
+// left to the hardware): a workgroup owns a SLAB of S consecutive voxels x all channels, held in LDS; every lane owns channels
+// (lane, lane + 256, ...) and walks the whole (RoI, bin) list in ascending order -- coalesced argmax rows, eight entries in flight --
+// adding the entries that point into its slab to ITS OWN LDS cells: no atomics, no two lanes on one cell, and each cell's sum is
+// built in exactly the order of the reference's loop (roi_n ascending, pw / ph / pl ascending), so the result is the reference's
+// bit for bit.  The slab is then ADDED to grad_in (the cffi entry point accumulates into the caller's tensor: dropin.py).
+__global__ __launch_bounds__(256) void roi_pool_backward_slab_kernel(const float *__restrict__ gout, const int32_t *__restrict__ argmax,
+                                                                     int64_t nent, int C, int nb, int64_t os_n, int64_t os_c, int64_t os_bin,
+                                                                     int W, int H, int L, int S, float *__restrict__ gin, int64_t gs_c,
+                                                                     int64_t gs_w, int64_t gs_h, int64_t gs_l)
 {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(t % C);
-        const int64_t r = t / C;
-        const int b = (int)(r % nb);
-        const int64_t n = r / nb;
-        const int64_t o = n * os_n + (int64_t)c * os_c + (int64_t)b * os_bin;
-        const int idx = argmax[o];
-        if (idx < 0) continue;                              // empty bin
-        const int l = idx % L, h = (idx / L) % H, w = (idx / (L * H)) % W, cc = idx / (L * H * W);
-        atomicAdd(gin + (int64_t)cc * gs_c + (int64_t)w * gs_w + (int64_t)h * gs_h + (int64_t)l * gs_l, gout[o]);
+    extern __shared__ float slab[];                           // [S][C]
+    const int nsp = W * H * L;
+    const int sp0 = blockIdx.x * S, sp1 = min(sp0 + S, nsp);
+    for (int i = threadIdx.x; i < S * C; i += blockDim.x) slab[i] = 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int64_t oc = (int64_t)c * os_c;
+        const int lo = c * nsp + sp0, hi = c * nsp + sp1;     // this channel's element indices inside the slab (argmax encodes the channel)
+        constexpr int U = 8;
+        int64_t e = 0;
+        for (; e + U <= nent; e += U) {
+            int idx[U];
+            int64_t o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t n = (e + u) / nb;
+                o[u] = n * os_n + oc + (int64_t)((e + u) - n * nb) * os_bin;
+                idx[u] = argmax[o[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)                        // ascending entry order: the reference's summation order
+                if (idx[u] >= lo && idx[u] < hi) slab[(idx[u] - lo) * C + c] += gout[o[u]];
+        }
+        for (; e < nent; ++e) {
+            const int64_t n = e / nb;
+            const int64_t o = n * os_n + oc + (int64_t)(e - n * nb) * os_bin;
+            const int idx = argmax[o];
+            if (idx >= lo && idx < hi) slab[(idx - lo) * C + c] += gout[o];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (sp1 - sp0) * C; i += blockDim.x) {
+        const int c = i % C, sp = sp0 + i / C;
+        const int l = sp % L, h = (sp / L) % H, w = sp / (L * H);
+        float *dst = gin + (int64_t)c * gs_c + (int64_t)w * gs_w + (int64_t)h * gs_h + (int64_t)l * gs_l;
+        *dst = *dst + slab[i];
     }
 }
 
@@ -219,10 +250,14 @@ extern "C" int sis3d_roi_pool_backward(const float *grad_out, const int32_t *arg
     if (R == 0) return SIS3D_OK;
     if (!grad_out || !argmax || !grad_in) return SIS3D_EINVAL;
     const int nb = pw * ph * pl;
-    const int64_t total = (int64_t)R * nb * C;
-    const int64_t blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(roi_pool_backward_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream), grad_out,
-                       argmax, total, C, nb, os_n, os_c, os_bin, W, H, L, grad_in, gs_c, gs_w, gs_h, gs_l);
+    if ((int64_t)C * W * H * L > 0x7fffffffLL) return SIS3D_EUNSUPPORTED;         // argmax is a 32-bit element index
+    // slab: as many voxels as 64 KB of LDS hold for C channels; one workgroup per slab
+    int S = 16384 / C;
+    if (S < 1) return SIS3D_EUNSUPPORTED;
+    if (S > W * H * L) S = W * H * L;
+    const int nslab = cdiv((int64_t)W * H * L, S);
+    hipLaunchKernelGGL(roi_pool_backward_slab_kernel, dim3((unsigned)nslab), dim3(256), (size_t)S * C * sizeof(float), as_stream(stream), grad_out,
+                       argmax, (int64_t)R * nb, C, nb, os_n, os_c, os_bin, W, H, L, S, grad_in, gs_c, gs_w, gs_h, gs_l);
     return sis3d_check_launch();
 }
 

@@ -58,7 +58,7 @@ def roi_pooling_backward_cuda(pooled_width, pooled_height, pooled_length, spatia
     """int roi_pooling_backward_cuda(int,int,int,float, THCudaTensor* top_grad, rois, bottom_grad, THCudaIntTensor* argmax)
     (roi_pooling_cuda.h): OVERWRITES the caller's bottom_grad, as ROIPoolBackward does (`bottom_diff[index] = gradient`,
     roi_pooling_kernel.cu:137-248) -- a reused, non-zeroed buffer gives the reference's result.  The sum over the RoIs that share
-    a voxel is a float atomicAdd here (order varies run to run: last-bit differences)."""
+    a voxel is built in the reference's order (RoI, then bin, ascending; r6: no atomics): the reference's result bit for bit."""
     g = ops.roi_pool_backward(top_grad, argmax, bottom_grad.shape, channels_last=ops.is_cl(bottom_grad))
     bottom_grad.copy_(g)
     return 1

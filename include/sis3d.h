@@ -100,7 +100,9 @@ int sis3d_roi_pool_levels(const float *features1, const float *features2, int C,
 /* backward (training).  Replaces int roi_pooling_backward_cuda(int,int,int,float, THCudaTensor* top_grad,
  * THCudaTensor* rois, THCudaTensor* bottom_grad, THCudaIntTensor* argmax)  (roi_pooling_cuda.h, ROIPoolBackward
  * roi_pooling_kernel.cu:137-248): grad_in[c,w,h,l] += grad_out[n,c,bin] for every (n,c,bin) whose argmax is (c,w,h,l).
- * grad_out / argmax addressed as in sis3d_roi_pool_forward; grad_in: CALLER-ZEROED map with element strides gs_*. */
+ * grad_out / argmax addressed as in sis3d_roi_pool_forward; grad_in: CALLER-ZEROED map with element strides gs_*.
+ * r6: deterministic -- every element's sum is built in the reference's order (RoI ascending, then pw / ph / pl ascending), no
+ * atomics: bit-identical to ROIPoolBackward / the Python RoIPool.backward on the same inputs.  C <= 16384. */
 int sis3d_roi_pool_backward(const float *grad_out, const int32_t *argmax, int R, int C, int pw, int ph, int pl, int64_t os_n,
                             int64_t os_c, int64_t os_bin, int W, int H, int L, float *grad_in, int64_t gs_c, int64_t gs_w,
                             int64_t gs_h, int64_t gs_l, sis3d_stream_t stream);
