@@ -40,33 +40,128 @@ def device_lock(device=None):
     return lk
 
 
-def candidate_streams(count=16, device=None):
-    """up to `count` DISTINCT streams for the chunk pipelines to choose from (("pipe", 0 .. count-1) of the pool); stops early when
-    torch's round-robin pool wraps around onto a stream this pool already holds"""
+# ---- r6: the streams are OURS, and their hardware queues are VERIFIED.  torch.cuda.Stream() hands out streams of a
+# 32-entry pool whose mapping onto HIP's hardware queues depends on everything the process created before; r5 therefore TIMED every
+# window of four pool streams at every start (calibrate()).  A stream created with hipStreamCreateWithPriority is placed by HIP at
+# creation, in creation order; eight of them created together land on min(8, GPU_MAX_HW_QUEUES) queues in a fixed pattern
+# (profiles/r06_own_streams.txt: 8 queues -> 8 classes, 4 queues -> the classes 0 1 2 3 3 2 1 0, identical in every process), and
+# four pipelines on four DISTINCT queues run at the calibrated best (0.733 ms per step on 4 and on 8 queues; any shared queue: 0.89-
+# 0.93).  So: create OWN_STREAMS streams once per device, find out which share a queue (a 1-ms spin on one, a tiny kernel on the
+# other: it waits iff they share -- tools/queue_identity_probe.py's test, ~40 ms once per process), and hand the pipelines streams of
+# pairwise distinct queues, the null stream's queue last.  calibrate() stays as the fallback for a process that cannot get enough
+# queues (and as an A/B tool).
+OWN_STREAMS = 8
+_OWN = {}                # device -> {"streams": [...], "klass": [...], "null_class": int}
+
+
+def _create_own_streams(dev, count):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")                  # the runtime torch has loaded
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi))
+    out = []
+    with torch.cuda.device(dev):
+        torch.cuda.current_stream()                      # HIP initialised, device current
+        for _ in range(count):
+            h = ctypes.c_void_p()
+            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(lo.value))      # 1 = hipStreamNonBlocking
+            if rc != 0 or not h.value:
+                raise ops._lib.Sis3dError("hipStreamCreateWithPriority failed (%d)" % rc)
+            out.append(torch.cuda.ExternalStream(h.value, device=dev))      # never destroyed: the process's streams
+    return out
+
+
+def _queue_classes(dev, streams):
+    """group [null stream] + streams by hardware queue: b shares a's queue iff a tiny kernel on b waits for a spin on a"""
+    import time
+    with torch.cuda.device(dev):
+        x = torch.zeros(64, device="cuda")
+        null = torch.cuda.default_stream()
+        torch.cuda.synchronize()
+        cyc = 200000
+        t0 = time.perf_counter()
+        torch.cuda._sleep(cyc)
+        torch.cuda.synchronize()
+        dt = max(time.perf_counter() - t0, 1e-5)
+        cyc = max(1000, int(cyc * 1e-3 / dt))                  # ~1 ms
+        t0 = time.perf_counter()
+        torch.cuda._sleep(cyc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+
+        def blocked(a, b):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(cyc)
+            with torch.cuda.stream(b):
+                t0 = time.perf_counter()
+                x.add_(1.0)
+                b.synchronize()
+                d = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            return d > 0.5 * dt
+        allst = [null] + list(streams)
+        klass, reps = [], []
+        for i, st in enumerate(allst):
+            for k, r in enumerate(reps):
+                if blocked(allst[r], st):
+                    klass.append(k)
+                    break
+            else:
+                klass.append(len(reps))
+                reps.append(i)
+    return klass[1:], klass[0]
+
+
+def own_streams(device=None):
+    """this device's own streams + the hardware-queue class of each (and of the null stream); created and probed on first use"""
     dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
     with _POOL_LOCK:
-        have = {st.cuda_stream for (d, _, _), st in _STREAM_POOL.items() if d == dev}
-        out = []
-        for j in range(int(count)):
-            key = (dev, "pipe", j)
-            st = _STREAM_POOL.get(key)
-            if st is None:
-                st = torch.cuda.Stream(device=dev)
-                if st.cuda_stream in have:
-                    break                                    # wrapped around: no more distinct streams to be had
-                _STREAM_POOL[key] = st
-                have.add(st.cuda_stream)
-            out.append(st)
-        return out
+        o = _OWN.get(dev)
+        if o is None:
+            with device_lock(dev):
+                st = _create_own_streams(dev, OWN_STREAMS)
+                klass, null_class = _queue_classes(dev, st)
+            o = _OWN[dev] = {"streams": st, "klass": klass, "null_class": null_class}
+        return o
+
+
+def distinct_queue_streams(n, device=None):
+    """n of the device's own streams on pairwise DISTINCT hardware queues (the null stream's queue is taken last), or as many as there
+    are -> (streams, verified: bool)"""
+    o = own_streams(device)
+    order = sorted(range(len(o["streams"])), key=lambda i: (o["klass"][i] == o["null_class"], i))
+    seen, pick = set(), []
+    for i in order:
+        if o["klass"][i] not in seen:
+            seen.add(o["klass"][i])
+            pick.append(i)
+        if len(pick) == n:
+            break
+    if len(pick) < n:                                          # not enough queues: fill up in creation order (they will share)
+        pick += [i for i in range(len(o["streams"])) if i not in pick][:n - len(pick)]
+    return [o["streams"][i] for i in pick[:n]], len(seen) >= n
+
+
+def candidate_streams(count=16, device=None):
+    """the device's own streams in creation order: what calibrate() (the fallback) chooses windows from"""
+    return list(own_streams(device)["streams"])[:int(count)]
 
 
 def pooled_stream(role, index=0, device=None):
+    """streams by ROLE, one set per device: ("pipe", i) = the i-th of the distinct-queue selection; the side roles ("capture", "round",
+    "merge", "copy") take own streams from the END of the list (the queues the pipelines are least likely to sit on)"""
     dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
     key = (dev, role, int(index))
     with _POOL_LOCK:
         st = _STREAM_POOL.get(key)
         if st is None:
-            st = torch.cuda.Stream(device=dev)
+            o = own_streams(dev)
+            if role == "pipe":
+                st = distinct_queue_streams(int(index) + 1, dev)[0][int(index)]
+            else:
+                side = [k for k in _STREAM_POOL if k[0] == dev and k[1] != "pipe"]
+                st = o["streams"][-1 - (len(side) % len(o["streams"]))]
             _STREAM_POOL[key] = st
         return st
 
@@ -382,21 +477,24 @@ def hw_queues():
 _QUEUE_WARNED = set()
 
 
-def check_hw_queues(n_pipelines, strict=None):
-    """r5: n pipelines need n + 2 hardware queues (their streams + the capture / copy stream + the null stream); on fewer, HIP maps
-    streams onto queues round-robin and a pipeline silently serialises behind another one (measured: four in flight 1.80 G voxels/s
-    on 4 queues, 2.28 G on 8 -- profiles/r04_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it cannot be
-    fixed up here: warn once per count (RuntimeWarning), or raise with SIS3D_STRICT_HW_QUEUES=1 / strict=True.  `import sis3d` sets
-    GPU_MAX_HW_QUEUES=8 itself when it is imported before torch has initialised HIP and the variable is unset (sis3d/__init__.py)."""
+def check_hw_queues(n_pipelines, strict=None, verified=None):
+    """n pipelines want n DISTINCT hardware queues.  verified (r6: what engine.distinct_queue_streams found by probing the device's own
+    streams): True -> nothing to check, whatever GPU_MAX_HW_QUEUES says (four own streams sit on four queues of HIP's default four);
+    False -> the process cannot give the pipelines a queue each: two of them will share one and serialise (measured 0.89-0.93 ms per
+    step instead of 0.73) -- RAISE with the fix spelled out when strict / SIS3D_STRICT_HW_QUEUES=1, else warn once per count and let
+    PipelinedEngines.prepare() fall back to its timing calibration.  verified=None (no probe result: a caller that only wants the
+    rule) falls back to the count of queues the environment asks HIP for.  `import sis3d` no longer edits os.environ (r6)."""
     import os
     import warnings
-    # up to three pipelines run as well on HIP's default of four queues (measured: 2.16 G voxels/s on either count)
-    have, need = hw_queues(), (int(n_pipelines) + 2 if n_pipelines >= 4 else 4)
-    if n_pipelines < 2 or have >= need:
+    have = hw_queues()
+    if n_pipelines < 2 or verified is True:
         return True
-    msg = ("sis3d: %d chunk pipelines want GPU_MAX_HW_QUEUES >= %d, this process has %d (HIP default 4): pipelines will share hardware "
-           "queues and serialise -- export GPU_MAX_HW_QUEUES=8 before the process starts (or use <= %d pipelines)"
-           % (n_pipelines, need, have, max(1, have - 1)))
+    if verified is None and have >= (int(n_pipelines) + 2 if n_pipelines >= 4 else 4):
+        return True
+    msg = ("sis3d: %d chunk pipelines need %d distinct hardware queues and this process cannot give them one each (GPU_MAX_HW_QUEUES=%d; "
+           "HIP's default is 4): pipelines will share a queue and serialise.  Fix: export GPU_MAX_HW_QUEUES=8 in the environment of the "
+           "process BEFORE it starts (the HIP runtime reads it once, when it initialises), or use <= %d pipelines"
+           % (n_pipelines, n_pipelines, have, max(1, min(have, n_pipelines) - 1)))
     if strict or (strict is None and os.environ.get("SIS3D_STRICT_HW_QUEUES", "0") not in ("", "0")):
         raise ops._lib.Sis3dError(msg)
     if n_pipelines not in _QUEUE_WARNED:
@@ -428,8 +526,8 @@ class PipelinedEngines:
         bricks = several workgroups per CU, so the pipelines' kernels interleave), none for a single pipeline"""
         cap = (108 if n >= 2 else 0) if brick_cap is None else int(brick_cap)
         self._brick_cap = cap
-        check_hw_queues(n)
-        self.streams = [pooled_stream("pipe", i) for i in range(n)]
+        self.streams, self.placement_verified = distinct_queue_streams(n)
+        check_hw_queues(n, verified=self.placement_verified)
         self.stream_window, self.stream_window_times = 0, {}
         self.engines = []
         for s in self.streams:
@@ -449,8 +547,11 @@ class PipelinedEngines:
                     e.prepare(warmup)
             torch.cuda.synchronize()
             if calibrate is None:
+                # r6: pipelines on verified distinct hardware queues need no timing pass; the fallback is for a process that could
+                # not get them (SIS3D_AUTO_CALIBRATE=1 forces it)
                 import os
-                calibrate = os.environ.get("SIS3D_NO_AUTO_CALIBRATE", "0") in ("", "0")
+                calibrate = (not self.placement_verified and os.environ.get("SIS3D_NO_AUTO_CALIBRATE", "0") in ("", "0")) \
+                    or os.environ.get("SIS3D_AUTO_CALIBRATE", "0") not in ("", "0")
             if calibrate and len(self.engines) >= 2 and all(e.graph is not None for e in self.engines):
                 self.calibrate(self.run, reps=3, warm=1)
         return self

@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE) over the "
                     "dominant kernel at the end of an N = 1 run; `roofline.traffic` then is the committed figure of profiles/")
+    ap.add_argument("--calibrate", action="store_true", help="time every window of the candidate streams and keep the fastest (r5's default; "
+                                                             "since r6 only the fallback when the pipelines' queues could not be verified)")
     ap.add_argument("--no-calibrate", action="store_true", help="keep the pipelines on the first streams of the pool instead of choosing "
                     "the window of streams by measurement (PipelinedEngines.calibrate / SceneRunner.calibrate)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the streamed-input variants (fresh chunks from pinned host memory)")
@@ -99,6 +101,26 @@ def parse(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ launching N ranks --
+
+
+def want_calibration(args, pipes):
+    """r6: pipelines whose streams sit on VERIFIED distinct hardware queues (engine.distinct_queue_streams) are not re-placed by timing;
+    --calibrate forces the r5 behaviour (time every window of the candidate streams), --no-calibrate forbids it"""
+    if args.no_calibrate:
+        return False
+    return bool(args.calibrate) or not getattr(pipes, "placement_verified", False)
+
+
+def stream_placement(pipes):
+    from sis3d import engine
+    try:
+        o = engine.own_streams(pipes.engines[0].device)
+        mine = [o["streams"].index(s) if s in o["streams"] else -1 for s in pipes.streams]
+        return {"verified_distinct_queues": bool(pipes.placement_verified), "own_streams": len(o["streams"]),
+                "queue_class_of_own_streams": o["klass"], "null_stream_class": o["null_class"], "pipelines_on_own_streams": mine,
+                "calibrated": bool(pipes.stream_window_times)}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def scene_origin(c, stride):
@@ -261,7 +283,7 @@ def time_streamed(net, stage, args, rank, nfl, barrier, mode):
             eng.feed(i, ring[i][(k[0] + 1) % RING])
             eng.run_fed(i)
         k[0] += 1
-    if not args.no_calibrate and nfl >= 2:
+    if want_calibration(args, eng) and nfl >= 2:
         preheat(step, min(args.preheat_ms, 60.0))
         eng.calibrate(step, reps=8, warm=2)
     preheat(step, args.preheat_ms)
@@ -324,7 +346,7 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
             else:
                 eng.load(i, data, slot=g)
     eng.prepare(warmup=2)
-    if not args.no_calibrate and nfl >= 2 and not args.no_graph:
+    if want_calibration(args, eng) and nfl >= 2 and not args.no_graph:
         preheat(eng.run, min(args.preheat_ms, 60.0))
         eng.calibrate(eng.run, reps=8, warm=2)
     preheat(eng.run, args.preheat_ms)
@@ -336,7 +358,7 @@ def run_chunk_pipeline(net, cfg, args, rank, world, workload, barrier, masks=Fal
         eng.run()
     barrier()
     dt = time.perf_counter() - t0
-    extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl}
+    extra = {"chunks_per_graph": grp, "streams_per_gpu": nfl, "stream_placement": stream_placement(eng)}
     if eng.stream_window_times:
         extra["stream_window"] = eng.stream_window
         extra["stream_window_ms_per_step"] = {str(k): round(v, 4) for k, v in eng.stream_window_times.items()}
@@ -501,7 +523,7 @@ def run_scene(net, args, rank, world, n_chunks, barrier, group=None, steps=None,
     lazy = not args.masks and not args.no_graph and (n_local == nfl or os.environ.get("SIS3D_BENCH_SCENE_LAZY", "1") == "1")
     if lazy and n_local == nfl:
         runner.prepare_round()              # the one-launch round graph is captured here, not inside the first timed / pipelined call
-    if not args.no_calibrate and not args.no_graph and not args.masks and runner.calibration is None and not streamed:
+    if want_calibration(args, runner.pipes) and not args.no_graph and not args.masks and runner.calibration is None and not streamed:
         runner.infer(chunks, gathered=gathered)
         runner.calibrate(chunks, gathered=gathered, lazy=lazy)
 

@@ -698,3 +698,35 @@ def test_two_threads_prepare_engines_on_one_gpu():
         ref.prepare()
         assert torch.equal(ref.run()["block"], blocks[i]), i
     assert not torch.equal(blocks[0], blocks[1])
+
+
+def test_pipelines_sit_on_verified_distinct_hardware_queues():
+    """r6: the pipelines' streams are created by the engine (hipStreamCreateWithPriority -> ExternalStream) and
+    their hardware queues PROBED: four pipelines get four streams of pairwise distinct queue classes, none of them torch's pool
+    streams, without any timing calibration; the side roles take other own streams; results do not depend on the placement"""
+    from sis3d import engine
+    from sis3d.engine import PipelinedEngines
+    o = engine.own_streams()
+    assert len(o["streams"]) == engine.OWN_STREAMS == len(o["klass"])
+    n_classes = len(set(o["klass"]))
+    assert n_classes >= 4, "this process has fewer than four hardware queues"
+    net, cfg = _small_net()
+    dims = (48, 24, 40)
+    pe = PipelinedEngines(net, 4, dims=dims, stage="detect")
+    assert pe.placement_verified
+    idx = [o["streams"].index(s) for s in pe.streams]
+    assert len({o["klass"][i] for i in idx}) == 4
+    if n_classes > 4:
+        assert all(o["klass"][i] != o["null_class"] for i in idx)      # the null stream's queue is taken last
+    for i in range(4):
+        pe.load(i, synthetic.synth_chunk(30 + i, dims))
+    pe.prepare()
+    assert not pe.stream_window_times, "no timing calibration when the placement is verified"
+    a = [d["block"].clone() for d in pe.run()]
+    torch.cuda.synchronize()
+    best, times = pe.calibrate(pe.run, reps=1, warm=1)                    # the fallback still works and changes nothing
+    b = [d["block"].clone() for d in pe.run()]
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and len(times) >= 2
+    side = engine.pooled_stream("capture", 0)
+    assert side in o["streams"]
