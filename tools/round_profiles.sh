@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 judged artefacts in ONE gpurun call (one profile refresh per round, not three):
+# Round-6 judged artefacts in ONE gpurun call (one profile refresh per round):
 #   full GPU suite with the [parity] log, the driver-style bench line, rocprofv3 kernel stats + per-grid tables (four chunks in flight
 #   and one chunk alone; detect and images-from-RGB alone), the dominant kernel from the trace, the N = 2 functional line on one GPU,
 #   PMC passes of the dominant (Winograd) kernel and the HBM table of the memory-bound kernels.
 #   usage: bash tools/round_profiles.sh <tag> [nosuite]      -> gpurun_out/<tag>/   (copy what is judged into profiles/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 MODE=${2:-full}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -38,6 +38,8 @@ prof backbone_rpn --workload backbone_rpn
 prof backbone_rpn_inflight1 --workload backbone_rpn --inflight 1
 prof detect_inflight1 --workload detect --inflight 1
 prof images_rgb_inflight1 --workload images --rgb --inflight 1
+prof detect --workload detect
+prof detect_masks_inflight1 --workload detect --masks --inflight 1
 cd "$ROOT"
 # PMC: counters only with --kernel-trace, FETCH_SIZE and WRITE_SIZE in their own passes (MI355X_MICROARCH.md)
 bash tools/wino_pmc.sh "$TAG/wino_pmc" rpn > "$OUT/wino_pmc.log" 2>&1
