@@ -1,15 +1,15 @@
 #!/bin/bash
 # copy what is judged from gpurun_out/<tag>/ (tools/round_profiles.sh) into profiles/ under the round's prefix
-#   usage: bash tools/collect_profiles.sh r05
+#   usage: bash tools/collect_profiles.sh r06
 set -eu
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 S=$ROOT/gpurun_out/$TAG
 P=$ROOT/profiles
 python "$ROOT/tools/hbm_table.py" --table "$S/hbm" > "$S/hbm/hbm_kernels.json"
 cp "$S/bench_driver_style.json" "$P/${TAG}_bench_driver_style.json"
 cp "$S/bench_n2_shared_gpu_functional.json" "$P/${TAG}_bench_n2_shared_gpu_functional.json"
-for n in backbone_rpn backbone_rpn_inflight1 detect_inflight1 images_rgb_inflight1; do
+for n in backbone_rpn backbone_rpn_inflight1 detect detect_inflight1 detect_masks_inflight1 images_rgb_inflight1; do
   cp "$S/bench_${n}_by_grid.md" "$P/${TAG}_bench_${n}_by_grid.md"
 done
 cp "$S/bench_backbone_rpn_kernel_stats.csv" "$P/${TAG}_bench_backbone_rpn_kernel_stats.csv"
