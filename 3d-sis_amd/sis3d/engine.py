@@ -450,6 +450,11 @@ class ChunkEngine:
     def run(self):
         """one pass over the chunk(s) currently in the static buffers; returns the (static) output dict (list of dicts
         for group > 1)"""
+        if self.mail is not None and self.mail_input == "sdf" and self.graph is not None and (self._slot is None or self._slot[0] is None):
+            # ADVICE r5: an sdf-mode mailbox engine encodes its input from the slot's source on EVERY pass; load() + run() would
+            # re-encode the previous chunk's staged SDF block over what load() wrote
+            raise ops._lib.Sis3dError("run(): an engine with mail_input='sdf' takes its chunk through submit(src=...) / run_fed(); "
+                                      "load() + run() is not a path it has")
         with torch.no_grad():
             if self.rgb and self.graph is not None:
                 if self.enet_graph is not None:
@@ -552,7 +557,8 @@ class PipelinedEngines:
                 import os
                 calibrate = (not self.placement_verified and os.environ.get("SIS3D_NO_AUTO_CALIBRATE", "0") in ("", "0")) \
                     or os.environ.get("SIS3D_AUTO_CALIBRATE", "0") not in ("", "0")
-            if calibrate and len(self.engines) >= 2 and all(e.graph is not None for e in self.engines):
+            sdf_fed = any(e.mail is not None and e.mail_input == "sdf" for e in self.engines)      # no pass without a source: the caller calibrates on its feed
+            if calibrate and len(self.engines) >= 2 and all(e.graph is not None for e in self.engines) and not sdf_fed:
                 self.calibrate(self.run, reps=3, warm=1)
         return self
 

@@ -722,11 +722,13 @@ def test_pipelines_sit_on_verified_distinct_hardware_queues():
         pe.load(i, synthetic.synth_chunk(30 + i, dims))
     pe.prepare()
     assert not pe.stream_window_times, "no timing calibration when the placement is verified"
-    a = [d["block"].clone() for d in pe.run()]
-    torch.cuda.synchronize()
+    outs = pe.run()
+    torch.cuda.synchronize()                                              # the static outputs are written on the pipelines' streams
+    a = [d["block"].clone() for d in outs]
     best, times = pe.calibrate(pe.run, reps=1, warm=1)                    # the fallback still works and changes nothing
-    b = [d["block"].clone() for d in pe.run()]
+    outs = pe.run()
     torch.cuda.synchronize()
+    b = [d["block"].clone() for d in outs]
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and len(times) >= 2
     side = engine.pooled_stream("capture", 0)
     assert side in o["streams"]
