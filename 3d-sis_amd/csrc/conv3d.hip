@@ -26,6 +26,7 @@
 //
 // This file may use FMA freely (fp32 tolerance 1e-4 applies, not bit-exactness).
 #include "common.h"
+#include "mfma16.h"
 #include <stdlib.h>
 #include <atomic>
 
@@ -915,6 +916,95 @@ __global__ __launch_bounds__(256) void conv_planar2_ragged_kernel(const float *_
     }
 }
 
+// r6: the same layer on the matrix pipe, for the mask head's 64 output channels.  The 54 taps of a voxel are the K dimension (padded to
+// 56 = 14 MFMAs of K=4), a wave owns 16 consecutive packed voxels x all 64 couts: D^T[cout][voxel] = W[cout][k] * X^T[k][voxel], the
+// transposed tile GEMM of mfma16.h, so a lane ends with 4 consecutive couts of one voxel (one 16 B store per cout tile).  A lane
+// (voxel l16, kq) gathers 14 taps instead of the 54 of the FMA kernel above, and the weights sit in 56 registers per lane (read from
+// LDS once per wave) instead of one ds_read_b128 per 4 FMAs -- that LDS traffic, not the FMAs, bounded the kernel above (22.2 us for
+// the 16-box batch of bench.py --workload detect --masks; this one: profiles/r06_mask_head_first_last_layer_ab.txt).
+constexpr int PL_MAXD = 128;
+__global__ __launch_bounds__(256) void conv_planar2_ragged_mfma_kernel(const float *__restrict__ in, int64_t is_c, int64_t is_x, int64_t is_y,
+                                                                       const PlanarDesc *__restrict__ desc, int ndesc, int64_t nvox_total,
+                                                                       const float *__restrict__ w, int flags, float *__restrict__ out,
+                                                                       int out_stride)
+{
+    constexpr int K = 54, KK = 14, CO = 64, WS = CO + 1;          // WS: padded row of the LDS weight table (k-major writes without conflicts)
+    __shared__ float wl[4 * KK * WS];
+    __shared__ PlanarDesc dl[PL_MAXD];
+    __shared__ int2 tap[4 * KK];                                   // tap k: its 32-bit offset from the voxel's own cell, (ddx, ddy, ddz) packed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+    if (tid < 4 * KK) {
+        const int kc = tid < K ? tid : K - 1;                      // k = 54, 55: zero weights, any valid tap
+        const int r = kc % 27, ddx = r / 9, ddy = (r / 3) % 3, ddz = r % 3;
+        tap[tid] = make_int2((kc / 27) * (int)is_c + (ddx - 1) * (int)is_x + (ddy - 1) * (int)is_y + (ddz - 1), ddx | (ddy << 2) | (ddz << 4));
+    }
+    for (int i = tid; i < CO * 4 * KK; i += 256) {                 // checkpoint layout (Cout, 2, 3, 3, 3): rows of 54, read along k
+        const int co = i / (4 * KK), k = i % (4 * KK);
+        wl[k * WS + co] = k < K ? w[co * K + k] : 0.0f;
+    }
+    const bool dlds = ndesc <= PL_MAXD;
+    if (dlds) for (int i = tid; i < ndesc; i += 256) dl[i] = desc[i];
+    __syncthreads();
+    const int64_t ntiles = (nvox_total + 15) / 16;
+    // decode the lane's voxel (32-bit arithmetic: the launcher checks the sizes) and issue its 14 tap loads
+    auto gather = [&](int64_t tile, float (&x)[KK], int64_t &ooff, bool &live) {
+        const int64_t gv0 = tile * 16 + l16;
+        live = gv0 < nvox_total;
+        const int64_t gv = live ? gv0 : nvox_total - 1;
+        const int64_t key = gv * (CO / 4);                        // desc[i].t0 counts (voxel, 4-channel) items as the host packs them
+        int lo = 0, hi = ndesc - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const int64_t t0 = dlds ? dl[mid].t0 : desc[mid].t0;
+            if (t0 <= key) lo = mid; else hi = mid - 1;
+        }
+        const PlanarDesc d = dlds ? dl[lo] : desc[lo];
+        const unsigned v = (unsigned)(gv - d.t0 / (CO / 4));
+        const unsigned t = v / (unsigned)d.dz, uox = t / (unsigned)d.dy;
+        const int oz = (int)(v - t * (unsigned)d.dz), oy = (int)(t - uox * (unsigned)d.dy), ox = (int)uox;
+        ooff = d.out_off + (int64_t)v * out_stride;
+        const float *centre = in + ((d.x0 + ox) * (int)is_x + (d.y0 + oy) * (int)is_y + (d.z0 + oz));
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int2 tp = tap[4 * kk + q];
+            const unsigned wx = (unsigned)(ox + (tp.y & 3) - 1), wy = (unsigned)(oy + ((tp.y >> 2) & 3) - 1), wz = (unsigned)(oz + (tp.y >> 4) - 1);
+            const bool ok = wx < (unsigned)d.dx && wy < (unsigned)d.dy && wz < (unsigned)d.dz;          // zero padding at the WINDOW border
+            const float tv = centre[ok ? tp.x : 0];           // a padded tap reads the voxel's own cell (always valid) and drops it
+            x[kk] = ok ? tv : 0.0f;
+        }
+    };
+    float x[KK];
+    int64_t ooff;
+    bool live;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntiles) gather(tile, x, ooff, live);                // in flight while the weights come out of LDS
+    float wr[KK][4];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wr[kk][n] = wl[(4 * kk + q) * WS + 16 * n + l16];
+    while (tile < ntiles) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[kk][n], x[kk], acc[n], 0, 0, 0);
+        float *o = out + ooff + 4 * q;
+        const bool st = live;
+        tile += (int64_t)gridDim.x * 4;
+        if (tile < ntiles) gather(tile, x, ooff, live);            // the next tile's taps fly under the stores
+        if (st) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float4 r = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+                *reinterpret_cast<float4 *>(o + 16 * n) = relu4(r, flags & SIS3D_EPI_RELU);
+            }
+        }
+    }
+}
+
 extern "C" int sis3d_ragged_tiling(int cin, int cout, int ksize, int *bx, int *by, int *bz, int *ngroups)
 {
     if (!bx || !by || !bz || !ngroups) return SIS3D_EINVAL;
@@ -953,6 +1043,14 @@ extern "C" int sis3d_conv3d_planar2_ragged(const float *in, int64_t is_c, int64_
                                            sis3d_stream_t stream)
 {
     if (!in || !w || !out || !desc_dev || ndesc <= 0 || total_items <= 0 || cout <= 0 || (cout % 4) || (out_stride % 4)) return SIS3D_EINVAL;
+    static const bool fma_only = [] { const char *e = getenv("SIS3D_PLANAR_FMA"); return e && atoi(e) != 0; }();      // A/B hook
+    if (cout == 64 && !fma_only && 2 * is_c < 0x7fffffff && is_x < is_c && is_y < is_c && total_items / 16 < 0x7fffffff) {     // 32-bit offsets
+        const int64_t nvox = total_items / 16, tiles = (nvox + 15) / 16;     // a wave per 16-voxel tile
+        const unsigned blocks = (unsigned)((tiles + 3) / 4 < 768 ? (tiles + 3) / 4 : 768);       // 3 waves per SIMD (VGPRs)
+        hipLaunchKernelGGL(conv_planar2_ragged_mfma_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), in, is_c, is_x, is_y,
+                           (const PlanarDesc *)desc_dev, ndesc, nvox, w, flags, out, out_stride);
+        return sis3d_check_launch();
+    }
     const int64_t items = total_items / (cout / 4) * ((cout + 15) / 16);     // threads: one per (voxel, 16 output channels)
     const unsigned blocks = (unsigned)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
     hipLaunchKernelGGL(conv_planar2_ragged_kernel, dim3(blocks), dim3(256), sizeof(float) * 54 * cout, as_stream(stream), in, is_c, is_x,

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
         });
     }
     const bool relu1 = a.flags1 & SIS3D_EPI_RELU, relu2 = a.flags2 & SIS3D_EPI_RELU;
+    const bool sig1 = a.flags1 & SIS3D_EPI_SIGMOID;             // r6: the mask head's last 1x1x1 conv (backbones.py:286), stage 1 only
     const int nmt = (a.nvox + 15) / 16;
     const int first = WS == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     const int step = WS == 1 ? gridDim.x * 4 : gridDim.x;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void pw16_kernel(const PwArgs a)
             t.x = acc[n][0] + bb1[n].x + r[n].x; t.y = acc[n][1] + bb1[n].y + r[n].y;
             t.z = acc[n][2] + bb1[n].z + r[n].z; t.w = acc[n][3] + bb1[n].w + r[n].w;
             z[n] = relu4(t, relu1);
+            if (sig1) z[n] = make_float4(1.0f / (1.0f + expf(-z[n].x)), 1.0f / (1.0f + expf(-z[n].y)), 1.0f / (1.0f + expf(-z[n].z)), 1.0f / (1.0f + expf(-z[n].w)));
             if (ok && a.out) *reinterpret_cast<float4 *>(a.out + (size_t)v * a.out_stride + a.out_coff + 16 * (t1_0 + n) + 4 * q) = z[n];
         });
         if constexpr (NT2 > 0) {
@@ -387,7 +389,8 @@ extern "C" int sis3d_conv3d_pw16(const float *in, int64_t nvox, int cin, int cin
     if ((cin_stride % 4) || cin_stride < cin || (out_stride % 4) || (out_coff % 4) || (res_stride % 4)) return SIS3D_EINVAL;
     if (!out && cout2 == 0) return SIS3D_EINVAL;
     if (cout2 > 0 && (!packed_w2 || !out2 || (out2_stride % 4) || out2_stride < cout2)) return SIS3D_EINVAL;
-    if ((flags & ~(SIS3D_EPI_RELU | SIS3D_EPI_RESIDUAL)) || (flags2 & ~SIS3D_EPI_RELU)) return SIS3D_EUNSUPPORTED;
+    if ((flags & ~(SIS3D_EPI_RELU | SIS3D_EPI_RESIDUAL | SIS3D_EPI_SIGMOID)) || (flags2 & ~SIS3D_EPI_RELU)) return SIS3D_EUNSUPPORTED;
+    if ((flags & SIS3D_EPI_SIGMOID) && cout2 > 0) return SIS3D_EUNSUPPORTED;          // the sigmoid ends a chain
     if ((flags & SIS3D_EPI_RESIDUAL) && !residual) return SIS3D_EINVAL;
     PwArgs a;
     a.in = in; a.in_stride = cin_stride; a.w1p = packed_w; a.b1 = bias;

@@ -23,7 +23,8 @@ class _Packed(object):
         w, b = conv.weight, conv.bias
         ver = (w._version, None if b is None else b._version, w.data_ptr())
         if self.pc is None or self.pc.version != ver:
-            self.pc = ops.PackedConv(w, b, cin_pad)
+            # k1: also the pw16 pack with cout padded to whole 16-row tiles (r6: the mask head's last conv runs on the pointwise kernel)
+            self.pc = ops.PackedConv(w, b, cin_pad, pad_cout16=(w.shape[2] == 1))
         return self.pc
 
 

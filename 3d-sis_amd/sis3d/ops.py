@@ -1019,12 +1019,15 @@ class PackedConv:
         self.bias = _dev(bias.detach(), "bias").contiguous().clone() if bias is not None else None
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
         # 1x1x1: second pack for the register-chained pointwise kernels (csrc/pointwise.hip): [cout/16][cin/16][64][4]
-        self.packed_pw16 = None
+        self.packed_pw16, self.bias16 = None, None
         if k == 1 and self.cin % 16 == 0 and (self.cout % 16 == 0 or pad_cout16) and not PW_LEGACY:
             npw = lib().sis3d_conv_pw16_packed_floats(self.cout, self.cin)
             self.packed_pw16 = torch.empty(npw, device=w.device)
             check(lib().sis3d_conv_pw16_pack_weight(_ptr(w), self.cout, self.cin, _ptr(self.packed_pw16), _stream()),
                   "sis3d_conv_pw16_pack_weight")
+            if self.cout % 16 and self.bias is not None:          # bias rows of the appended zero couts (sis3d_conv3d_pw16 reads whole tiles)
+                self.bias16 = torch.zeros((self.cout + 15) // 16 * 16, device=w.device)
+                self.bias16[:self.cout] = self.bias
         # k2 s2: the same register-chained kernel with 8 gathered rows (column index tap*Cin + ci)
         if k == 2 and self.cin % 16 == 0 and self.cout % 16 == 0 and not PW_LEGACY:
             w2 = w.permute(0, 2, 3, 4, 1).reshape(self.cout, 8 * self.cin).contiguous()
@@ -1459,9 +1462,17 @@ class MaskPlan:
         self.g3t, self.g3w, self.g3m = self.devbuf[o3:o4], self.devbuf[o5:o6], self.devbuf[o6:]       # (part 4 was the split-bf16 table, removed in r6)
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
-        self.out = torch.empty(self.voxels, NC, device=device)
+        # the last layer's rows padded to whole 16-cout tiles (the pointwise kernel stores 16 B per lane); `out` = the (voxels, NC) view
+        self.out_pad = torch.empty(self.voxels, (NC + 15) // 16 * 16, device=device) if NC <= 32 else None
+        self.out = self.out_pad[:, :NC] if self.out_pad is not None else torch.empty(self.voxels, NC, device=device)
         # 2 FLOP per MAC: conv0 (2 -> C, k3), four C -> C k3 convs, the C -> NC k1 head
         self.flops = 2.0 * self.voxels * (54 * C + 4 * 27 * C * C + C * NC)
+
+    def out_dense(self):
+        """a contiguous (voxels, NC) output for the kernels that need one (the generic ragged 1x1x1 fallback)"""
+        self.out_pad = None
+        self.out = torch.empty(self.voxels, self.NC, device=self.a.device)
+        return self.out
 
     def views(self):
         res, voff = [], 0
@@ -1499,9 +1510,18 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
             check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(plan.g3), n,
                                             plan.blocks, _stream()), "sis3d_conv3d_ragged")
         src, dst = dst, src
-    if NC <= 32:
+    NCP = plan.out_pad.shape[1] if plan.out_pad is not None else 0
+    if NCP and pc_last.packed_pw16 is not None and not PW_LEGACY and lib().sis3d_conv3d_pw16(
+            _ptr(src), plan.voxels, C, C, _ptr(pc_last.packed_pw16), _ptr(pc_last.bias16 if pc_last.cout % 16 else pc_last.bias), NCP,
+            EPI_SIGMOID if sigmoid else 0, None, 0, _ptr(plan.out_pad), NCP, 0, None, None, 0, 0, None, 0, _stream()) == 0:
+        # r6: a 1x1x1 conv does not see the crop structure -- the packed crops are one list of voxel rows for the register-chained
+        # pointwise kernel (csrc/pointwise.hip; 11.6 -> ~5 us for the 16-box batch); its rows are padded to whole 16-cout tiles,
+        # plan.out is the (voxels, NC) view of them
+        pass
+    elif NC <= 32:
+        out_c = plan.out if plan.out.is_contiguous() else plan.out_dense()
         check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
-                                        _ptr(plan.out), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
+                                        _ptr(out_c), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
     else:
         # a 1x1x1 conv does not see the crop structure: the packed buffer is one (voxels x 1 x 1) channels-last activation
         # (the 64-feature output of the geometry stack under MASK_USE_IMAGES, lib/nets/backbones.py:246)

@@ -374,7 +374,7 @@ int sis3d_conv3d_pw_chain(const float *in, int X, int Y, int Z, int cin, int cin
  *     out2 = epi2(W2 out + b2)                       optional (cout2 > 0)
  * in: nvox rows of cin_stride floats (channels-last activations of ANY grid, flattened).  packed_w / packed_w2 from
  * sis3d_conv_pw16_pack_weight (checkpoint layout (Cout,Cin[,1,1,1]) -> [cout/16][cin/16][64][4]).  flags: SIS3D_EPI_RELU |
- * SIS3D_EPI_RESIDUAL; flags2: SIS3D_EPI_RELU.  SIS3D_EUNSUPPORTED for (cin, cout, cout2) combinations that are not
+ * SIS3D_EPI_RESIDUAL | SIS3D_EPI_SIGMOID (r6: applied last, only without a second stage); flags2: SIS3D_EPI_RELU.  SIS3D_EUNSUPPORTED for (cin, cout, cout2) combinations that are not
  * instantiated (callers fall back to sis3d_conv3d_pw_chain / sis3d_conv3d). */
 size_t sis3d_conv_pw16_packed_floats(int cout, int cin);
 int sis3d_conv_pw16_pack_weight(const float *w, int cout, int cin, float *packed, sis3d_stream_t stream);

@@ -161,6 +161,32 @@ def test_register_chained_pointwise_vs_torch_cpu(ops, cin, cout, cnext, dims):
     assert bool((wide[:, :16] == 5.0).all()) and bool((wide[:, 16 + cout:] == 5.0).all())
 
 
+@pytest.mark.parametrize("cin,nc", [(64, 19), (128, 19), (64, 32), (64, 21)])
+def test_pointwise_sigmoid_head_with_padded_couts_vs_torch_cpu(ops, cin, nc):
+    """r6: the mask head's last layer (Conv3d(64, NUM_CLASSES, 1) + sigmoid, lib/nets/backbones.py:247 + network.py:312) on the
+    register-chained pointwise kernel: couts padded to whole 16-row tiles (zero weight rows, zero bias), sigmoid in the epilogue;
+    rows of the padded output beyond NUM_CLASSES hold sigmoid(0) = 0.5 and are never viewed"""
+    g = torch.Generator().manual_seed(cin + nc)
+    nvox = 1237                                                    # ragged last 16-voxel tile
+    x = torch.randn(nvox, cin, generator=g)
+    w, b = _w(nc, cin, 1, g), torch.randn(nc, generator=g) * 0.1
+    pc = ops.PackedConv(w.cuda(), b.cuda(), pad_cout16=True)
+    assert pc.packed_pw16 is not None and (nc % 16 == 0 or pc.bias16.numel() == 32)
+    ncp = (nc + 15) // 16 * 16
+    out = torch.full((nvox, ncp), 7.0, device="cuda")
+    xc = x.cuda()
+    rc = ops.lib().sis3d_conv3d_pw16(xc.data_ptr(), nvox, cin, cin, pc.packed_pw16.data_ptr(), (pc.bias16 if nc % 16 else pc.bias).data_ptr(),
+                                     ncp, ops.EPI_SIGMOID, None, 0, out.data_ptr(), ncp, 0, None, None, 0, 0, None, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = torch.sigmoid(x @ w.view(nc, cin).t() + b)
+    assert (out[:, :nc].cpu() - want).abs().max().item() <= TOL
+    assert bool((out[:, nc:] == 0.5).all())
+    # a sigmoid cannot feed a chained second stage
+    assert ops.lib().sis3d_conv3d_pw16(xc.data_ptr(), nvox, 64, 64, pc.packed_pw16.data_ptr(), None, 32, ops.EPI_SIGMOID, None, 0, out.data_ptr(),
+                                       ncp, 0, pc.packed_pw16.data_ptr(), None, 32, 0, out.data_ptr(), 32, None) != 0
+
+
 def test_plain_k1_conv_routes_through_pw16_and_matches_legacy(ops):
     g = torch.Generator().manual_seed(77)
     x = cl(torch.randn(1, 128, 24, 12, 24, generator=g))
