@@ -124,12 +124,9 @@ __global__ __launch_bounds__(256) void roi_pool_slab_kernel(const float *__restr
     const float lv = levels[n];
     const float *feat = lv == 1.0f ? f1 : f2;
     const bool live = lv == 1.0f || lv == 2.0f;
-    RoiGeom g = {0, 0, 0, 0.f, 0.f, 0.f};
+    const RoiGeom g = roi_geom(rois + 6 * n, scale, PW, PH, PL);   // read beside the level (one round trip, not two); unused when !live
     int ws = 0, we = 0;
-    if (live) {
-        g = roi_geom(rois + 6 * n, scale, PW, PH, PL);
-        bin_range(pw, g.bw, g.rs_w, W, ws, we);
-    }
+    if (live) bin_range(pw, g.bw, g.rs_w, W, ws, we);
     const int nb = PH * PL;
     for (int b0 = 4 * wave; b0 < nb; b0 += 16) {
         int hs[4], ls[4], nh[4], nl[4], nwin[4];
@@ -153,17 +150,25 @@ __global__ __launch_bounds__(256) void roi_pool_slab_kernel(const float *__restr
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int e = 0; e < V; ++e) mx[k][e] = nwin[k] > 0 ? -FLT_MAX : 0.0f;
+        // r6: the window is walked with three carried counters per bin (wave-uniform: scalar adds and compares) -- the flat-index
+        // form divided three times per voxel, ~1,600 instructions per step of 16 loads, and THAT was the kernel's 11 us
+        int cw[4], chh[4], cll[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cw[k] = ws; chh[k] = hs[k]; cll[k] = ls[k]; }
         for (int i0 = 0; i0 < maxwin; i0 += 4) {
             vec v[4][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int i = min(i0 + j, max(nwin[k] - 1, 0));
-                    const int hl = max(nh[k] * nl[k], 1), nlk = max(nl[k], 1);
-                    const int w = ws + i / hl, h = hs[k] + (i / nlk) % max(nh[k], 1), l = ls[k] + i % nlk;
                     const bool ok = nwin[k] > 0;
-                    v[k][j] = *reinterpret_cast<const vec *>(feat + (ok ? (int64_t)w * fs_w + (int64_t)h * fs_h + (int64_t)l * fs_l : 0) + V * lane);
+                    v[k][j] = *reinterpret_cast<const vec *>(feat + (ok ? (int64_t)cw[k] * fs_w + (int64_t)chh[k] * fs_h + (int64_t)cll[k] * fs_l : 0) + V * lane);
+                    if (i0 + j + 1 < nwin[k]) {                    // next voxel in w -> h -> l order; the last one is re-read, never passed
+                        if (++cll[k] == ls[k] + nl[k]) {
+                            cll[k] = ls[k];
+                            if (++chh[k] == hs[k] + nh[k]) { chh[k] = hs[k]; ++cw[k]; }
+                        }
+                    }
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k)

@@ -15,7 +15,12 @@ sys.path.insert(0, os.path.join(ROOT, "3d-sis_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from sis3d import ops, synthetic  # noqa: E402
 from sis3d.engine import PipelinedEngines  # noqa: E402
-from launch_probe import build_net, VOX  # noqa: E402
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def build_net():
+    return bench.build_net("detect")[0]
 
 
 def timed(step, chunks, label, steps=200):
