@@ -629,6 +629,9 @@ def conv3d_pw16(x, pc, residual=None, relu=True, out=None, out_coff=0, stage=Non
     (sis3d_conv3d_pw16).  -> (main | None, stage_out | None); raises Sis3dUnsupported for shapes without an instantiation."""
     if pc.packed_pw16 is None or (stage is not None and stage["pc"].packed_pw16 is None):
         raise Sis3dUnsupported("no pw16 pack for this layer")
+    if pc.cout % 16 or (stage is not None and stage["pc"].cout % 16):
+        # packs with zero rows appended (pad_cout16: the RPN heads, the mask head's last layer) belong to the callers that own a padded output
+        raise Sis3dUnsupported("pw16 pack padded to whole cout tiles")
     _, cin_t, X, Y, Z = x.shape
     od = (X, Y, Z)
     if cin_t != pc.cin:

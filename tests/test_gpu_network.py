@@ -262,6 +262,16 @@ def test_mask_head_batched_equals_per_box(oracle):
         worst = max(worst, float((g - single).abs().max()))
     assert worst <= 1e-5
     report("mask head, 6 crops: Winograd ragged batch vs direct per-box launches, max |diff| on the sigmoid outputs %.1e" % worst)
+    # training mode returns the raw logits (backbones.py:286-287 applies the sigmoid only when not self.training): the last layer then
+    # runs WITHOUT the sigmoid epilogue, per box (generic kernel: its pack is padded to 32 couts for the batch) and batched
+    net.mask_backbone.train()
+    try:
+        raw1 = net.mask_backbone(data.cuda(), None, window=wins[0])
+        rawb = net.mask_backbone.forward_batched(data.cuda(), wins)[0]
+    finally:
+        net.mask_backbone.eval()
+    assert (torch.sigmoid(raw1) - got[0]).abs().max() <= 1e-5 and (torch.sigmoid(rawb) - got[0]).abs().max() <= 1e-5
+    assert float(raw1.min()) < 0.0                                  # logits, not probabilities
     # r4: the batch above ran on MINI geometry (quads of 4 x 4 x 4 bricks); the 8 x 4 x 8-block launch computes the same tiles in another
     # grouping -> bit-identical outputs, with fewer work items
     assert plan.wino_mini and plan.items_mini < plan.blocks_wino
