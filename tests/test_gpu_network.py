@@ -287,6 +287,25 @@ def test_mask_head_batched_equals_per_box(oracle):
     assert net.mask_backbone.forward_batched(data.cuda(), []) == []
 
 
+def test_mask_head_batch_of_more_crops_than_the_lds_descriptor_table():
+    """r6: the first (planar) layer's MFMA kernel keeps up to 128 crop descriptors in LDS and reads them from global memory beyond that:
+    150 small crops in one batch == the same crops in two batches of 75 (same arithmetic per voxel: bit-identical)"""
+    cfg = config.scannet_benchmark_cfg()
+    net, _ = build(cfg)
+    net.mask_backbone.eval()
+    data = synthetic.synth_chunk(6).cuda()
+    g = torch.Generator().manual_seed(11)
+    wins = []
+    for _ in range(150):
+        d = torch.randint(1, 8, (3,), generator=g).tolist()
+        o = [int(torch.randint(0, hi - dd + 1, (1,), generator=g)) for hi, dd in zip((96, 48, 96), d)]
+        wins.append((o[0], o[1], o[2], o[0] + d[0], o[1] + d[1], o[2] + d[2]))
+    whole = [t.clone() for t in net.mask_backbone.forward_batched(data, wins)]
+    halves = [t.clone() for t in net.mask_backbone.forward_batched(data, wins[:75])] + \
+             [t.clone() for t in net.mask_backbone.forward_batched(data, wins[75:])]
+    assert len(whole) == 150 and all(torch.equal(a, b) for a, b in zip(whole, halves))
+
+
 @pytest.mark.parametrize("dims", [(70, 46, 58), (128, 64, 40)])
 def test_whole_scene_odd_grid_vs_oracle(oracle, dims):
     """the reference's benchmark mode convolves whole (non-chunked) scene grids of arbitrary size
