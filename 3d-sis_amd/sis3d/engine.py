@@ -72,34 +72,46 @@ def _create_own_streams(dev, count):
 
 
 def _queue_classes(dev, streams):
-    """group [null stream] + streams by hardware queue: b shares a's queue iff a tiny kernel on b waits for a spin on a"""
-    import time
+    """group [null stream] + streams by hardware queue: b shares a's queue iff a tiny kernel on b cannot finish while a spins.
+    Timed on the DEVICE (events on both streams), so a stalled host thread cannot fake a free queue: a kernel that finished inside the
+    spin was not behind it.  The opposite reading -- finished after the spin -- is also what a host stall between the two launches
+    looks like, so it only counts when three trials in a row say so."""
     with torch.cuda.device(dev):
         x = torch.zeros(64, device="cuda")
         null = torch.cuda.default_stream()
         torch.cuda.synchronize()
+
+        def spin_ms(cycles):                                   # device-side duration of the spin kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda._sleep(cycles)
+            e1.record()
+            torch.cuda.synchronize()
+            return max(e0.elapsed_time(e1), 1e-3)
+        spin_ms(1000)                                          # the first launches load their code objects: not measurements
+        x.add_(1.0)
         cyc = 200000
-        t0 = time.perf_counter()
-        torch.cuda._sleep(cyc)
-        torch.cuda.synchronize()
-        dt = max(time.perf_counter() - t0, 1e-5)
-        cyc = max(1000, int(cyc * 1e-3 / dt))                  # ~1 ms
-        t0 = time.perf_counter()
-        torch.cuda._sleep(cyc)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        for _ in range(4):                                     # ~1 ms, re-measured: a spin that came out short would make every reading marginal
+            ms = spin_ms(cyc)
+            if 0.7 <= ms <= 1.5:
+                break
+            cyc = max(1000, int(cyc / ms))
 
         def blocked(a, b):
-            torch.cuda.synchronize()
-            with torch.cuda.stream(a):
-                torch.cuda._sleep(cyc)
-            with torch.cuda.stream(b):
-                t0 = time.perf_counter()
-                x.add_(1.0)
-                b.synchronize()
-                d = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            return d > 0.5 * dt
+            for _ in range(3):
+                torch.cuda.synchronize()
+                sa, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                with torch.cuda.stream(a):
+                    sa.record()
+                    torch.cuda._sleep(cyc)
+                    ea.record()
+                with torch.cuda.stream(b):
+                    x.add_(1.0)
+                    eb.record()
+                torch.cuda.synchronize()
+                if sa.elapsed_time(eb) < 0.5 * sa.elapsed_time(ea):
+                    return False
+            return True
         allst = [null] + list(streams)
         klass, reps = [], []
         for i, st in enumerate(allst):
@@ -121,7 +133,10 @@ def own_streams(device=None):
         if o is None:
             with device_lock(dev):
                 st = _create_own_streams(dev, OWN_STREAMS)
-                klass, null_class = _queue_classes(dev, st)
+                for _ in range(2):                             # fewer classes than pipelines: probe once more before believing it
+                    klass, null_class = _queue_classes(dev, st)
+                    if len(set(klass)) >= 4:
+                        break
             o = _OWN[dev] = {"streams": st, "klass": klass, "null_class": null_class}
         return o
 

@@ -709,10 +709,14 @@ def test_pipelines_sit_on_verified_distinct_hardware_queues():
     o = engine.own_streams()
     assert len(o["streams"]) == engine.OWN_STREAMS == len(o["klass"])
     n_classes = len(set(o["klass"]))
-    assert n_classes >= 4, "this process has fewer than four hardware queues"
     net, cfg = _small_net()
     dims = (48, 24, 40)
     pe = PipelinedEngines(net, 4, dims=dims, stage="detect")
+    if n_classes < 4:
+        # a process the runtime gives fewer than four hardware queues (GPU_MAX_HW_QUEUES < 4, or a probe that read shared queues):
+        # the engine must SAY so -- prepare() then falls back to the timing calibration -- and this test has nothing to verify
+        assert not pe.placement_verified
+        pytest.skip("fewer than four distinct hardware queues in this process: %s (null %s)" % (o["klass"], o["null_class"]))
     assert pe.placement_verified
     idx = [o["streams"].index(s) for s in pe.streams]
     assert len({o["klass"][i] for i in idx}) == 4
