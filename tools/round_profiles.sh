@@ -3,7 +3,7 @@
 #   full GPU suite with the [parity] log, the driver-style bench line, rocprofv3 kernel stats + per-grid tables (four chunks in flight
 #   and one chunk alone; detect and images-from-RGB alone), the dominant kernel from the trace, the N = 2 functional line on one GPU,
 #   PMC passes of the dominant (Winograd) kernel and the HBM table of the memory-bound kernels.
-#   usage: bash tools/round_profiles.sh <tag> [nosuite]      -> gpurun_out/<tag>/   (copy what is judged into profiles/)
+#   usage: bash tools/round_profiles.sh <tag> [nosuite|tail]      -> gpurun_out/<tag>/   (copy what is judged into profiles/)
 set -u
 TAG=${1:-r06}
 MODE=${2:-full}
@@ -21,7 +21,7 @@ if [ "$MODE" = full ]; then
 fi
 timeout 500 python bench.py --steps 20 --warmup 5 2> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_driver_style.json"
 # N = 2 ranks on this one GPU (gloo instead of RCCL): the N-rank code path end to end -- a functional line, not a measurement
-SIS3D_BENCH_SHARE_GPU=1 timeout 500 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-live-pmc 2> "$OUT/bench_n2.err" | tail -1 > "$OUT/bench_n2_shared_gpu_functional.json"
+[ "$MODE" != tail ] && SIS3D_BENCH_SHARE_GPU=1 timeout 500 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-live-pmc 2> "$OUT/bench_n2.err" | tail -1 > "$OUT/bench_n2_shared_gpu_functional.json"
 cd /tmp && export TMPDIR=/tmp
 prof() {   # prof <name> <bench args...>: kernel trace + stats -> by-grid table
   local name=$1; shift
@@ -34,6 +34,14 @@ prof() {   # prof <name> <bench args...>: kernel trace + stats -> by-grid table
   [ -n "$t" ] && python "$ROOT/tools/trace_by_grid.py" "$t" > "$OUT/bench_${name}_by_grid.md"
   [ -n "$t" ] && [ "$name" = backbone_rpn ] && python "$ROOT/tools/dominant_from_trace.py" "$t" "$OUT/bench_${name}_under_rocprof.json" > "$OUT/dominant_kernel_from_trace.json"
 }
+if [ "$MODE" = tail ]; then      # only the tables of the detection tail and the mask head (kernels changed after the round's refresh)
+  prof detect_inflight1 --workload detect --inflight 1
+  prof detect --workload detect
+  prof detect_masks_inflight1 --workload detect --masks --inflight 1
+  cd "$ROOT"
+  python tools/show_line.py "$OUT/bench_driver_style.json"
+  exit 0
+fi
 prof backbone_rpn --workload backbone_rpn
 prof backbone_rpn_inflight1 --workload backbone_rpn --inflight 1
 prof detect_inflight1 --workload detect --inflight 1
