@@ -128,10 +128,12 @@ def cpu_baseline(workload, sd, cfg, seconds):
         if not cfg["USE_IMAGES_GT"]:
             feats = synthetic.synth_images(0, cfg["NUM_IMAGES"])
 
+    views = feats                                            # what one() feeds the net (the stage table re-binds feats under --rgb)
+
     def one():
         with torch.no_grad():
             if workload in ("detect", "scene") or not cfg["USE_IMAGES_GT"]:
-                net.forward(data, feats, i3d, i2d)
+                net.forward(data, views, i3d, i2d)
             else:
                 imageft = orc.project_views_max(feats, i3d, i2d, data.shape[2:]) if workload == "images" else None
                 l1, l2 = net.backbone(data, imageft)
@@ -158,6 +160,12 @@ def cpu_baseline(workload, sd, cfg, seconds):
     # per-stage table at the same thread count, then the whole forward at one thread
     stages = {}
     with torch.no_grad():
+        if workload == "images" and not cfg["USE_IMAGES_GT"]:
+            # --rgb: the views are RGB images; the stage table below starts from the encoder's feature maps (network.py:203-205)
+            rgb = feats
+            feats = orc.enet_features(sd, rgb)
+            d, k = timed(lambda: orc.enet_features(sd, rgb), seconds * 0.05, 5)
+            stages["enet_encoder_5_views"] = {"ms": d * 1e3, "threads": threads, "runs": k}
         l1, l2 = net.backbone(data, None) if workload != "images" else net.backbone(data, orc.project_views_max(feats, i3d, i2d, data.shape[2:]))
         o = None
         if not cfg["USE_IMAGES"]:

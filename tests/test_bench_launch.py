@@ -117,3 +117,19 @@ def test_hardware_queues_and_chunks_in_flight(monkeypatch):
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.index('os.environ.setdefault("GPU_MAX_HW_QUEUES"') < src.index("def parse(")        # before anything can import torch
     assert "\nimport torch" not in src.split("def parse(")[0]
+
+
+def test_cpu_baseline_of_the_rgb_workload_times_the_encoder_too():
+    """`bench.py --workload images --rgb`: the CPU baseline's views are RGB images; its stage table starts from the oracle's ENet feature
+    maps (r6: it fed the RGB views to the 128-channel colour branch and took the line down)"""
+    from sis3d import config, synthetic
+    from sis3d.nets import backbones
+    from benchlib.cpu_baseline import cpu_baseline
+    cfg = config.scannet_benchmark_cfg()
+    cfg.USE_IMAGES, cfg.USE_IMAGES_GT, cfg.USE_MASK = True, False, False
+    net = backbones.ScanNet_Backbone(cfg=cfg)
+    net.init_modules()
+    sd = synthetic.synth_checkpoint({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0)
+    r = cpu_baseline("images", sd, cfg, 1.0)
+    assert r["value"] > 0 and r["port"]["value"] > 0
+    assert {"enet_encoder_5_views", "rpn_convs_heads", "projection_view_max"} <= set(r["stages"])
