@@ -8,7 +8,8 @@
 // with BatchNorm (eval) and the torch7-style dropout scale folded into the weights on the host (sis3d/nets/enet_hip.py).
 // Activations are pixels x channels (NHWC) rows; a wave owns 16 consecutive pixels and runs the transposed tile GEMM of mfma16.h
 // (D^T[cout][pixel] = W[cout][k] X^T[k][pixel]) whose result is the operand layout of the next GEMM, so the three convolutions
-// chain through registers.  Weights are A operands read straight from L2 in the pw16 lane order [cout/16][cin/16][64][4].
+// chain through registers.  Weights are A operands in the pw16 lane order [cout/16][cin/16][64][4]; since r4 a workgroup's four waves
+// share ONE copy of them in LDS (LDS-DMA, one L2 round trip together with the tap / skip rows, biases and slopes: enet_block_kernel).
 // The two stride-2 projections (2x2, stride 2) and the initial block (3x3 stride-2 conv || 2x2 max-pool, concatenated) have their
 // own small kernels.  fp32 throughout; the summation order differs from MIOpen's, results agree to ~1e-6 of the feature scale.
 #include "common.h"
