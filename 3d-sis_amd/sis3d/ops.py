@@ -1466,16 +1466,12 @@ class MaskPlan:
         self.a = torch.empty(self.voxels, C, device=device)
         self.b = torch.empty(self.voxels, C, device=device)
         # the last layer's rows padded to whole 16-cout tiles (the pointwise kernel stores 16 B per lane); `out` = the (voxels, NC) view
-        self.out_pad = torch.empty(self.voxels, (NC + 15) // 16 * 16, device=device) if NC <= 32 else None
+        # (sis3d_conv3d_pw16 is instantiated for 64 / 128 -> 32 couts: 17..32 classes; other heads keep the dense rows of the generic kernel)
+        ncp = (NC + 15) // 16 * 16
+        self.out_pad = torch.empty(self.voxels, ncp, device=device) if (ncp == 32 and C in (64, 128) and not PW_LEGACY) else None
         self.out = self.out_pad[:, :NC] if self.out_pad is not None else torch.empty(self.voxels, NC, device=device)
         # 2 FLOP per MAC: conv0 (2 -> C, k3), four C -> C k3 convs, the C -> NC k1 head
         self.flops = 2.0 * self.voxels * (54 * C + 4 * 27 * C * C + C * NC)
-
-    def out_dense(self):
-        """a contiguous (voxels, NC) output for the kernels that need one (the generic ragged 1x1x1 fallback)"""
-        self.out_pad = None
-        self.out = torch.empty(self.voxels, self.NC, device=self.a.device)
-        return self.out
 
     def views(self):
         res, voff = [], 0
@@ -1513,18 +1509,19 @@ def mask_head_run(scene, plan, w0, pcs, pc_last, sigmoid=True):
             check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc.packed), _ptr(pc.bias), C, 3, EPI_RELU, _ptr(dst), C, _ptr(plan.g3), n,
                                             plan.blocks, _stream()), "sis3d_conv3d_ragged")
         src, dst = dst, src
-    NCP = plan.out_pad.shape[1] if plan.out_pad is not None else 0
-    if NCP and pc_last.packed_pw16 is not None and not PW_LEGACY and lib().sis3d_conv3d_pw16(
-            _ptr(src), plan.voxels, C, C, _ptr(pc_last.packed_pw16), _ptr(pc_last.bias16 if pc_last.cout % 16 else pc_last.bias), NCP,
-            EPI_SIGMOID if sigmoid else 0, None, 0, _ptr(plan.out_pad), NCP, 0, None, None, 0, 0, None, 0, _stream()) == 0:
+    if plan.out_pad is not None and pc_last.packed_pw16 is not None:
         # r6: a 1x1x1 conv does not see the crop structure -- the packed crops are one list of voxel rows for the register-chained
-        # pointwise kernel (csrc/pointwise.hip; 11.6 -> ~5 us for the 16-box batch); its rows are padded to whole 16-cout tiles,
-        # plan.out is the (voxels, NC) view of them
-        pass
+        # pointwise kernel (csrc/pointwise.hip; 11.6 -> 6.2 us for the 16-box batch); its rows are padded to whole 16-cout tiles
+        # (MaskPlan.out_pad), plan.out is the (voxels, NC) view of them
+        NCP = plan.out_pad.shape[1]
+        check(lib().sis3d_conv3d_pw16(_ptr(src), plan.voxels, C, C, _ptr(pc_last.packed_pw16), _ptr(pc_last.bias16 if pc_last.cout % 16 else pc_last.bias),
+                                      NCP, EPI_SIGMOID if sigmoid else 0, None, 0, _ptr(plan.out_pad), NCP, 0, None, None, 0, 0, None, 0, _stream()),
+              "sis3d_conv3d_pw16")
     elif NC <= 32:
-        out_c = plan.out if plan.out.is_contiguous() else plan.out_dense()
+        if plan.out_pad is not None:                               # a plan built for the pointwise kernel, weights without its pack
+            raise _lib.Sis3dError("mask head: the last layer has no pw16 pack (SIS3D_PW_LEGACY set after the plan was built?)")
         check(lib().sis3d_conv3d_ragged(_ptr(src), C, C, _ptr(pc_last.packed), _ptr(pc_last.bias), NC, 1, EPI_SIGMOID if sigmoid else 0,
-                                        _ptr(out_c), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
+                                        _ptr(plan.out), NC, _ptr(plan.g1), n, plan.blocks, _stream()), "sis3d_conv3d_ragged")
     else:
         # a 1x1x1 conv does not see the crop structure: the packed buffer is one (voxels x 1 x 1) channels-last activation
         # (the 64-feature output of the geometry stack under MASK_USE_IMAGES, lib/nets/backbones.py:246)

@@ -287,6 +287,26 @@ def test_mask_head_batched_equals_per_box(oracle):
     assert net.mask_backbone.forward_batched(data.cuda(), []) == []
 
 
+@pytest.mark.parametrize("classes", [9, 26, 40])
+def test_mask_head_last_layer_routes_by_class_count(oracle, classes):
+    """the batched mask head's last layer: 17..32 classes (ScanNet 19, SUNCG 26) run on the pointwise kernel with rows padded to 32
+    couts, fewer (9) on the generic ragged 1x1x1 kernel with dense rows, more (40) through ops.conv3d -- all three == the oracle"""
+    from sis3d import ops
+    cfg = config.scannet_benchmark_cfg()
+    cfg.NUM_CLASSES = classes
+    net, sd = build(cfg, seed=2)
+    on = oracle.OracleNet(sd, cfg, config.anchor_sizes(cfg, 1), config.anchor_sizes(cfg, 2))
+    data = synthetic.synth_chunk(7)
+    wins = [(10, 5, 20, 22, 25, 33), (0, 0, 0, 8, 10, 9), (80, 30, 70, 96, 48, 96), (40, 10, 40, 71, 33, 59)]
+    plan = ops.MaskPlan(wins, 64, classes, torch.device("cuda"))
+    assert (plan.out_pad is not None) == (16 < classes <= 32)
+    net.mask_backbone.eval()
+    got = net.mask_backbone.forward_batched(data.cuda(), wins)
+    for w, g in zip(wins, got):
+        want = on.mask_backbone(data[:, :, w[0]:w[3], w[1]:w[4], w[2]:w[5]])
+        assert g.shape == want.shape and (g.cpu() - want).abs().max() <= TOL
+
+
 def test_mask_head_batch_of_more_crops_than_the_lds_descriptor_table():
     """r6: the first (planar) layer's MFMA kernel keeps up to 128 crop descriptors in LDS and reads them from global memory beyond that:
     150 small crops in one batch == the same crops in two batches of 75 (same arithmetic per voxel: bit-identical)"""
