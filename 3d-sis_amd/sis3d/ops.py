@@ -1376,7 +1376,7 @@ class MaskPlan:
             best = None
             forced = int(_os.environ.get("SIS3D_MASK_BRICK", "-1"))        # tuning hook
             # 3x6x6, 4x4x4, 4x4x8, 3x3x6: least estimated SIMD time wins (6x6x6 = brick 1 exists but measured slower on 9-20 voxel crops:
-            # 0.58 vs 0.48 ms for the 16-box batch, tools/mask_time.py)
+            # 0.58 vs 0.48 ms for the 16-box batch, measured in r3)
             for brick in ((forced,) if forced >= 0 else (2, 4, 5, 3)):
                 tb = [ctypes.c_int() for _ in range(5)]
                 if lib().sis3d_ragged_tiling_k3t16(C, C, brick, *[ctypes.byref(v) for v in tb]) != 0:
