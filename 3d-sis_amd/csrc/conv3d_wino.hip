@@ -277,10 +277,10 @@ __device__ __forceinline__ f32x2 pk_bt_hi(f32x2 a, f32x2 b)
     return r;
 }
 
-// r6 -- STAGING THE RAW BRICK BY LDS-DMA (a [slot][4 channels] brick read with ds_read2_b32: no staging registers, no LDS stores, no halo
-// zero-fill) was built and measured at the end of the round and is not in: bit-identical, 18-35 % slower on every shape -- an LDS-DMA
-// instruction whose 64 lanes read 64 different channels-last rows holds the issue path ~0.1 us, where the U fill's contiguous 1 KB
-// pieces cost 11-16 ns and the same rows through global_load_dwordx4 ~11 ns (profiles/r06_raw_staging_dma_probe.txt).
+// r6 -- A [slot][4 channels] RAW BRICK (what an LDS-DMA staging of the channels-last rows leaves in LDS; z pairs read with ds_read2_b32)
+// was built at the end of the round, with LDS-DMA staging and with the register staging below, and is not in: bit-identical, 18-35 %
+// slower either way -- the LDS serves ds_read2 as 16-lane groups on banks mod 32, where 16-byte slots leave the 16 tiles only 8 distinct
+// banks (profiles/r06_raw_staging_dma_probe.txt).  The channel-major brick and its conflict-free ds_read_b64 stay.
 // r6 -- a PERSISTENT WORK LOOP (a launch of fewer workgroups than work items, workgroup b taking items b, b + G, ...: VERDICT r5 item 2)
 // was built and measured and is not in: same binary, same box, items strided over 216 workgroups against one workgroup per item
 // (profiles/r06_wino_persistent_loop_ab.txt): rpn_net pair 96.8 against 95.7 us, four problems 177.9 / 178.6, 32 -> 32 @48x24x48 x2
