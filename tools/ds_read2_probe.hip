@@ -7,6 +7,9 @@
 // and the staging side of the same question, per step and lane (reads of kind A / B included):
 //   D  today: 3 global_load_dwordx4 into registers, 12 (v_add address + ds_write_b32) one step later      (+ A's reads)
 //   E  LDS-DMA: 3 global_load_lds_dwordx4, nothing else                                                     (+ B's reads)
+// CAVEAT (profiles/r06_raw_staging_dma_probe.txt): B looks as cheap as A HERE, where nothing else uses the LDS and nothing waits for the rows;
+// in the kernel (16 ds_read_b128 of U per step beside them, the transform waiting for its rows) the same ds_read2_b32 reads made every shape
+// 18-35 % slower -- they conflict four-way inside the LDS's 16-lane groups.  A microbenchmark of instruction ISSUE, not of LDS throughput.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ds_read2_probe.hip -o tools/_bin/ds_read2_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
